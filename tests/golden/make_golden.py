@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the REFERENCE on CPU.
+
+Run in the build container only (the reference lives at /root/reference and never
+travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What this script does
+  * puts /root/reference on sys.path (read-only use, no bytecode written),
+  * installs in-process stand-ins for packages the container lacks and that the
+    reference imports at module level (pytorch_lightning, torchvision, cv2, imageio,
+    PIL).  They only have to make the `import` lines succeed; none of their code is on
+    the hot path,
+  * installs the 6-line `models.networks.cost_volume_net.CostVolumeLayer` stand-in
+    (that module is imported by the reference but missing from it):
+    CostVolumeLayer(d).forward(f1, f2) == compute_cost_volume(f1, f2, d).  THIS IS OUR
+    DEFINITION and is recorded in every fixture's metadata,
+  * runs the hot-path ops on small seeded inputs and writes `*.npz` files next to this
+    script: inputs, outputs and gradients (data only - no reference source).
+
+Whole-network fixtures use an RNG-free weight rule (`rngfree_fill`, restated in
+tests/golden_util.py) so the 10-40 MB of weights never have to be stored.
+"""
+import sys
+import os
+import types
+import math
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("OCFLOW_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(HERE))  # tests/ for golden_util
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from golden_util import rngfree_fill, smooth_field  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+# ----------------------------------------------------------------------------- stubs
+def _install_stubs():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(nn.Module):
+        global_step = 0
+        current_epoch = 0
+        logger = None
+
+        def log(self, *a, **k):
+            pass
+
+    pl.LightningModule = LightningModule
+    pl.Trainer = object
+    pl.seed_everything = lambda s: torch.manual_seed(s)
+    sys.modules["pytorch_lightning"] = pl
+    for name in ("pytorch_lightning.loggers", "pytorch_lightning.callbacks"):
+        sys.modules[name] = types.ModuleType(name)
+
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.utils = types.ModuleType("torchvision.utils")
+    tv.transforms.Compose = tv.transforms.ToTensor = tv.transforms.Normalize = object
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tv.models
+    sys.modules["torchvision.transforms"] = tv.transforms
+    sys.modules["torchvision.utils"] = tv.utils
+
+    for name in ("cv2", "imageio"):
+        m = types.ModuleType(name)
+        m.imread = None
+        sys.modules[name] = m
+    try:
+        import PIL  # noqa: F401
+    except Exception:
+        pil = types.ModuleType("PIL")
+        pil.Image = types.ModuleType("PIL.Image")
+        sys.modules["PIL"] = pil
+        sys.modules["PIL.Image"] = pil.Image
+
+    # the module the reference imports but does not ship
+    from models.networks.correlation_layer import compute_cost_volume
+
+    cvn = types.ModuleType("models.networks.cost_volume_net")
+
+    class CostVolumeLayer(nn.Module):
+        def __init__(self, max_displacement=4):
+            super().__init__()
+            self.max_displacement = max_displacement
+
+        def forward(self, f1, f2):
+            return compute_cost_volume(f1, f2, self.max_displacement)
+
+    cvn.CostVolumeLayer = CostVolumeLayer
+    sys.modules["models.networks.cost_volume_net"] = cvn
+
+
+_install_stubs()
+
+from models.networks.correlation_layer import compute_cost_volume, normalize_features  # noqa: E402
+from models.networks.cost_volume_flow_net import FlowNetCV  # noqa: E402
+import models.model as ref_model  # noqa: E402
+from models.flow_model import FlowModel  # noqa: E402
+from models.flow_occ_model import FlowOccModel  # noqa: E402
+from models.data.utils import flow_utils as ref_flow_utils  # noqa: E402
+
+META = dict(
+    reference="dongliangcao/OCFlow @ /root/reference",
+    torch=torch.__version__,
+    cost_volume_layer="CostVolumeLayer(d).forward(f1,f2) := compute_cost_volume(f1,f2,d) (our stand-in for the missing module)",
+)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    out["_meta"] = np.array(repr(META))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items() if k != "_meta"})
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------ 1. cost volume (a1)
+def gold_corr():
+    cases = {"a": ((2, 8, 6, 7), 1), "b": ((2, 8, 6, 7), 4), "c": ((1, 32, 12, 20), 4), "d": ((1, 5, 3, 4), 2)}
+    arrs = {}
+    for tag, (shape, d) in cases.items():
+        f1 = torch.randn(shape, generator=g(11)).requires_grad_()
+        f2 = torch.randn(shape, generator=g(12)).requires_grad_()
+        out = compute_cost_volume(f1, f2, d)
+        cot = torch.randn(out.shape, generator=g(13))
+        gf1, gf2 = torch.autograd.grad(out, (f1, f2), cot)
+        arrs.update({f"{tag}_f1": f1, f"{tag}_f2": f2, f"{tag}_d": np.int64(d), f"{tag}_out": out,
+                     f"{tag}_cot": cot, f"{tag}_gf1": gf1, f"{tag}_gf2": gf2})
+    save("corr", **arrs)
+
+
+# ------------------------------------------------------------ 2. feature normalise (a3)
+def gold_norm():
+    f1 = (torch.randn((2, 16, 5, 6), generator=g(21)) * 2 + 0.3).requires_grad_()
+    f2 = (torch.randn((2, 16, 5, 6), generator=g(22)) * 0.5 - 1.0).requires_grad_()
+    n1, n2 = normalize_features([f1, f2])
+    c1 = torch.randn(n1.shape, generator=g(23))
+    c2 = torch.randn(n2.shape, generator=g(24))
+    gf1, gf2 = torch.autograd.grad((n1 * c1).sum() + (n2 * c2).sum(), (f1, f2))
+    save("norm", f1=f1, f2=f2, n1=n1, n2=n2, c1=c1, c2=c2, gf1=gf1, gf2=gf2)
+
+
+# ------------------------------------------------------------------- 3. warps (a4, a5)
+def gold_warp():
+    arrs = {}
+    shapes = {"main": (2, 5, 13, 17), "h1": (1, 3, 1, 9), "w1": (1, 3, 7, 1), "s22": (2, 4, 2, 2), "s11": (1, 2, 1, 1)}
+    for tag, shape in shapes.items():
+        B, C, H, W = shape
+        img = torch.randn(shape, generator=g(31)).requires_grad_()
+        flow = (torch.randn((B, 2, H, W), generator=g(32)) * 3.0).requires_grad_()
+        cot = torch.randn(shape, generator=g(33))
+        # AC-False: the in-network feature warp  (cost_volume_flow_net.py:121-151)
+        o0 = FlowNetCV.warp(None, img, flow)
+        gi0, gf0 = torch.autograd.grad(o0, (img, flow), cot)
+        # AC-True: the loss-side image warp       (flow_model.py:49-79)
+        o1 = FlowModel.warp(None, img, flow)
+        gi1, gf1 = torch.autograd.grad(o1, (img, flow), cot)
+        arrs.update({f"{tag}_img": img, f"{tag}_flow": flow, f"{tag}_cot": cot,
+                     f"{tag}_out_ac0": o0, f"{tag}_gimg_ac0": gi0, f"{tag}_gflow_ac0": gf0,
+                     f"{tag}_out_ac1": o1, f"{tag}_gimg_ac1": gi1, f"{tag}_gflow_ac1": gf1})
+    save("warp", **arrs)
+
+
+# ---------------------------------------------------------------- 4. losses (a6, a7, a8)
+def gold_losses():
+    B, H, W = 2, 16, 24
+    img1 = torch.rand((B, 3, H, W), generator=g(41)) * 2 - 1
+    img2 = torch.rand((B, 3, H, W), generator=g(42)) * 2 - 1
+    # image-like (smooth) variants so that the edge weights exp(-(100 dI)^2) are not all ~0
+    simg = torch.from_numpy(smooth_field((B, 3, H, W), seed=43, amp=0.02)).float()
+    flow = (torch.randn((B, 2, H, W), generator=g(44)) * 2.0).requires_grad_()
+    occ = (torch.rand((B, 1, H, W), generator=g(45)) < 0.3).float()
+    arrs = dict(img1=img1, img2=img2, simg=simg, flow=flow, occ=occ)
+
+    pred = (img2 + 0.1 * torch.randn(img2.shape, generator=g(46))).requires_grad_()
+    for tag, o in (("none", None), ("occ", occ)):
+        L = ref_model.photometric_error(pred, img1, o)
+        (gp,) = torch.autograd.grad(L, pred)
+        arrs[f"photo_{tag}"] = L
+        arrs[f"photo_{tag}_gpred"] = gp
+    arrs["pred"] = pred
+
+    # fused chain the training step uses: warp(AC-True) -> photometric(+occ)   (model.py:379,394)
+    wrapper = types.SimpleNamespace()
+    for tag, o in (("none", None), ("occ", occ)):
+        warped = ref_model.FlowStageModel.warp(wrapper, img2, flow)
+        L = ref_model.photometric_error(warped, img1, o)
+        (gfl,) = torch.autograd.grad(L, flow)
+        arrs[f"warpphoto_{tag}"] = L
+        arrs[f"warpphoto_{tag}_gflow"] = gfl
+
+    for name, fn in (("smooth1", ref_model.first_order_smoothness_loss), ("smooth2", ref_model.second_order_smoothness_loss)):
+        for itag, im in (("noise", img1), ("smooth", simg)):
+            L = fn(im, flow)
+            (gfl,) = torch.autograd.grad(L, flow)
+            arrs[f"{name}_{itag}"] = L
+            arrs[f"{name}_{itag}_gflow"] = gfl
+    save("losses", **arrs)
+
+
+# ------------------------------------------------------------------- 5. range map (a9)
+def gold_range():
+    arrs = {}
+    for tag, shape, amp in (("a", (2, 2, 8, 9), 2.0), ("b", (1, 2, 5, 16), 6.0), ("zero", (1, 2, 4, 4), 0.0)):
+        flow = torch.randn(shape, generator=g(51)) * amp
+        rm = FlowModel.compute_range_map(types.SimpleNamespace(flow_to_warp=lambda f: FlowModel.flow_to_warp(None, f)), flow)
+        occ = 1.0 - torch.clamp(rm, min=0.0, max=1.0)
+        arrs.update({f"{tag}_flow": flow, f"{tag}_range": rm, f"{tag}_occ": occ})
+    save("range_map", **arrs)
+
+
+# ------------------------------------------------------- 6./7. whole networks + train step
+def _net_fixture(model, x, mode):
+    rngfree_fill(model)
+    model.train(mode == "train")
+    with torch.no_grad():
+        out = model(x)
+    return out
+
+
+def gold_nets():
+    arrs = {}
+    x64 = torch.rand((1, 6, 64, 64), generator=g(61)) * 2 - 1
+    x64b2 = torch.rand((2, 6, 64, 64), generator=g(62)) * 2 - 1
+    x96 = torch.from_numpy(smooth_field((1, 6, 64, 96), seed=63, amp=1.0)).float().clamp(-1, 1)
+    arrs.update(x64=x64, x64b2=x64b2, x96=x96)
+
+    manifests = {}
+    # Cfg1: models.flow_model forward on 2 random 64x64x3 frames (BASELINE.json configs[0])
+    for name, x, mode in (("simple", x64b2, "train"), ("simple", x64, "eval"), ("pwc", x64, "train"), ("flownet", x96, "eval")):
+        m = FlowModel({"learning_rate": 1e-3, "model": name, "displacement": 4})
+        out = _net_fixture(m, x, mode)
+        arrs[f"flowmodel_{name}_{mode}"] = out
+        manifests[f"flowmodel_{name}"] = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    # pwc second output (quarter-res flow * 5)
+    m = FlowModel({"learning_rate": 1e-3, "model": "pwc"})
+    rngfree_fill(m)
+    with torch.no_grad():
+        f_full, f_q = m.flow_pred(x64)
+    arrs["flownetcv_full"], arrs["flownetcv_quarter"] = f_full, f_q
+
+    for name, x, mode in (("flowoccnet", x96, "eval"), ("pwoc", x64, "train"), ("simple", x64b2, "train")):
+        m = FlowOccModel({"learning_rate": 1e-3, "model": name})
+        fl, oc = _net_fixture(m, x, mode)
+        arrs[f"flowoccmodel_{name}_{mode}_flow"] = fl
+        arrs[f"flowoccmodel_{name}_{mode}_occ"] = oc
+        manifests[f"flowoccmodel_{name}"] = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+
+    # supervised steps with gradients (a12)
+    m = FlowOccModel({"learning_rate": 1e-3, "model": "pwoc"})
+    rngfree_fill(m)
+    m.train()
+    gt_flow = torch.randn((1, 2, 64, 64), generator=g(64))
+    gt_occ = (torch.rand((1, 1, 64, 64), generator=g(65)) < 0.3).float()
+    fl_loss, oc_loss = m.general_step((x64, gt_flow, gt_occ), 0, "train")
+    (fl_loss + oc_loss).backward()
+    arrs.update(pwoc_step_gt_flow=gt_flow, pwoc_step_gt_occ=gt_occ, pwoc_step_flow_loss=fl_loss, pwoc_step_occ_loss=oc_loss,
+                pwoc_step_grad_conv2_0=m.model.conv2_0[0].weight.grad[:4, :8], pwoc_step_grad_conv1a=m.model.conv1a[0].weight.grad)
+
+    # unsupervised step (a10): FlowStageModel pwc, occ_aware, config weights
+    hp = dict(learning_rate=1e-5, model="pwc", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0,
+              with_occ=False, occ_aware=True)
+    xs = torch.from_numpy(smooth_field((2, 6, 64, 128), seed=66, amp=1.0)).float().clamp(-1, 1)
+    gt_flow2 = torch.randn((2, 2, 64, 128), generator=g(67)) * 2
+    gt_occ2 = (torch.rand((2, 1, 64, 128), generator=g(68)) < 0.3).float()
+    for occ_aware, tag in ((True, "occaware"), (False, "plain")):
+        hp["occ_aware"] = occ_aware
+        m = ref_model.FlowStageModel(dict(hp))
+        rngfree_fill(m)
+        m.train()
+        m.logger = None
+        m.global_step = 1  # skip tensorboard
+        if occ_aware:
+            res = m.general_step_occ_aware((xs, gt_flow2, gt_occ2), 0, "train")
+        else:
+            res = m.general_step((xs, gt_flow2, gt_occ2), 0, "train")
+        loss = hp["photo_weight"] * res[0] + hp["smooth1_weight"] * res[1] + hp["smooth2_weight"] * res[2]
+        loss.backward()
+        arrs[f"stage_{tag}_scalars"] = torch.stack([r.detach() for r in res])
+        arrs[f"stage_{tag}_loss"] = loss
+        arrs[f"stage_{tag}_grad_predict_flow2"] = m.flow_pred.predict_flow2.weight.grad[:, :16]
+        arrs[f"stage_{tag}_grad_conv1a"] = m.flow_pred.conv1a[0].weight.grad
+    arrs.update(stage_x=xs, stage_gt_flow=gt_flow2, stage_gt_occ=gt_occ2)
+    manifests["flowstage_pwc"] = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    save("nets", **arrs)
+
+    import json
+    with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
+        json.dump(manifests, f)
+    print("wrote state_dict_manifest.json", {k: len(v) for k, v in manifests.items()})
+
+
+# -------------------------------------------------------------------------- 8. EPE
+def gold_epe():
+    rs = np.random.RandomState(81)
+    tu, tv, u, v = [rs.randn(8, 9).astype(np.float32) * 3 for _ in range(4)]
+    tu[0, 0] = 1e9  # unknown-flow sentinel path
+    occ = (rs.rand(8, 9) < 0.3).astype(np.float32)
+    e0 = ref_flow_utils.flow_error(tu.copy(), tv.copy(), u.copy(), v.copy())
+    # the occ path indexes the EPE map with a flattened mask (flow_utils.py:227-230) => 1-D inputs
+    e1 = ref_flow_utils.flow_error(tu.reshape(-1).copy(), tv.reshape(-1).copy(), u.reshape(-1).copy(), v.reshape(-1).copy(), occ)
+    save("epe", tu=tu, tv=tv, u=u, v=v, occ=occ, epe=np.float64(e0), epe_occ=np.float64(e1))
+
+
+if __name__ == "__main__":
+    gold_corr()
+    gold_norm()
+    gold_warp()
+    gold_losses()
+    gold_range()
+    gold_epe()
+    gold_nets()
