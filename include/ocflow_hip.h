@@ -1,0 +1,129 @@
+/* ocflow_hip.h -- C ABI of libocflow_hip.so: the MI355X (gfx950) hot path of OCFlow.
+ *
+ * Every entry point is a stream-ordered launcher: plain device pointers + explicit element
+ * strides + sizes + a hipStream_t passed as void*.  No torch types, no allocation, no host
+ * synchronisation, re-entrant, graph-capturable.  Return value: 0 = OCF_OK, negative = error
+ * (never throws).  Each function names the reference interface (file:line under the OCFlow
+ * tree) it replaces; the reference-side binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - tensors are logical NCHW [B,C,H,W] described by ocf_tensor4 {data, stride_b, stride_c,
+ *     stride_h, stride_w} with strides in ELEMENTS, so NCHW-contiguous tensors, channels_last
+ *     tensors, channel slices of a wider buffer and views such as x[:, :3] are all passed
+ *     without a copy.  Fast paths: stride_c == 1 (channels_last) with 16-byte aligned pixels,
+ *     or stride_w == 1 (NCHW).
+ *   - feature tensors (f1, f2, img of the warp, cost volume, their gradients) have element
+ *     type `dtype` (OCF_F32 or OCF_BF16); accumulation is always fp32.
+ *   - flow  [B,2,H,W] (ch0 = u, x-displacement; ch1 = v, y-displacement), occ [B,1,H,W],
+ *     loss-side images and all loss gradients are fp32.
+ *   - reductions return fp64 partial sums in device memory (`double*`), zeroed by the
+ *     launcher with hipMemsetAsync on `stream`.
+ */
+#ifndef OCFLOW_HIP_H
+#define OCFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCF_ABI_VERSION 1
+#define OCF_MAX_DISPLACEMENT 4
+
+enum ocf_dtype { OCF_F32 = 0, OCF_BF16 = 1 };
+
+enum ocf_status {
+  OCF_OK = 0,
+  OCF_EINVAL = -1,       /* null pointer / non-positive size / bad enum                      */
+  OCF_EUNSUPPORTED = -2, /* valid request this build has no kernel for (e.g. displacement>4) */
+  OCF_ELAUNCH = -3,      /* HIP reported an error at launch (hipGetLastError)                */
+  OCF_ENODEVICE = -4     /* no HIP device / wrong architecture                               */
+};
+
+typedef struct ocf_tensor4 {
+  void* data;
+  int64_t sb, sc, sh, sw; /* element strides of the logical [B,C,H,W] tensor */
+} ocf_tensor4;
+
+int ocf_abi_version(void);
+const char* ocf_status_string(int status);
+/* device name + CU count of the current device; returns OCF_ENODEVICE when there is none. */
+int ocf_device_info(char* name, int name_len, int* compute_units);
+
+/* ---- K1+K2  local cost volume, optionally fused with the backward warp of f2 -------------
+ * out[b,(dy+d)(2d+1)+(dx+d),y,x] = 1/C * sum_c f1[b,c,y,x] * w2[b,c,y+dy,x+dx]   (0 outside)
+ *   w2 = f2                                            when flow == NULL
+ *   w2 = warp(f2, flow*flow_scale, align_corners)      when flow != NULL
+ *   w2 = w2 * occ  (occ broadcast over channels)       when occ  != NULL
+ * replaces: compute_cost_volume        models/networks/correlation_layer.py:7-40
+ *           CostVolumeLayer.forward    models/networks/cost_volume_net.py (missing module; call
+ *                                      sites flow_occ_net.py:168, cost_volume_flow_occ_net.py:188)
+ *           warp -> [*occ] -> corr     flow_net.py:110-112, cost_volume_flow_occ_net.py:204-206
+ * d <= OCF_MAX_DISPLACEMENT.  out has (2d+1)^2 channels and element type `dtype`. */
+int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
+                 const ocf_tensor4* out, int B, int C, int H, int W, int d, float flow_scale, int align_corners,
+                 int dtype, void* stream);
+
+/* gradient of the plain cost volume w.r.t. both operands (w2 materialised by the caller):
+ *   g1[b,c,y,x] = 1/C sum_k gout[b,k,y,x]       * w2[b,c,y+dy,x+dx]
+ *   g2[b,c,y,x] = 1/C sum_k gout[b,k,y-dy,x-dx] * f1[b,c,y-dy,x-dx]
+ * replaces: autograd of correlation_layer.py:33-39 (81 x MulBackward/MeanBackward + CatBackward) */
+int ocf_corr_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* gout, const ocf_tensor4* g1,
+                 const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, void* stream);
+
+/* ---- K2  backward bilinear warp (zeros padding), both align_corners variants --------------
+ * out[b,c,y,x] = bilinear(img[b,c], px, py), neighbours outside the image contribute 0
+ *   align_corners=0: px = (x+s*u)*W/max(W-1,1) - 0.5, py likewise     (in-network feature warp)
+ *   align_corners=1: px = (x+s*u)*(W-1)/max(W-1,1),   py likewise     (loss-side image warp)
+ * replaces: warp()  cost_volume_flow_net.py:121-151, cost_volume_flow_occ_net.py:137-167,
+ *           flow_net.py:57-87, flow_occ_net.py:96-126 (AC-False); models/model.py:191-221,
+ *           flow_model.py:49-79 (AC-True)  [grid build + F.grid_sample] */
+int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* out, int B, int C, int H, int W,
+                 float flow_scale, int align_corners, int dtype, void* stream);
+/* gimg  : fp32 [B,C,H,W] accumulation buffer, MUST be zeroed by the caller (float atomics);
+ * gflow : fp32 [B,2,H,W], written (gradient w.r.t. the UNSCALED flow, i.e. includes s). */
+int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
+                 const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners, int dtype,
+                 void* stream);
+
+/* ---- K4  Charbonnier photometric error, optionally fused with the AC-True image warp ------
+ * e = sqrt((P - img1)^2 + 1e-6),  P = img2 (flow==NULL) or warp_ac1(img2, flow)
+ * sums[0] = sum e*(1-occ)   sums[1] = sum (1-occ)   (occ==NULL: occ := 0, sums[1] = B*H*W)
+ * replaces: FlowStageModel.warp + robust_l1 + photometric_error   models/model.py:191-221, 27-46
+ *           (call sites model.py:327-330, 355-358, 379-394) */
+int ocf_photo_loss_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const ocf_tensor4* flow,
+                       const ocf_tensor4* occ, double* sums, int B, int C, int H, int W, void* stream);
+/* scale: device fp32 scalar = dLoss/d(sums[0]);  writes gflow [B,2,H,W] (flow != NULL) and/or
+ * gpred [B,C,H,W] = dLoss/dP (flow == NULL only).  Either output pointer may be NULL. */
+int ocf_photo_loss_bwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const ocf_tensor4* flow,
+                       const ocf_tensor4* occ, const float* scale, const ocf_tensor4* gflow, const ocf_tensor4* gpred,
+                       int B, int C, int H, int W, void* stream);
+
+/* ---- K5  edge-aware first + second order smoothness, one pass ----------------------------
+ * sums[0] = sum wx *charb(dxF)   over [B,2,H,W-1]     sums[1] = sum wy *charb(dyF)  over [B,2,H-1,W]
+ * sums[2] = sum wxx*charb(dxxF)  over [B,2,H,W-2]     sums[3] = sum wyy*charb(dyyF) over [B,2,H-2,W]
+ * w = exp(-mean_c (alpha*dI)^2), stride-1 image differences for order 1, stride-2 for order 2.
+ * replaces: gradient, first_order_smoothness_loss, second_order_smoothness_loss  models/model.py:53-66, 93-114 */
+int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, double* sums, int B, int C, int H, int W,
+                        float alpha, void* stream);
+/* coef: device fp32[4] = dLoss/d(sums[i]); writes gflow [B,2,H,W] */
+int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const float* coef, const ocf_tensor4* gflow,
+                        int B, int C, int H, int W, float alpha, void* stream);
+
+/* ---- K6  range map (forward splat of bilinear weights) + occlusion mask -------------------
+ * range[b,0,ty,tx] += w for the 4 integer neighbours of (x+u, y+v) that lie inside the image;
+ * occ = 1 - clamp(range, 0, 1) (written when occ != NULL).  range/occ: contiguous fp32 [B,1,H,W];
+ * range is zeroed by the launcher.
+ * replaces: flow_to_warp + compute_range_map  models/model.py:223-305 (dup flow_model.py:81-163), model.py:391 */
+int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, int B, int H, int W, void* stream);
+
+/* ---- K3  moments for normalize_features ---------------------------------------------------
+ * sums[2*b+0] = sum over (C,H,W) of f[b],  sums[2*b+1] = sum of squares  (fp64, B pairs)
+ * replaces: torch.var_mean(dim=(1,2,3)) in models/networks/correlation_layer.py:59-64 */
+int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int H, int W, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCFLOW_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libocflow_hip.so (C ABI declared in include/ocflow_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is missing it is built once with
+hipcc (ocflow_amd/build.py); if that fails, importing the ops raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import build as _build
+
+OCF_F32, OCF_BF16 = 0, 1
+OCF_OK = 0
+
+
+class Tensor4(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("sb", C.c_int64), ("sc", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)]
+
+
+_T4P = C.POINTER(Tensor4)
+_i, _f, _vp = C.c_int, C.c_float, C.c_void_p
+
+# name -> argtypes; mirrors include/ocflow_hip.h one to one (tests/test_abi.py checks the header against this)
+SIGNATURES = {
+    "ocf_abi_version": [],
+    "ocf_device_info": [C.c_char_p, _i, C.POINTER(_i)],
+    "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ocf_corr_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_warp_fwd": [_T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ocf_warp_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ocf_photo_loss_fwd": [_T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
+    "ocf_photo_loss_bwd": [_T4P, _T4P, _T4P, _T4P, _vp, _T4P, _T4P, _i, _i, _i, _i, _vp],
+    "ocf_smooth_loss_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _f, _vp],
+    "ocf_smooth_loss_bwd": [_T4P, _T4P, _vp, _T4P, _i, _i, _i, _i, _f, _vp],
+    "ocf_range_map": [_T4P, _vp, _vp, _i, _i, _i, _vp],
+    "ocf_moments": [_T4P, _vp, _i, _i, _i, _i, _i, _vp],
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Return the loaded library, building it first if the .so is absent.  Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            _build.build()
+        try:
+            lib = C.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError(f"ocflow_amd: cannot load {path}: {e}. The HIP extension is required; "
+                               "there is no CPU fallback (python -m ocflow_amd.build)") from e
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        lib.ocf_status_string.argtypes = [C.c_int]
+        lib.ocf_status_string.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != OCF_OK:
+        msg = load().ocf_status_string(status).decode()
+        raise RuntimeError(f"ocflow_amd: {what} failed: {msg} (status {status})")

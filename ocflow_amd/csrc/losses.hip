@@ -1,0 +1,407 @@
+// K4 photometric (Charbonnier, optionally fused with the AC-True image warp and the occlusion mask),
+// K5 edge-aware smoothness (orders 1 and 2 in one pass), K6 range map, K3 moments.
+// All HBM-bound streaming kernels: one thread per pixel, lanes = consecutive x (coalesced NCHW image
+// planes), wave-shuffle + LDS block reduction, one fp64 atomic per block and sum.
+// reference: models/model.py:27-46 (photometric), :53-66,93-114 (smoothness), :223-305,391 (range map),
+//            models/networks/correlation_layer.py:59-64 (moments)
+#include "ocf_common.h"
+
+namespace ocf {
+
+constexpr int LB = 256;
+constexpr int MAXC = 8;  // channels of the loss-side images (3 in the reference)
+
+template <int NS>
+__device__ __forceinline__ void block_reduce_atomic(double (&v)[NS], double* sums) {
+  __shared__ double red[NS][LB / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    const double s = wave_sum_d(v[i]);
+    if (lane == 0) red[i][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < LB / 64; w++) s += red[threadIdx.x][w];
+    atomicAdd(&sums[threadIdx.x], s);
+  }
+}
+
+__device__ __forceinline__ float charb(float d) { return sqrtf(__builtin_fmaf(d, d, 1e-6f)); }
+
+// ------------------------------------------------------------------------------------ photometric
+struct PhotoPix {
+  float w[4];
+  long off[4];
+  float wx1, wy1;
+};
+__device__ __forceinline__ PhotoPix photo_setup(const T4& img2, const T4& flow, int b, int y, int x, int H, int W,
+                                                const WarpGeom& wg) {
+  PhotoPix p;
+  const float* fl = (const float*)flow.p;
+  const long fo = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
+  const Bilin s = bilin_setup(((float)x + fl[fo]) * wg.ax + wg.bx, ((float)y + fl[fo + flow.sc]) * wg.ay + wg.by, H, W);
+  p.wx1 = s.wx1; p.wy1 = s.wy1;
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const int ddx = n & 1, ddy = n >> 1;
+    const bool ok = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
+    p.w[n] = ok ? (ddx ? s.wx1 : 1.f - s.wx1) * (ddy ? s.wy1 : 1.f - s.wy1) : 0.f;
+    p.off[n] = ok ? (long)b * img2.sb + (long)(s.y0 + ddy) * img2.sh + (long)(s.x0 + ddx) * img2.sw : -1;
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(LB) void photo_fwd_kernel(T4 img1, T4 img2, T4 flow, T4 occ, double* sums, int B, int C, int H,
+                                                       int W, WarpGeom wg, long npix) {
+  double acc[2] = {0.0, 0.0};
+  const float* i1 = (const float*)img1.p;
+  const float* i2 = (const float*)img2.p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const float vis = occ.p ? 1.f - ((const float*)occ.p)[(long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw] : 1.f;
+    const long o1 = (long)b * img1.sb + (long)y * img1.sh + (long)x * img1.sw;
+    float e = 0.f;
+    if (flow.p) {
+      const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
+      for (int c = 0; c < C; c++) {
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+          if (p.off[n] >= 0) v = __builtin_fmaf(p.w[n], i2[p.off[n] + (long)c * img2.sc], v);
+        e += charb(v - i1[o1 + (long)c * img1.sc]);
+      }
+    } else {
+      const long o2 = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
+      for (int c = 0; c < C; c++) e += charb(i2[o2 + (long)c * img2.sc] - i1[o1 + (long)c * img1.sc]);
+    }
+    acc[0] += (double)(e * vis);
+    acc[1] += (double)vis;
+  }
+  block_reduce_atomic<2>(acc, sums);
+}
+
+__global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow, T4 occ, const float* scale, T4 gflow,
+                                                       T4 gpred, int B, int C, int H, int W, WarpGeom wg, long npix) {
+  const float* i1 = (const float*)img1.p;
+  const float* i2 = (const float*)img2.p;
+  const float sc = *scale;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const float vis = occ.p ? 1.f - ((const float*)occ.p)[(long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw] : 1.f;
+    const long o1 = (long)b * img1.sb + (long)y * img1.sh + (long)x * img1.sw;
+    const float k = sc * vis;
+    if (flow.p) {
+      const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
+      float gx = 0.f, gy = 0.f;
+      for (int c = 0; c < C; c++) {
+        float nb[4];
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+          nb[n] = p.off[n] >= 0 ? i2[p.off[n] + (long)c * img2.sc] : 0.f;
+          v = __builtin_fmaf(p.w[n], nb[n], v);
+        }
+        const float dlt = v - i1[o1 + (long)c * img1.sc];
+        const float ge = k * dlt / charb(dlt);
+        gx = __builtin_fmaf(ge, (1.f - p.wy1) * (nb[1] - nb[0]) + p.wy1 * (nb[3] - nb[2]), gx);
+        gy = __builtin_fmaf(ge, (1.f - p.wx1) * (nb[2] - nb[0]) + p.wx1 * (nb[3] - nb[1]), gy);
+      }
+      if (gflow.p) {
+        float* gf = (float*)gflow.p;
+        const long o = (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
+        gf[o] = gx * wg.ax;
+        gf[o + gflow.sc] = gy * wg.ay;
+      }
+    } else if (gpred.p) {
+      const long o2 = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
+      float* gp = (float*)gpred.p;
+      const long og = (long)b * gpred.sb + (long)y * gpred.sh + (long)x * gpred.sw;
+      for (int c = 0; c < C; c++) {
+        const float dlt = i2[o2 + (long)c * img2.sc] - i1[o1 + (long)c * img1.sc];
+        gp[og + (long)c * gpred.sc] = k * dlt / charb(dlt);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- smoothness
+// exp(-mean_c (alpha * (I[p+s] - I[p]))^2) for a step of `s` pixels along x (dirx) or y.
+__device__ __forceinline__ float edge_w(const float* im, long o, long step, long sc, int C, float alpha) {
+  float m = 0.f;
+  for (int c = 0; c < C; c++) {
+    const float d = alpha * (im[o + step + (long)c * sc] - im[o + (long)c * sc]);
+    m = __builtin_fmaf(d, d, m);
+  }
+  return expf(-m / (float)C);
+}
+
+__global__ __launch_bounds__(LB) void smooth_fwd_kernel(T4 img, T4 flow, double* sums, int B, int C, int H, int W, float alpha,
+                                                        long npix) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const float* im = (const float*)img.p;
+  const float* fl = (const float*)flow.p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const long oi = (long)b * img.sb + (long)y * img.sh + (long)x * img.sw;
+    const long of = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
+    if (x + 1 < W) {
+      const float w = edge_w(im, oi, img.sw, img.sc, C, alpha);
+      float s = 0.f;
+      for (int f = 0; f < 2; f++) s += charb(fl[of + flow.sw + f * flow.sc] - fl[of + f * flow.sc]);
+      acc[0] += (double)(w * s);
+    }
+    if (y + 1 < H) {
+      const float w = edge_w(im, oi, img.sh, img.sc, C, alpha);
+      float s = 0.f;
+      for (int f = 0; f < 2; f++) s += charb(fl[of + flow.sh + f * flow.sc] - fl[of + f * flow.sc]);
+      acc[1] += (double)(w * s);
+    }
+    if (x + 2 < W) {
+      const float w = edge_w(im, oi, 2 * img.sw, img.sc, C, alpha);
+      float s = 0.f;
+      for (int f = 0; f < 2; f++) {
+        const long o = of + f * flow.sc;
+        s += charb((fl[o + 2 * flow.sw] - fl[o + flow.sw]) - (fl[o + flow.sw] - fl[o]));
+      }
+      acc[2] += (double)(w * s);
+    }
+    if (y + 2 < H) {
+      const float w = edge_w(im, oi, 2 * img.sh, img.sc, C, alpha);
+      float s = 0.f;
+      for (int f = 0; f < 2; f++) {
+        const long o = of + f * flow.sc;
+        s += charb((fl[o + 2 * flow.sh] - fl[o + flow.sh]) - (fl[o + flow.sh] - fl[o]));
+      }
+      acc[3] += (double)(w * s);
+    }
+  }
+  block_reduce_atomic<4>(acc, sums);
+}
+
+// phi(p) = w1(p) * d/charb(d), d = F[p+1]-F[p]           (defined for 0 <= p < n-1)
+// psi(p) = w2(p) * dd/charb(dd), dd = F[p+2]-2F[p+1]+F[p]  (defined for 0 <= p < n-2)
+// dL/dF[p] = c1*(phi(p-1) - phi(p)) + c2*(psi(p-2) - 2 psi(p-1) + psi(p))
+__device__ __forceinline__ float smooth_axis_grad(const float* im, const float* fl, long oi, long of, long istep, long isc,
+                                                  long fstep, int C, float alpha, int p, int n, float c1, float c2) {
+  float g = 0.f;
+  if (c1 != 0.f) {
+    if (p >= 1) {
+      const float d = fl[of] - fl[of - fstep];
+      g += c1 * edge_w(im, oi - istep, istep, isc, C, alpha) * d / charb(d);
+    }
+    if (p + 1 < n) {
+      const float d = fl[of + fstep] - fl[of];
+      g -= c1 * edge_w(im, oi, istep, isc, C, alpha) * d / charb(d);
+    }
+  }
+  if (c2 != 0.f) {
+    if (p >= 2) {
+      const float d = (fl[of] - fl[of - fstep]) - (fl[of - fstep] - fl[of - 2 * fstep]);
+      g += c2 * edge_w(im, oi - 2 * istep, 2 * istep, isc, C, alpha) * d / charb(d);
+    }
+    if (p >= 1 && p + 1 < n) {
+      const float d = (fl[of + fstep] - fl[of]) - (fl[of] - fl[of - fstep]);
+      g -= 2.f * c2 * edge_w(im, oi - istep, 2 * istep, isc, C, alpha) * d / charb(d);
+    }
+    if (p + 2 < n) {
+      const float d = (fl[of + 2 * fstep] - fl[of + fstep]) - (fl[of + fstep] - fl[of]);
+      g += c2 * edge_w(im, oi, 2 * istep, isc, C, alpha) * d / charb(d);
+    }
+  }
+  return g;
+}
+
+__global__ __launch_bounds__(LB) void smooth_bwd_kernel(T4 img, T4 flow, const float* coef, T4 gflow, int B, int C, int H, int W,
+                                                        float alpha, long npix) {
+  const float* im = (const float*)img.p;
+  const float* fl = (const float*)flow.p;
+  float* gf = (float*)gflow.p;
+  const float cx1 = coef[0], cy1 = coef[1], cx2 = coef[2], cy2 = coef[3];
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const long oi = (long)b * img.sb + (long)y * img.sh + (long)x * img.sw;
+    const long of = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
+    const long og = (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
+    for (int f = 0; f < 2; f++) {
+      float g = smooth_axis_grad(im, fl, oi, of + f * flow.sc, img.sw, img.sc, flow.sw, C, alpha, x, W, cx1, cx2);
+      g += smooth_axis_grad(im, fl, oi, of + f * flow.sc, img.sh, img.sc, flow.sh, C, alpha, y, H, cy1, cy2);
+      gf[og + f * gflow.sc] = g;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------- range map
+__global__ __launch_bounds__(LB) void range_splat_kernel(T4 flow, float* range, int B, int H, int W, long npix) {
+  const float* fl = (const float*)flow.p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const long fo = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
+    const float cx = (float)x + fl[fo], cy = (float)y + fl[fo + flow.sc];
+    if (!(cx == cx) || !(cy == cy)) continue;
+    float fx = floorf(cx), fy = floorf(cy);
+    const float rx = cx - fx, ry = cy - fy;
+    fx = fminf(fmaxf(fx, -2.f), (float)W + 1.f);
+    fy = fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+    const int x0 = (int)fx, y0 = (int)fy;
+    float* dst = range + (long)b * H * W;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int di = n & 1, dj = n >> 1;
+      const int tx = x0 + di, ty = y0 + dj;
+      if (tx >= 0 && tx < W && ty >= 0 && ty < H) atomicAdd(dst + (long)ty * W + tx, (di ? rx : 1.f - rx) * (dj ? ry : 1.f - ry));
+    }
+  }
+}
+
+__global__ __launch_bounds__(LB) void occ_from_range_kernel(const float* range, float* occ, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    occ[i] = 1.f - fminf(fmaxf(range[i], 0.f), 1.f);
+}
+
+// ---------------------------------------------------------------------------------------- moments
+template <typename T>
+__global__ __launch_bounds__(LB) void moments_kernel(T4 f, double* sums, int C, int H, int W, int blocks_per_b) {
+  const int b = blockIdx.x / blocks_per_b, blk = blockIdx.x % blocks_per_b;
+  const long n = (long)C * H * W;
+  double acc[2] = {0.0, 0.0};
+  float s1 = 0.f, s2 = 0.f;
+  int cnt = 0;
+  for (long idx = (long)blk * LB + threadIdx.x; idx < n; idx += (long)blocks_per_b * LB) {
+    // iterate in memory order of whichever layout is dense
+    int c, y, x;
+    long r = idx;
+    if (f.sc == 1) { c = r % C; r /= C; x = r % W; y = r / W; }
+    else           { x = r % W; r /= W; y = r % H; c = r / H; }
+    const float v = ldf<T>(f.p, (long)b * f.sb + (long)c * f.sc + (long)y * f.sh + (long)x * f.sw);
+    s1 += v; s2 = __builtin_fmaf(v, v, s2);
+    if (++cnt == 64) { acc[0] += (double)s1; acc[1] += (double)s2; s1 = s2 = 0.f; cnt = 0; }
+  }
+  acc[0] += (double)s1; acc[1] += (double)s2;
+  block_reduce_atomic<2>(acc, sums + 2 * b);
+}
+
+static inline int rgrid(long n) {
+  long blocks = (n + LB - 1) / LB;
+  return (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
+}
+
+}  // namespace ocf
+
+using namespace ocf;
+
+extern "C" int ocf_photo_loss_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const ocf_tensor4* flow,
+                                  const ocf_tensor4* occ, double* sums, int B, int C, int H, int W, void* stream) {
+  if (!img1 || !img2 || !sums || !img1->data || !img2->data) return OCF_EINVAL;
+  if ((flow && !flow->data) || (occ && !occ->data)) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, 2 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(photo_fwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, mk(img1), mk(img2), mk(flow), mk(occ), sums, B, C, H,
+                     W, WarpGeom(H, W, 1), npix);
+  return launch_status();
+}
+
+extern "C" int ocf_photo_loss_bwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const ocf_tensor4* flow,
+                                  const ocf_tensor4* occ, const float* scale, const ocf_tensor4* gflow,
+                                  const ocf_tensor4* gpred, int B, int C, int H, int W, void* stream) {
+  if (!img1 || !img2 || !scale || !img1->data || !img2->data) return OCF_EINVAL;
+  if ((flow && !flow->data) || (occ && !occ->data) || (gflow && !gflow->data) || (gpred && !gpred->data)) return OCF_EINVAL;
+  if ((flow && !gflow) || (!flow && !gpred)) return OCF_EINVAL;
+  if (flow && gpred) return OCF_EUNSUPPORTED; /* grad w.r.t. the un-warped image through the fused warp */
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(photo_bwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
+                     mk(occ), scale, mk(gflow), mk(gpred), B, C, H, W, WarpGeom(H, W, 1), npix);
+  return launch_status();
+}
+
+extern "C" int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, double* sums, int B, int C, int H, int W,
+                                   float alpha, void* stream) {
+  if (!img || !flow || !sums || !img->data || !flow->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, 4 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
+  return launch_status();
+}
+
+extern "C" int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const float* coef, const ocf_tensor4* gflow,
+                                   int B, int C, int H, int W, float alpha, void* stream) {
+  if (!img || !flow || !coef || !gflow || !img->data || !flow->data || !gflow->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(smooth_bwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
+                     B, C, H, W, alpha, npix);
+  return launch_status();
+}
+
+extern "C" int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, int B, int H, int W, void* stream) {
+  if (!flow || !flow->data || !range) return OCF_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long npix = (long)B * H * W;
+  if (hipMemsetAsync(range, 0, npix * sizeof(float), st) != hipSuccess) return OCF_ELAUNCH;
+  hipLaunchKernelGGL(range_splat_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, mk(flow), range, B, H, W, npix);
+  if (occ) hipLaunchKernelGGL(occ_from_range_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, (const float*)range, occ, npix);
+  return launch_status();
+}
+
+extern "C" int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int H, int W, int dtype, void* stream) {
+  if (!f || !f->data || !sums) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, 2 * (size_t)B * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
+  const long n = (long)C * H * W;
+  long bpb = (n + LB * 16 - 1) / (LB * 16);
+  if (bpb < 1) bpb = 1;
+  if (bpb > 512) bpb = 512;
+  if (dtype == OCF_F32)
+    hipLaunchKernelGGL(moments_kernel<float>, dim3((unsigned)(B * bpb)), dim3(LB), 0, st, mk(f), sums, C, H, W, (int)bpb);
+  else if (dtype == OCF_BF16)
+    hipLaunchKernelGGL(moments_kernel<bf16>, dim3((unsigned)(B * bpb)), dim3(LB), 0, st, mk(f), sums, C, H, W, (int)bpb);
+  else
+    return OCF_EINVAL;
+  return launch_status();
+}
+
+extern "C" int ocf_abi_version(void) { return OCF_ABI_VERSION; }
+
+extern "C" const char* ocf_status_string(int s) {
+  switch (s) {
+    case OCF_OK: return "ok";
+    case OCF_EINVAL: return "invalid argument";
+    case OCF_EUNSUPPORTED: return "unsupported configuration";
+    case OCF_ELAUNCH: return "HIP launch error";
+    case OCF_ENODEVICE: return "no HIP device";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int ocf_device_info(char* name, int name_len, int* compute_units) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return OCF_ENODEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return OCF_ENODEVICE;
+  if (name && name_len > 0) {
+    int i = 0;
+    for (; i < name_len - 1 && prop.gcnArchName[i]; i++) name[i] = prop.gcnArchName[i];
+    name[i] = 0;
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  return OCF_OK;
+}

@@ -1,0 +1,162 @@
+// Shared device helpers for the OCFlow gfx950 kernels (wave = 64 lanes, 16-byte channel units).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ocflow_hip.h"
+
+namespace ocf {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Device-side view of ocf_tensor4 (passed by value in the kernel argument segment).
+struct T4 {
+  char* p;
+  long sb, sc, sh, sw;  // element strides
+};
+static inline T4 mk(const ocf_tensor4* t) {
+  T4 r;
+  if (t) { r.p = (char*)t->data; r.sb = t->sb; r.sc = t->sc; r.sh = t->sh; r.sw = t->sw; }
+  else   { r.p = nullptr; r.sb = r.sc = r.sh = r.sw = 0; }
+  return r;
+}
+
+// One 16-byte "unit" = U consecutive channels of one pixel: 4 x fp32 or 8 x bf16.
+template <typename T> struct Unit;
+template <> struct Unit<float> { static constexpr int U = 4; };
+template <> struct Unit<bf16>  { static constexpr int U = 8; };
+
+template <typename T> __device__ __forceinline__ float ldf(const char* base, long eoff) {
+  return (float)(((const T*)base)[eoff]);
+}
+template <typename T> __device__ __forceinline__ void stf(char* base, long eoff, float v) {
+  ((T*)base)[eoff] = (T)v;
+}
+
+// unit (u32x4 bits) <-> U floats
+template <typename T> __device__ __forceinline__ void unit_to_f(u32x4 v, float* f);
+template <> __device__ __forceinline__ void unit_to_f<float>(u32x4 v, float* f) {
+  f32x4 x = __builtin_bit_cast(f32x4, v);
+  f[0] = x[0]; f[1] = x[1]; f[2] = x[2]; f[3] = x[3];
+}
+template <> __device__ __forceinline__ void unit_to_f<bf16>(u32x4 v, float* f) {
+  // bf16 -> f32 is a 16-bit shift
+  f[0] = __builtin_bit_cast(float, v[0] << 16); f[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
+  f[2] = __builtin_bit_cast(float, v[1] << 16); f[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
+  f[4] = __builtin_bit_cast(float, v[2] << 16); f[5] = __builtin_bit_cast(float, v[2] & 0xffff0000u);
+  f[6] = __builtin_bit_cast(float, v[3] << 16); f[7] = __builtin_bit_cast(float, v[3] & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ u32x4 f_to_unit(const float* f);
+template <> __device__ __forceinline__ u32x4 f_to_unit<float>(const float* f) {
+  f32x4 x = {f[0], f[1], f[2], f[3]};
+  return __builtin_bit_cast(u32x4, x);
+}
+template <> __device__ __forceinline__ u32x4 f_to_unit<bf16>(const float* f) {
+  bf16x8 x = {(bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3], (bf16)f[4], (bf16)f[5], (bf16)f[6], (bf16)f[7]};
+  return __builtin_bit_cast(u32x4, x);
+}
+
+// dot product of two units, fp32 accumulate.  bf16: 4 x v_dot2c_f32_bf16.
+template <typename T> __device__ __forceinline__ float unit_dot(u32x4 a, u32x4 b, float acc);
+template <> __device__ __forceinline__ float unit_dot<float>(u32x4 a, u32x4 b, float acc) {
+  f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
+  acc = __builtin_fmaf(x[0], y[0], acc); acc = __builtin_fmaf(x[1], y[1], acc);
+  acc = __builtin_fmaf(x[2], y[2], acc); acc = __builtin_fmaf(x[3], y[3], acc);
+  return acc;
+}
+template <> __device__ __forceinline__ float unit_dot<bf16>(u32x4 a, u32x4 b, float acc) {
+  bf16x8 x = __builtin_bit_cast(bf16x8, a), y = __builtin_bit_cast(bf16x8, b);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(y, y, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(y, y, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(y, y, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(y, y, 6, 7), acc, false);
+  return acc;
+}
+
+// Load the unit holding channels [c0, c0+U) of pixel (b,y,x); channels >= C read as 0.
+// VEC: stride_c == 1 and the address is 16-byte aligned (checked on the host).
+template <typename T, bool VEC>
+__device__ __forceinline__ u32x4 load_unit(const T4& t, long pix_off, int c0, int C) {
+  constexpr int U = Unit<T>::U;
+  if (VEC) {
+    if (c0 + U <= C) return *(const u32x4*)(t.p + (pix_off + c0) * (long)sizeof(T));
+  }
+  float f[U];
+#pragma unroll
+  for (int j = 0; j < U; j++) f[j] = (c0 + j < C) ? ldf<T>(t.p, pix_off + (long)(c0 + j) * t.sc) : 0.f;
+  return f_to_unit<T>(f);
+}
+template <typename T, bool VEC>
+__device__ __forceinline__ void load_unit_f(const T4& t, long pix_off, int c0, int C, float* f) {
+  constexpr int U = Unit<T>::U;
+  if (VEC) {
+    if (c0 + U <= C) { unit_to_f<T>(*(const u32x4*)(t.p + (pix_off + c0) * (long)sizeof(T)), f); return; }
+  }
+#pragma unroll
+  for (int j = 0; j < U; j++) f[j] = (c0 + j < C) ? ldf<T>(t.p, pix_off + (long)(c0 + j) * t.sc) : 0.f;
+}
+template <typename T, bool VEC>
+__device__ __forceinline__ void store_unit_f(const T4& t, long pix_off, int c0, int C, const float* f) {
+  constexpr int U = Unit<T>::U;
+  if (VEC) {
+    if (c0 + U <= C) { *(u32x4*)(t.p + (pix_off + c0) * (long)sizeof(T)) = f_to_unit<T>(f); return; }
+  }
+#pragma unroll
+  for (int j = 0; j < U; j++) if (c0 + j < C) stf<T>(t.p, pix_off + (long)(c0 + j) * t.sc, f[j]);
+}
+
+// Sampling geometry of the backward warp: source coordinate of output pixel (x,y).
+struct WarpGeom {
+  float ax, bx, ay, by;  // px = (x+u)*ax + bx
+  __host__ __device__ WarpGeom(int H, int W, int align_corners) {
+    float wd = (float)(W > 1 ? W - 1 : 1), hd = (float)(H > 1 ? H - 1 : 1);
+    if (align_corners) { ax = (float)(W - 1) / wd; bx = 0.f; ay = (float)(H - 1) / hd; by = 0.f; }
+    else               { ax = (float)W / wd;       bx = -0.5f; ay = (float)H / hd;     by = -0.5f; }
+  }
+};
+
+struct Bilin {
+  int x0, y0;
+  float wx1, wy1;   // fractional parts; weights are (1-wx1, wx1) x (1-wy1, wy1)
+  bool vx0, vx1, vy0, vy1;
+};
+__device__ __forceinline__ Bilin bilin_setup(float px, float py, int H, int W) {
+  Bilin s;
+  float fx = floorf(px), fy = floorf(py);
+  s.wx1 = px - fx; s.wy1 = py - fy;
+  // clamp before the int conversion so huge/NaN coordinates cannot overflow
+  fx = fminf(fmaxf(fx, -2.f), (float)W + 1.f);
+  fy = fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+  s.x0 = (int)fx; s.y0 = (int)fy;
+  s.vx0 = (s.x0 >= 0) & (s.x0 < W); s.vx1 = (s.x0 + 1 >= 0) & (s.x0 + 1 < W);
+  s.vy0 = (s.y0 >= 0) & (s.y0 < H); s.vy1 = (s.y0 + 1 >= 0) & (s.y0 + 1 < H);
+  if (!(px == px) || !(py == py)) { s.vx0 = s.vx1 = s.vy0 = s.vy1 = false; s.wx1 = s.wy1 = 0.f; }
+  return s;
+}
+
+// wave-level sum over 64 lanes (result valid in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+// XCD a contiguous range of logical tile ids (neighbouring tiles share halos in that XCD's L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? OCF_OK : OCF_ELAUNCH; }
+
+}  // namespace ocf

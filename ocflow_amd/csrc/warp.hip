@@ -1,0 +1,174 @@
+// K2: backward bilinear warp with zero padding, both align_corners variants.
+// reference: cost_volume_flow_net.py:121-151 (AC-False), models/model.py:191-221 (AC-True).
+//
+// One thread per output pixel; the thread walks the pixel's channels in 16-byte units (channels_last:
+// one global_load_dwordx4 per neighbour and unit) or per channel plane (NCHW: lanes = consecutive x,
+// coalesced).  Backward: grad_img is a scatter (float atomics into an fp32 buffer, 4 neighbours),
+// grad_flow is accumulated in registers over the channels and written once -- no atomics.
+#include "ocf_common.h"
+
+namespace ocf {
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void warp_fwd_kernel(T4 img, T4 flow, T4 out, int B, int C, int H, int W, float fs,
+                                                       WarpGeom wg, long npix) {
+  constexpr int U = Unit<T>::U;
+  const float* fl = (const float*)flow.p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const long fo = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
+    const float uu = fl[fo] * fs, vv = fl[fo + flow.sc] * fs;
+    const Bilin s = bilin_setup(((float)x + uu) * wg.ax + wg.bx, ((float)y + vv) * wg.ay + wg.by, H, W);
+    float w[4];
+    long off[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int ddx = n & 1, ddy = n >> 1;
+      const bool ok = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
+      w[n] = ok ? (ddx ? s.wx1 : 1.f - s.wx1) * (ddy ? s.wy1 : 1.f - s.wy1) : 0.f;
+      off[n] = ok ? (long)b * img.sb + (long)(s.y0 + ddy) * img.sh + (long)(s.x0 + ddx) * img.sw : -1;
+    }
+    const long oo = (long)b * out.sb + (long)y * out.sh + (long)x * out.sw;
+    for (int c0 = 0; c0 < C; c0 += U) {
+      float a[U];
+#pragma unroll
+      for (int j = 0; j < U; j++) a[j] = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        if (off[n] >= 0) {
+          float f[U];
+          load_unit_f<T, VEC>(img, off[n], c0, C, f);
+#pragma unroll
+          for (int j = 0; j < U; j++) a[j] = __builtin_fmaf(w[n], f[j], a[j]);
+        }
+      }
+      store_unit_f<T, VEC>(out, oo, c0, C, a);
+    }
+  }
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(T4 img, T4 flow, T4 gout, T4 gimg, T4 gflow, int B, int C, int H, int W,
+                                                       float fs, WarpGeom wg, long npix) {
+  constexpr int U = Unit<T>::U;
+  const float* fl = (const float*)flow.p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const long fo = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
+    const float uu = fl[fo] * fs, vv = fl[fo + flow.sc] * fs;
+    const Bilin s = bilin_setup(((float)x + uu) * wg.ax + wg.bx, ((float)y + vv) * wg.ay + wg.by, H, W);
+    bool ok[4];
+    float w[4];
+    long off[4], goff[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int ddx = n & 1, ddy = n >> 1;
+      ok[n] = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
+      w[n] = (ddx ? s.wx1 : 1.f - s.wx1) * (ddy ? s.wy1 : 1.f - s.wy1);
+      off[n] = (long)b * img.sb + (long)(s.y0 + ddy) * img.sh + (long)(s.x0 + ddx) * img.sw;
+      goff[n] = (long)b * gimg.sb + (long)(s.y0 + ddy) * gimg.sh + (long)(s.x0 + ddx) * gimg.sw;
+    }
+    const long go = (long)b * gout.sb + (long)y * gout.sh + (long)x * gout.sw;
+    float gx = 0.f, gy = 0.f;
+    for (int c0 = 0; c0 < C; c0 += U) {
+      float g[U];
+      load_unit_f<T, VEC>(gout, go, c0, C, g);
+      float v[4][U];
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        if (ok[n]) {
+          load_unit_f<T, VEC>(img, off[n], c0, C, v[n]);
+          if (gimg.p) {
+#pragma unroll
+            for (int j = 0; j < U; j++)
+              if (c0 + j < C) atomicAdd((float*)gimg.p + goff[n] + (long)(c0 + j) * gimg.sc, w[n] * g[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < U; j++) v[n][j] = 0.f;
+        }
+      }
+      // d out / d px = (1-wy)(v01 - v00) + wy (v11 - v10);  d out / d py = (1-wx)(v10 - v00) + wx (v11 - v01)
+#pragma unroll
+      for (int j = 0; j < U; j++) {
+        const float dxv = (1.f - s.wy1) * (v[1][j] - v[0][j]) + s.wy1 * (v[3][j] - v[2][j]);
+        const float dyv = (1.f - s.wx1) * (v[2][j] - v[0][j]) + s.wx1 * (v[3][j] - v[1][j]);
+        gx = __builtin_fmaf(g[j], dxv, gx);
+        gy = __builtin_fmaf(g[j], dyv, gy);
+      }
+    }
+    if (gflow.p) {
+      float* gf = (float*)gflow.p;
+      const long o = (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
+      gf[o] = gx * wg.ax * fs;
+      gf[o + gflow.sc] = gy * wg.ay * fs;
+    }
+  }
+}
+
+template <typename T> static bool wvec_ok(const ocf_tensor4* t) {
+  constexpr int U = Unit<T>::U;
+  return t->sc == 1 && ((uintptr_t)t->data % 16 == 0) && t->sw % U == 0 && t->sh % U == 0 && t->sb % U == 0;
+}
+
+static inline int grid_for(long n) {
+  long blocks = (n + 255) / 256;
+  return (int)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks));
+}
+
+template <typename T>
+static int warp_fwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* out, int B, int C, int H, int W,
+                      float fs, int ac, hipStream_t st) {
+  const long npix = (long)B * H * W;
+  const WarpGeom wg(H, W, ac);
+  if (wvec_ok<T>(img) && wvec_ok<T>(out))
+    hipLaunchKernelGGL((warp_fwd_kernel<T, true>), dim3(grid_for(npix)), dim3(256), 0, st, mk(img), mk(flow), mk(out), B, C, H,
+                       W, fs, wg, npix);
+  else
+    hipLaunchKernelGGL((warp_fwd_kernel<T, false>), dim3(grid_for(npix)), dim3(256), 0, st, mk(img), mk(flow), mk(out), B, C, H,
+                       W, fs, wg, npix);
+  return launch_status();
+}
+
+template <typename T>
+static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
+                      const ocf_tensor4* gflow, int B, int C, int H, int W, float fs, int ac, hipStream_t st) {
+  const long npix = (long)B * H * W;
+  const WarpGeom wg(H, W, ac);
+  if (wvec_ok<T>(img) && wvec_ok<T>(gout))
+    hipLaunchKernelGGL((warp_bwd_kernel<T, true>), dim3(grid_for(npix)), dim3(256), 0, st, mk(img), mk(flow), mk(gout),
+                       mk(gimg), mk(gflow), B, C, H, W, fs, wg, npix);
+  else
+    hipLaunchKernelGGL((warp_bwd_kernel<T, false>), dim3(grid_for(npix)), dim3(256), 0, st, mk(img), mk(flow), mk(gout),
+                       mk(gimg), mk(gflow), B, C, H, W, fs, wg, npix);
+  return launch_status();
+}
+
+}  // namespace ocf
+
+extern "C" int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* out, int B, int C, int H,
+                            int W, float flow_scale, int align_corners, int dtype, void* stream) {
+  if (!img || !flow || !out || !img->data || !flow->data || !out->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OCF_F32) return ocf::warp_fwd_t<float>(img, flow, out, B, C, H, W, flow_scale, align_corners, st);
+  if (dtype == OCF_BF16) return ocf::warp_fwd_t<ocf::bf16>(img, flow, out, B, C, H, W, flow_scale, align_corners, st);
+  return OCF_EINVAL;
+}
+
+extern "C" int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
+                            const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners,
+                            int dtype, void* stream) {
+  if (!img || !flow || !gout || !img->data || !flow->data || !gout->data) return OCF_EINVAL;
+  if ((gimg && !gimg->data) || (gflow && !gflow->data) || (!gimg && !gflow)) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OCF_F32) return ocf::warp_bwd_t<float>(img, flow, gout, gimg, gflow, B, C, H, W, flow_scale, align_corners, st);
+  if (dtype == OCF_BF16)
+    return ocf::warp_bwd_t<ocf::bf16>(img, flow, gout, gimg, gflow, B, C, H, W, flow_scale, align_corners, st);
+  return OCF_EINVAL;
+}

@@ -1,0 +1,443 @@
+"""Functional operators of the OCFlow hot path on MI355X.
+
+Each operator keeps the name, argument meaning and error behaviour of the reference function it replaces
+(file:line under the OCFlow tree) and runs the hand-written HIP kernels of libocflow_hip.so through the C ABI
+(include/ocflow_hip.h).  Tensors must live on a HIP device: there is deliberately NO CPU / PyTorch fallback --
+a CPU tensor raises, a missing library raises.
+
+Layout: inputs may be NCHW-contiguous, channels_last, or arbitrary strided views (x[:, :3], channel slices of a
+concat buffer); strides are passed to the kernels, nothing is copied.  Features may be fp32 or bf16 (fp32
+accumulation); flow / occlusion / images of the losses are fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+__all__ = [
+    "compute_cost_volume", "corr_warp", "warp", "normalize_features", "robust_l1", "photometric_error",
+    "warp_photometric_error", "gradient", "first_order_smoothness_loss", "second_order_smoothness_loss",
+    "smoothness_losses", "compute_range_map", "occlusion_from_flow",
+]
+
+MAX_DISPLACEMENT = 4
+
+
+# ------------------------------------------------------------------------------------------------ plumbing
+def _require_hip(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ocflow_amd.ops: tensors must be on a HIP (cuda) device; the MI355X kernels have no "
+                               "CPU fallback")
+
+
+def _t4(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    sb, sc, sh, sw = t.stride()
+    return C.byref(_lib.Tensor4(t.data_ptr(), sb, sc, sh, sw))
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.OCF_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.OCF_BF16
+    raise TypeError(f"ocflow_amd.ops: unsupported feature dtype {t.dtype}")
+
+
+def _is_cl(t: torch.Tensor) -> bool:
+    return t.stride(1) == 1 and t.size(1) > 1
+
+
+def _empty_like_layout(ref: torch.Tensor, shape, dtype=None) -> torch.Tensor:
+    fmt = torch.channels_last if _is_cl(ref) else torch.contiguous_format
+    return torch.empty(shape, device=ref.device, dtype=dtype or ref.dtype, memory_format=fmt)
+
+
+def _zeros_like_layout(ref: torch.Tensor, shape, dtype=None) -> torch.Tensor:
+    fmt = torch.channels_last if _is_cl(ref) else torch.contiguous_format
+    return torch.empty(shape, device=ref.device, dtype=dtype or ref.dtype, memory_format=fmt).zero_()
+
+
+def _features(*ts):
+    """Bring feature operands to one kernel dtype (bf16 only if all are bf16, else fp32)."""
+    dt = torch.bfloat16 if all(t.dtype == torch.bfloat16 for t in ts) else torch.float32
+    return [t if t.dtype == dt else t.to(dt) for t in ts]
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else (t if t.dtype == torch.float32 else t.float())
+
+
+def _check4(t, name, C_=None):
+    if t.dim() != 4:
+        raise ValueError(f"{name} must be [B,C,H,W], got {tuple(t.shape)}")
+    if C_ is not None and t.size(1) != C_:
+        raise ValueError(f"{name} must have {C_} channels, got {t.size(1)}")
+
+
+# ------------------------------------------------------------------------------------- raw launch wrappers
+def _warp_fwd_raw(img, flow, flow_scale, align_corners):
+    B, C_, H, W = img.shape
+    out = _empty_like_layout(img, img.shape)
+    with torch.cuda.device(img.device):
+        _lib.check(_lib.load().ocf_warp_fwd(_t4(img), _t4(flow), _t4(out), B, C_, H, W, float(flow_scale),
+                                            int(bool(align_corners)), _dtype_code(img), _stream(img)), "ocf_warp_fwd")
+    return out
+
+
+def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flow):
+    B, C_, H, W = img.shape
+    gimg = _zeros_like_layout(img, img.shape, torch.float32) if need_img else None
+    gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32) if need_flow else None
+    if gout.dtype != img.dtype:
+        gout = gout.to(img.dtype)
+    with torch.cuda.device(img.device):
+        _lib.check(_lib.load().ocf_warp_bwd(_t4(img), _t4(flow), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W,
+                                            float(flow_scale), int(bool(align_corners)), _dtype_code(img), _stream(img)),
+                   "ocf_warp_bwd")
+    if gimg is not None and gimg.dtype != img.dtype:
+        gimg = gimg.to(img.dtype)
+    return gimg, gflow
+
+
+# --------------------------------------------------------------------------------------------- cost volume
+class _CorrWarpFn(Function):
+    @staticmethod
+    def forward(ctx, f1, f2, flow, occ, d, flow_scale, align_corners):
+        B, C_, H, W = f1.shape
+        n = 2 * d + 1
+        out = _empty_like_layout(f1, (B, n * n, H, W))
+        with torch.cuda.device(f1.device):
+            _lib.check(_lib.load().ocf_corr_fwd(_t4(f1), _t4(f2), _t4(flow), _t4(occ), _t4(out), B, C_, H, W, d,
+                                                float(flow_scale), int(bool(align_corners)), _dtype_code(f1), _stream(f1)),
+                       "ocf_corr_fwd")
+        ctx.save_for_backward(f1, f2, flow, occ)
+        ctx.cfg = (d, float(flow_scale), bool(align_corners))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        f1, f2, flow, occ = ctx.saved_tensors
+        d, fs, ac = ctx.cfg
+        B, C_, H, W = f1.shape
+        need1, need2, needf, needo = ctx.needs_input_grad[:4]
+        if gout.dtype != f1.dtype:
+            gout = gout.to(f1.dtype)
+        # second operand of the plain correlation (recomputed: the fused forward never stored it)
+        w2 = _warp_fwd_raw(f2, flow, fs, ac) if flow is not None else f2
+        w2o = w2 * occ.to(w2.dtype) if occ is not None else w2
+        need_w2 = need2 or needf or needo
+        g1 = _empty_like_layout(f1, f1.shape) if need1 else None
+        gw = _empty_like_layout(w2o, w2o.shape) if need_w2 else None
+        if need1 or need_w2:
+            with torch.cuda.device(f1.device):
+                _lib.check(_lib.load().ocf_corr_bwd(_t4(f1), _t4(w2o), _t4(gout), _t4(g1), _t4(gw), B, C_, H, W, d,
+                                                    _dtype_code(f1), _stream(f1)), "ocf_corr_bwd")
+        g2 = gflow = gocc = None
+        if need_w2:
+            if occ is not None:
+                if needo:
+                    gocc = (gw.float() * w2.float()).sum(dim=1, keepdim=True)
+                gw = gw * occ.to(gw.dtype)
+            if flow is not None:
+                if need2 or needf:
+                    g2, gflow = _warp_bwd_raw(f2, flow, gw, fs, ac, need2, needf)
+            else:
+                g2 = gw if need2 else None
+        return g1, g2, gflow, gocc, None, None, None
+
+
+def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flow_scale=1.0, align_corners=False):
+    """Cost volume of features1 against  warp(features2, flow*flow_scale) [* occ]  in ONE kernel: the search window
+    is gathered through the warp straight into LDS, the warped tensor never exists in HBM.
+
+    Fuses the per-level chain  warp -> [* occ] -> correlation  of flow_net.py:110-112 and
+    cost_volume_flow_occ_net.py:204-206 (with flow=None, occ given: flow_occ_net.py:167-168)."""
+    _check4(features1, "features1")
+    _check4(features2, "features2")
+    if features1.shape != features2.shape:
+        raise ValueError(f"feature shapes differ: {tuple(features1.shape)} vs {tuple(features2.shape)}")
+    d = int(max_displacement)
+    if d < 1 or d > MAX_DISPLACEMENT:
+        raise ValueError(f"max_displacement must be in [1, {MAX_DISPLACEMENT}] for the MI355X kernel, got {d}")
+    _require_hip(features1, features2, flow, occ)
+    B, _, H, W = features1.shape
+    if flow is not None:
+        _check4(flow, "flow", 2)
+        if flow.shape[0] != B or flow.shape[2:] != features1.shape[2:]:
+            raise ValueError("flow must be [B,2,H,W] matching the features")
+    if occ is not None:
+        _check4(occ, "occ", 1)
+        if occ.shape[0] != B or occ.shape[2:] != features1.shape[2:]:
+            raise ValueError("occ must be [B,1,H,W] matching the features")
+    f1, f2 = _features(features1, features2)
+    return _CorrWarpFn.apply(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners)
+
+
+def compute_cost_volume(features1, features2, max_displacement=4):
+    """Drop-in for models/networks/correlation_layer.py:7-40.
+
+    out[b, (dy+d)(2d+1)+(dx+d), y, x] = mean_c features1[b,c,y,x] * features2[b,c,y+dy,x+dx]   (zero outside)."""
+    return corr_warp(features1, features2, None, None, max_displacement)
+
+
+# ---------------------------------------------------------------------------------------------------- warp
+class _WarpFn(Function):
+    @staticmethod
+    def forward(ctx, img, flow, flow_scale, align_corners):
+        ctx.save_for_backward(img, flow)
+        ctx.cfg = (float(flow_scale), bool(align_corners))
+        return _warp_fwd_raw(img, flow, flow_scale, align_corners)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        img, flow = ctx.saved_tensors
+        fs, ac = ctx.cfg
+        gimg, gflow = _warp_bwd_raw(img, flow, gout, fs, ac, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gimg, gflow, None, None
+
+
+def warp(img, flow, align_corners=False, flow_scale=1.0):
+    """Backward bilinear warp of `img` [B,C,H,W] by `flow` [B,2,H,W] (zeros padding).
+
+    align_corners=False: the in-network feature warp (cost_volume_flow_net.py:121-151 and clones) -- the grid is
+    normalised with 2x/(W-1)-1 but sampled with align_corners=False, i.e. at ((x+u)W/(W-1)-0.5, ...).
+    align_corners=True : the loss-side image warp (models/model.py:191-221, flow_model.py:49-79), samples at (x+u, y+v)."""
+    _check4(img, "img")
+    _check4(flow, "flow", 2)
+    if flow.shape[0] != img.shape[0] or flow.shape[2:] != img.shape[2:]:
+        raise ValueError("flow must be [B,2,H,W] matching img")
+    _require_hip(img, flow)
+    (x,) = _features(img)
+    return _WarpFn.apply(x, _f32(flow), flow_scale, align_corners)
+
+
+# ------------------------------------------------------------------------------------ feature normalisation
+def _moments(f):
+    B, C_, H, W = f.shape
+    sums = torch.empty((B, 2), device=f.device, dtype=torch.float64)
+    with torch.cuda.device(f.device):
+        _lib.check(_lib.load().ocf_moments(_t4(f), C.c_void_p(sums.data_ptr()), B, C_, H, W, _dtype_code(f), _stream(f)),
+                   "ocf_moments")
+    return sums
+
+
+class _NormalizeFn(Function):
+    """(f_s - mu)/sqrt(var+1e-16) with ONE scalar mu/var over {maps, batch} (correlation_layer.py:59-82);
+    gradients flow through mu and var as in the reference."""
+
+    @staticmethod
+    def forward(ctx, *feats):
+        n = float(feats[0][0].numel())
+        sums = torch.stack([_moments(f) for f in feats])  # [S,B,2] fp64
+        m1 = sums[..., 0] / n
+        var_sb = sums[..., 1] / n - m1 * m1
+        mu = m1.mean()
+        var = var_sb.mean()
+        inv_std = torch.rsqrt(var + 1e-16)
+        outs = tuple(((f.float() - mu.float()) * inv_std.float()).to(f.dtype) for f in feats)
+        ctx.save_for_backward(*feats, m1.float(), mu.float(), inv_std.float())
+        ctx.n = n
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gouts):
+        *feats, m1, mu, inv_std = ctx.saved_tensors
+        S, B = m1.shape
+        n = ctx.n
+        gsum = sum(g.float().sum() for g in gouts)
+        gdot = sum((g.float() * (f.float() - mu)).sum() for g, f in zip(gouts, feats))
+        dmu = -inv_std * gsum / (S * B * n)
+        dvar = -0.5 * gdot * inv_std ** 3
+        grads = []
+        for s, (g, f) in enumerate(zip(gouts, feats)):
+            centred = f.float() - m1[s].view(B, 1, 1, 1)
+            grads.append((g.float() * inv_std + dmu + dvar * 2.0 * centred / (S * B * n)).to(f.dtype))
+        return tuple(grads)
+
+
+def normalize_features(feature_list: Sequence[torch.Tensor], normalize=True, center=True, moments_across_channels=True,
+                       moments_across_images=True) -> List[torch.Tensor]:
+    """Drop-in for models/networks/correlation_layer.py:42-82 (defaults only, as every call site uses them)."""
+    if not (normalize and center and moments_across_channels and moments_across_images):
+        raise NotImplementedError("normalize_features: only the reference defaults are implemented")
+    feats = list(feature_list)
+    for f in feats:
+        _check4(f, "feature")
+    _require_hip(*feats)
+    if any(f.shape != feats[0].shape for f in feats):
+        raise ValueError("normalize_features: all feature maps must have the same shape")
+    feats = _features(*feats)
+    return list(_NormalizeFn.apply(*feats))
+
+
+# ------------------------------------------------------------------------------------------- photometric
+def robust_l1(x, alpha=0.001):
+    """Charbonnier penalty (models/model.py:27-35); plain elementwise helper."""
+    return (x ** 2 + alpha ** 2) ** 0.5
+
+
+class _PhotoFn(Function):
+    @staticmethod
+    def forward(ctx, img1, img2, flow, occ):
+        B, C_, H, W = img1.shape
+        sums = torch.empty(2, device=img1.device, dtype=torch.float64)
+        with torch.cuda.device(img1.device):
+            _lib.check(_lib.load().ocf_photo_loss_fwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(sums.data_ptr()),
+                                                      B, C_, H, W, _stream(img1)), "ocf_photo_loss_fwd")
+        ctx.save_for_backward(img1, img2, flow, occ)
+        num, den = sums[0].float(), sums[1].float()
+        ctx.mark_non_differentiable(den)
+        return num, den
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gnum, _gden):
+        img1, img2, flow, occ = ctx.saved_tensors
+        B, C_, H, W = img1.shape
+        n1, n2, nf, no = ctx.needs_input_grad
+        if no:
+            raise NotImplementedError("photometric_error: gradient w.r.t. the occlusion mask is not implemented "
+                                      "(the reference computes the mask under no_grad, models/model.py:381-391)")
+        if flow is not None and (n1 or n2):
+            raise NotImplementedError("warp_photometric_error: image gradients through the fused warp are not "
+                                      "implemented; use ops.warp + ops.photometric_error")
+        scale = gnum.float().reshape(1).contiguous()
+        gflow = torch.empty((B, 2, H, W), device=img1.device, dtype=torch.float32) if (flow is not None and nf) else None
+        gpred = torch.empty((B, C_, H, W), device=img1.device, dtype=torch.float32) if (flow is None and (n1 or n2)) else None
+        if gflow is not None or gpred is not None:
+            with torch.cuda.device(img1.device):
+                _lib.check(_lib.load().ocf_photo_loss_bwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(scale.data_ptr()),
+                                                          _t4(gflow), _t4(gpred), B, C_, H, W, _stream(img1)),
+                           "ocf_photo_loss_bwd")
+        g1 = -gpred if (gpred is not None and n1) else None
+        g2 = gpred if (gpred is not None and n2) else None
+        return g1, g2, gflow, None
+
+
+def _photo(img1, img2, flow, occ):
+    _check4(img1, "img")
+    _check4(img2, "img_pred")
+    if img1.shape != img2.shape:
+        raise ValueError("photometric_error: image shapes differ")
+    _require_hip(img1, img2, flow, occ)
+    if occ is not None:
+        _check4(occ, "occ", 1)
+    num, den = _PhotoFn.apply(_f32(img1), _f32(img2), _f32(flow), _f32(occ))
+    if occ is not None:
+        return num / (den * img1.shape[1] + 1e-16)
+    return num / float(img1.numel())
+
+
+def photometric_error(img_pred, img, occ=None):
+    """Drop-in for models/model.py:37-46: mean Charbonnier error, or sum(e*(1-occ)) / (3*sum(1-occ) + 1e-16)
+    (the 3 being the channel count of `img`; occ: 1 occluded, 0 visible)."""
+    return _photo(img, img_pred, None, occ)
+
+
+def warp_photometric_error(img1, img2, flow, occ=None):
+    """photometric_error(warp(img2, flow, align_corners=True), img1, occ) in one pass: the warped image is never
+    written (models/model.py:379+394 / :327-330)."""
+    _check4(flow, "flow", 2)
+    return _photo(img1, img2, flow, occ)
+
+
+# -------------------------------------------------------------------------------------------- smoothness
+def gradient(img, stride=1):
+    """Forward differences (models/model.py:53-66); plain slicing helper."""
+    assert img.dim() == 4
+    return img[:, :, :, stride:] - img[:, :, :, :-stride], img[:, :, stride:, :] - img[:, :, :-stride, :]
+
+
+class _SmoothFn(Function):
+    @staticmethod
+    def forward(ctx, img, flow, alpha):
+        B, C_, H, W = img.shape
+        sums = torch.empty(4, device=img.device, dtype=torch.float64)
+        with torch.cuda.device(img.device):
+            _lib.check(_lib.load().ocf_smooth_loss_fwd(_t4(img), _t4(flow), C.c_void_p(sums.data_ptr()), B, C_, H, W,
+                                                       float(alpha), _stream(img)), "ocf_smooth_loss_fwd")
+        ctx.save_for_backward(img, flow)
+        ctx.alpha = float(alpha)
+        return sums.float()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gsums):
+        img, flow = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("smoothness loss: gradient w.r.t. the image is not implemented")
+        B, C_, H, W = img.shape
+        coef = gsums.float().contiguous()
+        gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32)
+        with torch.cuda.device(img.device):
+            _lib.check(_lib.load().ocf_smooth_loss_bwd(_t4(img), _t4(flow), C.c_void_p(coef.data_ptr()), _t4(gflow), B, C_, H, W,
+                                                       ctx.alpha, _stream(img)), "ocf_smooth_loss_bwd")
+        return None, gflow, None
+
+
+def smoothness_losses(img, flow, alpha=100.0):
+    """(first_order, second_order) edge-aware smoothness of models/model.py:93-114 from ONE pass over img/flow."""
+    _check4(img, "img")
+    _check4(flow, "flow", 2)
+    if img.shape[0] != flow.shape[0] or img.shape[2:] != flow.shape[2:]:
+        raise ValueError("smoothness: img and flow must share B,H,W")
+    _require_hip(img, flow)
+    B, _, H, W = img.shape
+    s = _SmoothFn.apply(_f32(img), _f32(flow), alpha)
+    nan = float("nan")  # torch.mean over an empty tensor is nan in the reference too
+    n = [B * 2 * H * (W - 1), B * 2 * (H - 1) * W, B * 2 * H * (W - 2), B * 2 * (H - 2) * W]
+    inv = [1.0 / v if v > 0 else nan for v in n]
+    first = 0.5 * (s[0] * inv[0] + s[1] * inv[1])
+    second = 0.5 * (s[2] * inv[2] + s[3] * inv[3])
+    return first, second
+
+
+def first_order_smoothness_loss(img, flow, alpha=100.0):
+    """Drop-in for models/model.py:93-101."""
+    return smoothness_losses(img, flow, alpha)[0]
+
+
+def second_order_smoothness_loss(img, flow, alpha=100.0):
+    """Drop-in for models/model.py:103-114."""
+    return smoothness_losses(img, flow, alpha)[1]
+
+
+# --------------------------------------------------------------------------------------------- range map
+def _range_map(flow, want_occ):
+    _check4(flow, "flow", 2)
+    _require_hip(flow)
+    f = _f32(flow.detach())
+    B, _, H, W = f.shape
+    rng = torch.empty((B, 1, H, W), device=f.device, dtype=torch.float32)
+    occ = torch.empty_like(rng) if want_occ else None
+    with torch.cuda.device(f.device):
+        _lib.check(_lib.load().ocf_range_map(_t4(f), C.c_void_p(rng.data_ptr()), C.c_void_p(occ.data_ptr()) if want_occ else None,
+                                             B, H, W, _stream(f)), "ocf_range_map")
+    return rng, occ
+
+
+def compute_range_map(flow):
+    """Drop-in for FlowStageModel.compute_range_map (models/model.py:243-305): forward splat of the bilinear weights
+    of (grid + flow); non-differentiable (the reference calls it under no_grad and scatter_add_ has no grad to flow)."""
+    return _range_map(flow, False)[0]
+
+
+def occlusion_from_flow(flow):
+    """occ = 1 - clamp(range_map(flow), 0, 1)  (models/model.py:388-391) in the same launch sequence."""
+    return _range_map(flow, True)[1]

@@ -1,0 +1,244 @@
+"""GPU parity: every HIP kernel, called through the C ABI (ocflow_amd.ops -> libocflow_hip.so), against
+(i) the golden vectors generated from the reference and (ii) the CPU oracle on seeded inputs.
+
+Tolerances (stated per north_star: 1e-4 fp32):  fp32 kernels 2e-5 abs/rel vs golden (different summation order
+than ATen), bf16 kernels vs the oracle evaluated on the SAME bf16-rounded inputs in fp32: 2e-2 (output rounding).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ocflow_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ocflow_amd import ops as _ops
+    return _ops
+
+
+def dev(a, grad=False):
+    t = (T(a) if isinstance(a, np.ndarray) else a).to(DEV)
+    return t.requires_grad_() if grad else t
+
+
+def close(a, b, tol=2e-5):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+
+
+def layouts(t):
+    """the same logical tensor as NCHW-contiguous, channels_last and a strided channel slice"""
+    yield "nchw", t.contiguous()
+    yield "cl", t.contiguous(memory_format=torch.channels_last)
+    big = torch.zeros((t.shape[0], t.shape[1] + 3, t.shape[2], t.shape[3] + 2), device=t.device, dtype=t.dtype)
+    big[:, 2:2 + t.shape[1], :, 1:1 + t.shape[3]] = t
+    yield "view", big[:, 2:2 + t.shape[1], :, 1:1 + t.shape[3]]
+
+
+# ------------------------------------------------------------------------------------------- cost volume
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_corr_golden(ops, golden, tag):
+    g = golden("corr")
+    d = int(g[f"{tag}_d"])
+    for (n1, f1), (n2, f2) in zip(layouts(dev(g[f"{tag}_f1"])), layouts(dev(g[f"{tag}_f2"]))):
+        f1 = f1.detach().requires_grad_()
+        f2 = f2.detach().requires_grad_()
+        out = ops.compute_cost_volume(f1, f2, d)
+        close(out, g[f"{tag}_out"])
+        gf1, gf2 = torch.autograd.grad(out, (f1, f2), dev(g[f"{tag}_cot"]))
+        close(gf1, g[f"{tag}_gf1"])
+        close(gf2, g[f"{tag}_gf2"])
+
+
+@pytest.mark.parametrize("shape,d", [((2, 32, 21, 45), 4), ((1, 196, 7, 16), 4), ((1, 64, 9, 70), 4), ((2, 16, 33, 33), 2),
+                                      ((1, 40, 8, 32), 3), ((1, 3, 1, 1), 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [False, True])
+def test_corr_vs_oracle(ops, shape, d, dtype, cl):
+    gen = torch.Generator().manual_seed(hash((shape, d)) & 0xffff)
+    f1 = torch.randn(shape, generator=gen).to(dtype)
+    f2 = torch.randn(shape, generator=gen).to(dtype)
+    ref = O.compute_cost_volume(f1.float(), f2.float(), d)
+    a, b = f1.to(DEV), f2.to(DEV)
+    if cl:
+        a, b = a.contiguous(memory_format=torch.channels_last), b.contiguous(memory_format=torch.channels_last)
+    out = ops.compute_cost_volume(a, b, d)
+    assert out.dtype == dtype and out.shape == ref.shape
+    close(out, ref, 2e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("ac", [False, True])
+@pytest.mark.parametrize("with_occ", [False, True])
+@pytest.mark.parametrize("cl", [False, True])
+def test_corr_warp_fused(ops, ac, with_occ, cl):
+    gen = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 24, 19, 37
+    f1 = torch.randn((B, C, H, W), generator=gen).requires_grad_()
+    f2 = torch.randn((B, C, H, W), generator=gen).requires_grad_()
+    flow = (torch.randn((B, 2, H, W), generator=gen) * 2.5).requires_grad_()
+    occ = torch.rand((B, 1, H, W), generator=gen).requires_grad_() if with_occ else None
+    cot = torch.randn((B, 81, H, W), generator=gen)
+    ref = O.corr_warp(f1, f2, flow, occ, 4, 1.25, ac)
+    ins = (f1, f2, flow) + ((occ,) if with_occ else ())
+    gref = torch.autograd.grad(ref, ins, cot)
+
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    a = f1.detach().to(DEV).contiguous(memory_format=fmt).requires_grad_()
+    b = f2.detach().to(DEV).contiguous(memory_format=fmt).requires_grad_()
+    fl = flow.detach().to(DEV).requires_grad_()
+    oc = occ.detach().to(DEV).requires_grad_() if with_occ else None
+    out = ops.corr_warp(a, b, fl, oc, 4, 1.25, ac)
+    close(out, ref, 3e-5)
+    gins = (a, b, fl) + ((oc,) if with_occ else ())
+    gout = torch.autograd.grad(out, gins, cot.to(DEV))
+    for x, y in zip(gout, gref):
+        close(x, y, 1e-4)
+
+
+def test_corr_occ_only(ops):
+    """flow_occ_net.py:167-168:  warped2 *= occ ; corr(feat1, warped2)  with warped2 already materialised"""
+    gen = torch.Generator().manual_seed(6)
+    f1 = torch.randn((1, 32, 14, 32), generator=gen)
+    f2 = torch.randn((1, 32, 14, 32), generator=gen)
+    occ = torch.rand((1, 1, 14, 32), generator=gen)
+    close(ops.corr_warp(f1.to(DEV), f2.to(DEV), None, occ.to(DEV)), O.compute_cost_volume(f1, f2 * occ, 4))
+
+
+def test_corr_errors(ops):
+    f = torch.zeros((1, 4, 8, 8), device=DEV)
+    with pytest.raises(ValueError):
+        ops.compute_cost_volume(f, f, 5)
+    with pytest.raises(ValueError):
+        ops.compute_cost_volume(f, f[:, :2], 4)
+    with pytest.raises(RuntimeError):
+        ops.compute_cost_volume(f.cpu(), f.cpu(), 4)
+
+
+# --------------------------------------------------------------------------------------------------- warp
+@pytest.mark.parametrize("tag", ["main", "h1", "w1", "s22", "s11"])
+@pytest.mark.parametrize("ac", [0, 1])
+def test_warp_golden(ops, golden, tag, ac):
+    g = golden("warp")
+    for name, img in layouts(dev(g[f"{tag}_img"])):
+        img = img.detach().requires_grad_()
+        flow = dev(g[f"{tag}_flow"], True)
+        out = ops.warp(img, flow, bool(ac))
+        close(out, g[f"{tag}_out_ac{ac}"])
+        gi, gf = torch.autograd.grad(out, (img, flow), dev(g[f"{tag}_cot"]))
+        close(gi, g[f"{tag}_gimg_ac{ac}"])
+        close(gf, g[f"{tag}_gflow_ac{ac}"], 5e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [False, True])
+def test_warp_vs_oracle(ops, dtype, cl):
+    gen = torch.Generator().manual_seed(9)
+    img = torch.randn((2, 40, 23, 31), generator=gen).to(dtype)
+    flow = torch.randn((2, 2, 23, 31), generator=gen) * 4
+    ref = O.warp(img.float(), flow * 0.625, False)
+    a = img.to(DEV)
+    if cl:
+        a = a.contiguous(memory_format=torch.channels_last)
+    out = ops.warp(a, flow.to(DEV), False, flow_scale=0.625)
+    close(out, ref, 2e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_warp_zero_flow_identity(ops):
+    img = torch.randn((1, 3, 9, 11), device=DEV)
+    close(ops.warp(img, torch.zeros((1, 2, 9, 11), device=DEV), True), img, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def test_losses_golden(ops, golden):
+    g = golden("losses")
+    img1, img2, occ = dev(g["img1"]), dev(g["img2"]), dev(g["occ"])
+    for tag, o in (("none", None), ("occ", occ)):
+        pred = dev(g["pred"], True)
+        L = ops.photometric_error(pred, img1, o)
+        close(L, g[f"photo_{tag}"], 1e-5)
+        close(torch.autograd.grad(L, pred)[0], g[f"photo_{tag}_gpred"], 1e-5)
+        flow = dev(g["flow"], True)
+        L = ops.warp_photometric_error(img1, img2, flow, o)
+        close(L, g[f"warpphoto_{tag}"], 1e-5)
+        close(torch.autograd.grad(L, flow)[0], g[f"warpphoto_{tag}_gflow"], 1e-5)
+    for itag, im in (("noise", img1), ("smooth", dev(g["simg"]))):
+        flow = dev(g["flow"], True)
+        s1, s2 = ops.smoothness_losses(im, flow)
+        close(s1, g[f"smooth1_{itag}"], 1e-5)
+        close(s2, g[f"smooth2_{itag}"], 1e-5)
+        close(torch.autograd.grad(s1, flow, retain_graph=True)[0], g[f"smooth1_{itag}_gflow"], 1e-5)
+        close(torch.autograd.grad(s2, flow)[0], g[f"smooth2_{itag}_gflow"], 1e-5)
+    close(ops.photometric_error(img1, img1), np.float32(0.001), 1e-6)
+
+
+def test_losses_strided_views(ops):
+    """the training step passes views: imgs[:, 0:3], imgs[:, 3:6] of the [B,6,H,W] batch (models/model.py:322)"""
+    gen = torch.Generator().manual_seed(12)
+    imgs = torch.rand((2, 6, 20, 28), generator=gen) * 2 - 1
+    flow = (torch.randn((2, 2, 20, 28), generator=gen) * 1.5).requires_grad_()
+    occ = (torch.rand((2, 1, 20, 28), generator=gen) < 0.3).float()
+    ref = O.photometric_error(O.warp(imgs[:, 3:6], flow, True), imgs[:, 0:3], occ)
+    (gref,) = torch.autograd.grad(ref, flow)
+    di = imgs.to(DEV)
+    fl = flow.detach().to(DEV).requires_grad_()
+    L = ops.warp_photometric_error(di[:, 0:3], di[:, 3:6], fl, occ.to(DEV))
+    close(L, ref, 1e-5)
+    close(torch.autograd.grad(L, fl)[0], gref, 1e-5)
+
+
+# --------------------------------------------------------------------------------------------- range map
+@pytest.mark.parametrize("tag", ["a", "b", "zero"])
+def test_range_map_golden(ops, golden, tag):
+    g = golden("range_map")
+    flow = dev(g[f"{tag}_flow"])
+    close(ops.compute_range_map(flow), g[f"{tag}_range"], 1e-5)
+    close(ops.occlusion_from_flow(flow), g[f"{tag}_occ"], 1e-5)
+
+
+def test_range_map_mass_conservation(ops):
+    """size-independent property at the full Sintel size: sum(range) == sum of in-bounds bilinear weights"""
+    gen = torch.Generator().manual_seed(3)
+    flow = torch.randn((2, 2, 436, 1024), generator=gen) * 3
+    rm = ops.compute_range_map(flow.to(DEV))
+    ref = O.compute_range_map(flow)
+    assert abs(float(rm.double().sum()) - float(ref.double().sum())) <= 1e-5 * float(ref.double().sum())
+    close(rm, ref, 1e-4)
+
+
+# ------------------------------------------------------------------------------------ feature normalise
+def test_normalize_golden(ops, golden):
+    g = golden("norm")
+    f1, f2 = dev(g["f1"], True), dev(g["f2"], True)
+    n1, n2 = ops.normalize_features([f1, f2])
+    close(n1, g["n1"], 1e-5)
+    close(n2, g["n2"], 1e-5)
+    gf1, gf2 = torch.autograd.grad((n1 * dev(g["c1"])).sum() + (n2 * dev(g["c2"])).sum(), (f1, f2))
+    close(gf1, g["gf1"], 5e-5)
+    close(gf2, g["gf2"], 5e-5)
+
+
+# ------------------------------------------------------------------- full-size, size-independent properties
+def test_full_size_properties(ops):
+    """BASELINE configs[1] level-2 shape (B=1, C=32, 109x256, d=4): linearity in f2, centre channel identity,
+    zero-flow fused warp == plain correlation (AC-True), bf16 path close to fp32 path."""
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    shape = (1, 32, 109, 256)
+    f1 = torch.randn(shape, device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+    f2 = torch.randn(shape, device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+    f3 = torch.randn(shape, device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+    cv = ops.compute_cost_volume(f1, f2)
+    close(cv[:, 40], (f1 * f2).mean(1), 1e-5)
+    close(ops.compute_cost_volume(f1, 2.0 * f2 + f3), 2.0 * cv + ops.compute_cost_volume(f1, f3), 2e-5)
+    zf = torch.zeros((1, 2, 109, 256), device=DEV)
+    close(ops.corr_warp(f1, f2, zf, None, 4, 1.0, True), cv, 1e-5)
+    cvb = ops.compute_cost_volume(f1.bfloat16(), f2.bfloat16())
+    close(cvb, ops.compute_cost_volume(f1.bfloat16().float(), f2.bfloat16().float()), 2e-2)
+    # NCHW and channels_last agree bit for bit on the same data (same arithmetic order)
+    assert torch.equal(ops.compute_cost_volume(f1.contiguous(), f2.contiguous()), cv.contiguous())
