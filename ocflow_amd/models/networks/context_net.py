@@ -1,0 +1,19 @@
+"""Dilated-conv flow refinement (reference: models/networks/context_net.py:5-28).  PyTorch-ROCm convs."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+_PLAN = ((128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (2, 1))  # (out channels, dilation)
+
+
+class ContextNetwork(nn.Module):
+    def __init__(self, input_channels):
+        super().__init__()
+        cin = input_channels
+        for i, (cout, dil) in enumerate(_PLAN, start=1):
+            setattr(self, f"conv{i}", nn.Conv2d(cin, cout, 3, 1, dil, dil))
+            cin = cout
+
+    def forward(self, x):
+        for i in range(1, len(_PLAN)):
+            x = F.leaky_relu(getattr(self, f"conv{i}")(x), negative_slope=0.1)
+        return getattr(self, f"conv{len(_PLAN)}")(x)

@@ -1,0 +1,121 @@
+"""`FlowNetCV` (model 'pwc'): PWC-Net-style 6-level siamese encoder, per level {normalise -> warp -> cost volume ->
+LeakyReLU -> 5 dense-connected convs -> flow}, dilated context net (reference:
+models/networks/cost_volume_flow_net.py:22-246).  Convolutions stay in PyTorch-ROCm; warp / cost volume /
+feature-moment kernels are HIP (ocflow_amd.ops).  Parameter names are the reference's (checkpoint compatible)."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ocflow_amd import ops
+
+ENC_WIDTHS = (3, 16, 32, 64, 96, 128, 196)
+DENSE_WIDTHS = (128, 128, 96, 64, 32)
+DENSE_TOTAL = int(np.sum(DENSE_WIDTHS))
+# level -> scale applied to the up-sampled flow before warping (20 / 2^level; cost_volume_flow_net.py:186,201,216,231)
+WARP_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}
+
+
+def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
+    return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding,
+                                   dilation=dilation, bias=True), nn.LeakyReLU(0.1))
+
+
+def predict_flow(in_planes):
+    return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
+
+
+def deconv(in_planes, out_planes, kernel_size=4, stride=2, padding=1):
+    return nn.ConvTranspose2d(in_planes, out_planes, kernel_size, stride, padding, bias=True)
+
+
+def build_encoder(net):
+    """conv{L}a (stride 2), conv{L}aa, conv{L}b for L=1..5; level 6 is registered as conv6aa (stride 2), conv6a, conv6b"""
+    for lvl in range(1, 7):
+        cin, cout = ENC_WIDTHS[lvl - 1], ENC_WIDTHS[lvl]
+        names = ("a", "aa", "b") if lvl < 6 else ("aa", "a", "b")
+        for j, suffix in enumerate(names):
+            setattr(net, f"conv{lvl}{suffix}", conv(cin if j == 0 else cout, cout, stride=2 if j == 0 else 1))
+
+
+def encode(net, im):
+    feats = []
+    x = im
+    for lvl in range(1, 7):
+        names = ("a", "aa", "b") if lvl < 6 else ("aa", "a", "b")
+        for suffix in names:
+            x = getattr(net, f"conv{lvl}{suffix}")(x)
+        feats.append(x)
+    return feats  # c1..c6
+
+
+def build_context(net, in_planes):
+    plan = ((128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1))
+    cin = in_planes
+    for i, (cout, dil) in enumerate(plan, start=1):
+        setattr(net, f"dc_conv{i}", conv(cin, cout, padding=dil, dilation=dil))
+        cin = cout
+    net.dc_conv7 = predict_flow(32)
+
+
+def context(net, x):
+    for i in range(1, 7):
+        x = getattr(net, f"dc_conv{i}")(x)
+    return net.dc_conv7(x)
+
+
+def dense_block(net, lvl, x):
+    """DenseNet connectivity, newest features FIRST: x = cat(conv(x), x)  (cost_volume_flow_net.py:176-180)"""
+    for j in range(5):
+        x = torch.cat((getattr(net, f"conv{lvl}_{j}")(x), x), 1)
+    return x
+
+
+class FlowNetCV(nn.Module):
+    def __init__(self, displacement=4):
+        super().__init__()
+        build_encoder(self)
+        self.normalize = ops.normalize_features
+        self.leakyRELU = nn.LeakyReLU(0.1)
+        self.displacement = displacement
+        nd = (2 * displacement + 1) ** 2
+        for lvl in range(6, 1, -1):
+            od = nd if lvl == 6 else nd + ENC_WIDTHS[lvl] + 4
+            cin = od
+            for j, w in enumerate(DENSE_WIDTHS):
+                setattr(self, f"conv{lvl}_{j}", conv(cin, w))
+                cin += w
+            setattr(self, f"predict_flow{lvl}", predict_flow(cin))
+            setattr(self, f"deconv{lvl}", deconv(2, 2))
+            if lvl > 2:
+                setattr(self, f"upfeat{lvl}", deconv(cin, 2))
+        build_context(self, nd + ENC_WIDTHS[2] + 4 + DENSE_TOTAL)
+        # default PyTorch init, as in the reference (its kaiming block is commented out, :114-118)
+
+    def warp(self, img, flow):
+        """feature warp, align_corners=False variant (cost_volume_flow_net.py:121-151)"""
+        return ops.warp(img, flow, align_corners=False)
+
+    def forward(self, x):
+        c1 = encode(self, x[:, :3])
+        c2 = encode(self, x[:, 3:])
+        up_flow = up_feat = flow = feats = None
+        for lvl in range(6, 1, -1):
+            f1, f2 = c1[lvl - 1], c2[lvl - 1]
+            if lvl < 6:
+                f2 = ops.warp(f2, up_flow, False, flow_scale=WARP_SCALE[lvl])
+            f1, f2 = self.normalize([f1, f2])
+            corr = self.leakyRELU(ops.compute_cost_volume(f1, f2, max_displacement=self.displacement))
+            if lvl == 6:
+                feats = corr
+            else:
+                # the NORMALISED c1 is what enters the decoder (:190)
+                feats = torch.cat((corr, f1, up_flow.to(corr.dtype), up_feat.to(corr.dtype)), 1)
+            feats = dense_block(self, lvl, feats)
+            flow = getattr(self, f"predict_flow{lvl}")(feats)
+            if lvl > 2:
+                up_flow = getattr(self, f"deconv{lvl}")(flow)
+                up_feat = getattr(self, f"upfeat{lvl}")(feats)
+        flow2 = flow + context(self, feats)
+        flow1 = F.interpolate(flow2.float(), scale_factor=4, mode="bilinear", align_corners=True) * 20
+        return flow1, flow2 * 5.0

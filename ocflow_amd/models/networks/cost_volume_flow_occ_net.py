@@ -1,0 +1,66 @@
+"""`FlowOccNetCV` (model 'pwoc'): FlowNetCV + per-level occlusion head; the warped second feature map is multiplied
+by the up-sampled occlusion map before the correlation (reference:
+models/networks/cost_volume_flow_occ_net.py:26-271).  On MI355X warp * occ -> cost volume is ONE kernel
+(ops.corr_warp); neither `warp5` nor `warp5 * up_occ6` (:204-206) is written to HBM."""
+import torch
+import torch.nn as nn
+
+from .cost_volume_flow_net import (DENSE_TOTAL, DENSE_WIDTHS, ENC_WIDTHS, WARP_SCALE, build_context, build_encoder, context,
+                                   conv, deconv, dense_block, encode, predict_flow)
+from .cost_volume_net import CostVolumeLayer
+from .flow_net import kaiming_init_
+from ocflow_amd import ops
+
+
+def predict_occlusion(in_planes):
+    return nn.Sequential(nn.Conv2d(in_planes, 1, kernel_size=3, stride=1, padding=1, bias=True), nn.Sigmoid())
+
+
+class FlowOccNetCV(nn.Module):
+    def __init__(self):
+        super().__init__()
+        build_encoder(self)
+        self.corr = CostVolumeLayer()
+        self.leakyRELU = nn.LeakyReLU(0.1)
+        nd = (2 * 4 + 1) ** 2
+        for lvl in range(6, 1, -1):
+            od = nd if lvl == 6 else nd + ENC_WIDTHS[lvl] + 4 + 1
+            cin = od
+            for j, w in enumerate(DENSE_WIDTHS):
+                setattr(self, f"conv{lvl}_{j}", conv(cin, w))
+                cin += w
+            setattr(self, f"predict_flow{lvl}", predict_flow(cin))
+            setattr(self, f"predict_occ{lvl}", predict_occlusion(cin))
+            if lvl > 2:
+                setattr(self, f"upflow{lvl}", deconv(2, 2))
+                setattr(self, f"upocc{lvl}", deconv(1, 1))
+                setattr(self, f"upfeat{lvl}", deconv(cin, 2))
+        build_context(self, nd + ENC_WIDTHS[2] + 4 + 1 + DENSE_TOTAL)
+        self.upsample1 = nn.Upsample(scale_factor=4, mode="bilinear")
+        self.upsample2 = nn.Upsample(scale_factor=4, mode="bilinear")
+        kaiming_init_(self)
+
+    def warp(self, img, flow):
+        """feature warp, align_corners=False variant (cost_volume_flow_occ_net.py:137-167)"""
+        return ops.warp(img, flow, align_corners=False)
+
+    def forward(self, x):
+        c1 = encode(self, x[:, :3])
+        c2 = encode(self, x[:, 3:])
+        up_flow = up_occ = up_feat = flow = occ = feats = None
+        for lvl in range(6, 1, -1):
+            f1, f2 = c1[lvl - 1], c2[lvl - 1]
+            if lvl == 6:
+                feats = self.leakyRELU(self.corr(f1, f2))
+            else:
+                corr = self.leakyRELU(self.corr(f1, f2, up_flow, up_occ, WARP_SCALE[lvl]))
+                feats = torch.cat((corr.to(f1.dtype), f1, up_flow.to(f1.dtype), up_occ.to(f1.dtype), up_feat.to(f1.dtype)), 1)
+            feats = dense_block(self, lvl, feats)
+            flow = getattr(self, f"predict_flow{lvl}")(feats)
+            occ = getattr(self, f"predict_occ{lvl}")(feats)
+            if lvl > 2:
+                up_flow = getattr(self, f"upflow{lvl}")(flow)
+                up_occ = getattr(self, f"upocc{lvl}")(occ)
+                up_feat = getattr(self, f"upfeat{lvl}")(feats)
+        flow2 = flow + context(self, feats)
+        return self.upsample1(flow2), self.upsample2(occ)

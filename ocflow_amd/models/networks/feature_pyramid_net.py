@@ -1,0 +1,58 @@
+"""Feature pyramid encoder (reference: models/networks/feature_pyramid_net.py:5-95).  Stays in PyTorch-ROCm
+(MIOpen -> MFMA); only the parameter names / shapes are contractual (state_dict compatibility)."""
+import torch.nn as nn
+
+_SLOPE = 0.1
+_WIDTHS = (3, 16, 32, 64, 96, 128, 196)
+
+
+def _conv_bn_act(cin, cout, k, stride):
+    return [nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False), nn.BatchNorm2d(cout),
+            nn.LeakyReLU(_SLOPE)]
+
+
+class DoubleConv(nn.Module):
+    """stride-2 conv + BN + LeakyReLU, then stride-1 conv + BN + LeakyReLU (keys double_conv.{0,1,3,4}.*)"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.double_conv = nn.Sequential(*_conv_bn_act(in_channels, out_channels, 3, 2),
+                                         *_conv_bn_act(out_channels, out_channels, 3, 1))
+
+    def forward(self, x):
+        return self.double_conv(x)
+
+
+class Upsample(nn.Module):
+    """transposed conv to the skip tensor's size + BN + LeakyReLU + skip add (keys deconv.*, batchnorm.*)"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.deconv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1)
+        self.batchnorm = nn.BatchNorm2d(out_channels)
+        self.leaky = nn.LeakyReLU(negative_slope=_SLOPE)
+
+    def forward(self, x, y):
+        return self.leaky(self.batchnorm(self.deconv(x, output_size=y.size()))) + y
+
+
+class FeaturePyramidNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        for lvl in range(1, 7):
+            setattr(self, f"layer{lvl}", DoubleConv(_WIDTHS[lvl - 1], _WIDTHS[lvl]))
+        self.pyr_top = nn.Sequential(nn.Conv2d(196, 196, kernel_size=1, bias=False), nn.BatchNorm2d(196), nn.LeakyReLU(_SLOPE))
+        for lvl in range(5, 1, -1):
+            setattr(self, f"upsample{lvl}", Upsample(_WIDTHS[lvl + 1], _WIDTHS[lvl]))
+
+    def forward(self, x):
+        skips = []
+        for lvl in range(1, 7):
+            x = getattr(self, f"layer{lvl}")(x)
+            skips.append(x)
+        p = self.pyr_top(skips[5])
+        pyramid = [p]
+        for lvl in range(5, 1, -1):
+            p = getattr(self, f"upsample{lvl}")(p, skips[lvl - 1])
+            pyramid.append(p)
+        return pyramid  # [p6, p5, p4, p3, p2] with 196, 128, 96, 64, 32 channels

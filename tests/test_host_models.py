@@ -1,0 +1,148 @@
+"""Host logic on CPU: the model mirror (ocflow_amd.models.*) reproduces the reference's outputs, state_dict keys and
+step scalars when its hot ops are computed by the oracle (monkeypatched in -- the product has no CPU path).
+Goldens: tests/golden/nets.npz + state_dict_manifest.json, produced by the reference with RNG-free weights."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import rngfree_fill
+from oracle_backend import patch_ops
+
+T = torch.from_numpy
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture
+def cpu_ops(monkeypatch):
+    patch_ops(monkeypatch)
+
+
+def close(a, b, tol):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+
+
+def epe(a, b):
+    return float(torch.sqrt(((a - T(b)) ** 2).sum(1)).mean())
+
+
+def test_config0_flow_model_cpu_no_patch(golden):
+    """BASELINE configs[0]: models.flow_model forward on 2 random 64x64x3 frames, CPU fp32 -- default model 'simple'
+    has no hot-path op, so it runs on CPU without any HIP kernel."""
+    from ocflow_amd.models.flow_model import FlowModel
+    g = golden("nets")
+    m = rngfree_fill(FlowModel({"learning_rate": 1e-3}))
+    m.train()
+    with torch.no_grad():
+        out = m(T(g["x64b2"]))
+    assert epe(out, g["flowmodel_simple_train"]) < 1e-4
+    rngfree_fill(m).eval()  # the train-mode pass above moved the BatchNorm running statistics
+    with torch.no_grad():
+        assert epe(m(T(g["x64"])), g["flowmodel_simple_eval"]) < 1e-4
+
+
+def test_ops_refuse_cpu():
+    from ocflow_amd import ops
+    f = torch.zeros(1, 4, 8, 8)
+    for call in (lambda: ops.compute_cost_volume(f, f), lambda: ops.warp(f, f[:, :2]), lambda: ops.compute_range_map(f[:, :2]),
+                 lambda: ops.photometric_error(f, f), lambda: ops.smoothness_losses(f, f[:, :2])):
+        with pytest.raises(RuntimeError, match="no CPU fallback|HIP"):
+            call()
+
+
+def test_unknown_model_raises():
+    from ocflow_amd.models.flow_model import FlowModel
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    with pytest.raises(ValueError, match="Unsupported model"):
+        FlowModel({"learning_rate": 1e-3, "model": "nope"})
+    with pytest.raises(ValueError, match="Unsupported model"):
+        FlowOccModel({"learning_rate": 1e-3, "model": "nope"})
+    with pytest.raises(KeyError):
+        FlowModel({})  # learning_rate is required (flow_model.py:21)
+
+
+@pytest.mark.parametrize("key,cls,name", [("flowmodel_simple", "FlowModel", "simple"), ("flowmodel_pwc", "FlowModel", "pwc"),
+                                           ("flowmodel_flownet", "FlowModel", "flownet"),
+                                           ("flowoccmodel_flowoccnet", "FlowOccModel", "flowoccnet"),
+                                           ("flowoccmodel_pwoc", "FlowOccModel", "pwoc"),
+                                           ("flowoccmodel_simple", "FlowOccModel", "simple"),
+                                           ("flowstage_pwc", "FlowStageModel", "pwc")])
+def test_state_dict_manifest(key, cls, name):
+    """checkpoint compatibility: same keys, shapes AND order as the reference's state_dict"""
+    from ocflow_amd.models.flow_model import FlowModel
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.models.model import FlowStageModel
+    with open(os.path.join(GOLDEN, "state_dict_manifest.json")) as f:
+        manifest = json.load(f)[key]
+    m = {"FlowModel": FlowModel, "FlowOccModel": FlowOccModel, "FlowStageModel": FlowStageModel}[cls](
+        {"learning_rate": 1e-3, "model": name})
+    mine = [(k, list(v.shape)) for k, v in m.state_dict().items()]
+    assert mine == [(k, list(s)) for k, s in manifest]
+
+
+def test_flow_model_pwc_and_flownet(cpu_ops, golden):
+    from ocflow_amd.models.flow_model import FlowModel
+    g = golden("nets")
+    m = rngfree_fill(FlowModel({"learning_rate": 1e-3, "model": "pwc", "displacement": 4}))
+    with torch.no_grad():
+        assert epe(m(T(g["x64"])), g["flowmodel_pwc_train"]) < 1e-4
+        full, quarter = m.flow_pred(T(g["x64"]))
+    close(full, g["flownetcv_full"], 1e-4)
+    close(quarter, g["flownetcv_quarter"], 1e-4)
+    m = rngfree_fill(FlowModel({"learning_rate": 1e-3, "model": "flownet"})).eval()
+    with torch.no_grad():
+        assert epe(m(T(g["x96"])), g["flowmodel_flownet_eval"]) < 1e-4
+
+
+def test_flow_occ_models(cpu_ops, golden):
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    g = golden("nets")
+    m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"})).eval()
+    with torch.no_grad():
+        fl, oc = m(T(g["x96"]))
+    assert epe(fl, g["flowoccmodel_flowoccnet_eval_flow"]) < 1e-4
+    assert float((oc - T(g["flowoccmodel_flowoccnet_eval_occ"])).abs().mean()) < 1e-4
+    m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "pwoc"}))
+    with torch.no_grad():
+        fl, oc = m(T(g["x64"]))
+    assert epe(fl, g["flowoccmodel_pwoc_train_flow"]) < 1e-4
+    assert float((oc - T(g["flowoccmodel_pwoc_train_occ"])).abs().mean()) < 1e-4
+    m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3}))
+    with torch.no_grad():
+        fl, oc = m(T(g["x64b2"]))
+    assert epe(fl, g["flowoccmodel_simple_train_flow"]) < 1e-4
+    close(oc, g["flowoccmodel_simple_train_occ"], 1e-4)
+
+
+def test_supervised_step_with_grads(cpu_ops, golden):
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    g = golden("nets")
+    m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "pwoc"}))
+    fl_loss, oc_loss = m.general_step((T(g["x64"]), T(g["pwoc_step_gt_flow"]), T(g["pwoc_step_gt_occ"])), 0, "train")
+    close(fl_loss, g["pwoc_step_flow_loss"], 1e-5)
+    close(oc_loss, g["pwoc_step_occ_loss"], 1e-5)
+    (fl_loss + oc_loss).backward()
+    close(m.model.conv2_0[0].weight.grad[:4, :8], g["pwoc_step_grad_conv2_0"], 2e-5)
+    close(m.model.conv1a[0].weight.grad, g["pwoc_step_grad_conv1a"], 2e-4)
+    opt = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 1e-3
+
+
+@pytest.mark.parametrize("occ_aware,tag", [(True, "occaware"), (False, "plain")])
+def test_unsupervised_stage_step(cpu_ops, golden, occ_aware, tag):
+    from ocflow_amd.models.model import FlowStageModel
+    g = golden("nets")
+    hp = dict(learning_rate=1e-5, model="pwc", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0,
+              with_occ=False, occ_aware=occ_aware)
+    m = rngfree_fill(FlowStageModel(hp))
+    batch = (T(g["stage_x"]), T(g["stage_gt_flow"]), T(g["stage_gt_occ"]))
+    res = m.general_step_occ_aware(batch, 0, "train") if occ_aware else m.general_step(batch, 0, "train")
+    close(torch.stack([r.detach() for r in res]), g[f"stage_{tag}_scalars"], 2e-5)
+    loss = m.training_step(batch, 0)
+    close(loss, g[f"stage_{tag}_loss"], 2e-5)
+    loss.backward()
+    close(m.flow_pred.predict_flow2.weight.grad[:, :16], g[f"stage_{tag}_grad_predict_flow2"], 5e-5)
+    close(m.flow_pred.conv1a[0].weight.grad, g[f"stage_{tag}_grad_conv1a"], 5e-4)
