@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the OCFlow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+metric (BASELINE.json): image-pairs/sec at 436x1024 bf16 + corr-kernel HBM GB/s.
+A "step" = ONE full training step of `FlowOccModel({'model': 'flowoccnet'})` (BASELINE configs[1]: flow_occ_model,
+436x1024 Sintel-style pairs, corr d=4, 5 pyramid levels) on one per-GPU shard of synthetic pairs: forward through the
+FPN + 5 woc levels (HIP warp + fused mask/correlation kernels) + L1/BCE loss + backward + Adam, bf16 autocast,
+channels_last, inputs resident in HBM before the timed region.  Per-GPU shard = `--batch` pairs (default 8 = the
+per-rank share of configs[4], "batch 64 across 8 GPUs"); weak scaling: per-GPU work is fixed as N grows.
+
+One JSON line on rank 0 with, besides the driver contract keys:
+  roofline     -- the fused correlation kernel (`corr_fwd_tiled`): algorithmic bytes of all its launches in the timed
+                  region / their HIP-event durations (events recorded on the launch stream), vs the 8 TB/s HBM3E peak.
+  cpu_baseline -- the oracle (CPU restatement of the reference's op structure, "port") running the SAME training step
+                  at batch 1, fp32, on this box's host cores (N=1 only, bounded to ~20 s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=8, help="image pairs per GPU per step")
+    p.add_argument("--height", type=int, default=436)
+    p.add_argument("--width", type=int, default=1024)
+    p.add_argument("--model", default="flowoccnet", choices=["flowoccnet", "pwoc"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--layout", default="cl", choices=["cl", "nchw"])
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables it)")
+    p.add_argument("--ops-only", action="store_true", help="also time the correlation launches alone (no convs)")
+    return p.parse_args()
+
+
+def build_stepper(args, env):
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.runtime import TrainStepper
+    torch.manual_seed(42)
+    module = FlowOccModel({"model": args.model, "learning_rate": 1e-4})
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+    return TrainStepper(module, env, amp_dtype=amp, channels_last=(args.layout == "cl"))
+
+
+def usable_cores() -> int:
+    """host cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (the GPU box gives a
+    one-GPU job a 16-core share of a much larger host; oversubscribing it makes the CPU leg crawl)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(q / int(f2.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, int(os.environ.get("OCFLOW_CPU_CORES", "32"))))
+
+
+def cpu_baseline(args, budget_s):
+    """Reference CPU path (oracle = port of the reference's ATen op structure) on the host cores: same model, same
+    training step, batch 1, fp32.  Bounded sample: the first step is the probe; further steps only while they fit the
+    budget.  Progress goes to stderr (a silent GPU box is taken for hung)."""
+    from oracle.backend import oracle_ops
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.runtime import DistEnv, TrainStepper, synthetic_batch
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    env = DistEnv()
+    times = []
+    with oracle_ops():
+        torch.manual_seed(42)
+        stepper = TrainStepper(FlowOccModel({"model": args.model, "learning_rate": 1e-4}), env, amp_dtype=None,
+                               channels_last=False)
+        batch = synthetic_batch(1, args.height, args.width, "cpu", seed=42)
+        t_start = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            stepper.step(batch)
+            times.append(time.perf_counter() - t0)
+            print(f"[bench] cpu_baseline step {len(times)}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
+            spent = time.perf_counter() - t_start
+            if len(times) >= 4 or spent + times[-1] > budget_s:
+                break
+    timed = times[1:] if len(times) > 1 else times  # first step pays allocator / oneDNN primitive warm-up
+    dt = sum(timed) / len(timed)
+    return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{len(timed)} training step(s){' after 1 warm-up' if len(times) > 1 else ' (cold)'} of "
+                      f"FlowOccModel('{args.model}') at batch 1, {args.height}x{args.width}, fp32, oracle ops "
+                      f"(pad-and-shift correlation, grid_sample warp), {dt:.2f} s/step"}
+
+
+def main():
+    args = parse()
+    from ocflow_amd import ops
+    from ocflow_amd.runtime import (KernelTimer, all_reduce_max, barrier, init_distributed, shutdown_distributed,
+                                    synthetic_batch)
+    env = init_distributed()
+    if env.device.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X: the OCFlow hot path has no CPU fallback")
+    if args.gpus != env.world_size:
+        if env.world_size == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.backends.cudnn.benchmark = False
+
+    stepper = build_stepper(args, env)
+    B = args.batch
+    batch = stepper.prepare(synthetic_batch(B, args.height, args.width, env.device, seed=42, index_offset=env.rank * B))
+
+    t_w = time.perf_counter()
+    for i in range(args.warmup):
+        stepper.step(batch)
+        if env.is_main:  # the first step JIT-compiles MIOpen kernels on a fresh box (tens of seconds): show progress
+            torch.cuda.synchronize()
+            print(f"[bench] warm-up step {i + 1}/{args.warmup} done at {time.perf_counter() - t_w:.1f} s", file=sys.stderr, flush=True)
+    timer = KernelTimer()
+    ops.set_kernel_timer(timer)
+    barrier(env)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = stepper.step(batch, i)
+    torch.cuda.synchronize()
+    barrier(env)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    elapsed = all_reduce_max(env, elapsed)
+    loss_val = float(loss)
+
+    # ---- roofline of the dominant hot-path kernel, from the launches of the timed region itself
+    summ = timer.summary().get("corr_fwd", None)
+    roofline = None
+    if summ and summ["ms_total"] > 0:
+        achieved = summ["bytes_total"] / (summ["ms_total"] * 1e-3) / 1e9
+        per_level = {k: {"launches": v["launches"], "avg_us": round(1e3 * v["ms_total"] / v["launches"], 2),
+                         "GBps": round(v["bytes"] / (1e-3 * v["ms_total"] / v["launches"]) / 1e9, 1)}
+                     for k, v in summ["by_shape"].items()}
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "corr_fwd_tiled",
+                    "launches": summ["launches"], "avg_launch_us": round(1e3 * summ["ms_total"] / summ["launches"], 2),
+                    "tflops": round(summ["flops_total"] / (summ["ms_total"] * 1e-3) / 1e12, 2), "per_level": per_level}
+
+    cpu = None
+    if env.is_main and env.world_size == 1 and args.cpu_seconds > 0:
+        try:
+            cpu = cpu_baseline(args, args.cpu_seconds)
+        except Exception as e:  # the GPU numbers stay valid without the baseline
+            cpu = {"value": None, "unit": "image-pairs/s", "cores": usable_cores(), "kind": "port", "sample": f"failed: {e}"}
+
+    if env.is_main:
+        n = env.world_size
+        pairs = B * n * args.steps
+        line = {
+            "metric": "image-pairs/sec at 436x1024 bf16 (training step)", "value": round(pairs / elapsed, 3),
+            "unit": "image-pairs/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"flow_occ_model FlowOccModel('{args.model}') full training step, {args.height}x{args.width} "
+                                   f"Sintel-style pairs, corr d=4, 5 pyramid levels, {B} pairs/GPU (BASELINE configs[1] "
+                                   f"shape; per-rank share of configs[4])",
+                       "global_batch": B * n, "height": args.height, "width": args.width, "layout": args.layout,
+                       "parallelism": f"dp{n}", "final_loss": round(loss_val, 5)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    shutdown_distributed()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,12 @@ import ctypes as C
 import os
 import threading
 
+# ONE HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so; importing torch first makes the dynamic linker
+# bind libocflow_hip.so's NEEDED libamdhip64.so.7 to that already-loaded copy.  Loaded the other way round (our library
+# first, against /opt/rocm) the process ends up with two runtimes and torch's stream handles are invalid in ours
+# (every launch fails with OCF_ELAUNCH) -- observed on the MI355X box, see DESIGN.md "Boundary".
+import torch  # noqa: F401  (load order, not an API dependency: the C ABI has no torch types)
+
 from . import build as _build
 
 OCF_F32, OCF_BF16 = 0, 1

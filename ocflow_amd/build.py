@@ -40,7 +40,7 @@ def _stamp() -> str:
     for p in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
             [os.path.join(INCLUDE, "ocflow_hip.h"), os.path.abspath(__file__)]:
         with open(p, "rb") as f:
-            h.update(p.encode()); h.update(f.read())
+            h.update(os.path.basename(p).encode()); h.update(f.read())  # path-independent: no rebuild on the GPU box
     return h.hexdigest()
 
 

@@ -286,6 +286,7 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
 extern "C" int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                             const ocf_tensor4* out, int B, int C, int H, int W, int d, float flow_scale, int align_corners,
                             int dtype, void* stream) {
+  ocf::clear_stale_error();
   if (!f1 || !f2 || !out || !f1->data || !f2->data || !out->data) return OCF_EINVAL;
   if ((flow && !flow->data) || (occ && !occ->data)) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
@@ -298,6 +299,7 @@ extern "C" int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const 
 
 extern "C" int ocf_corr_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* gout, const ocf_tensor4* g1,
                             const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, void* stream) {
+  ocf::clear_stale_error();
   if (!f1 || !w2 || !gout || !f1->data || !w2->data || !gout->data) return OCF_EINVAL;
   if ((g1 && !g1->data) || (g2 && !g2->data) || (!g1 && !g2)) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;

@@ -304,6 +304,7 @@ using namespace ocf;
 
 extern "C" int ocf_photo_loss_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const ocf_tensor4* flow,
                                   const ocf_tensor4* occ, double* sums, int B, int C, int H, int W, void* stream) {
+  ocf::clear_stale_error();
   if (!img1 || !img2 || !sums || !img1->data || !img2->data) return OCF_EINVAL;
   if ((flow && !flow->data) || (occ && !occ->data)) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
@@ -318,6 +319,7 @@ extern "C" int ocf_photo_loss_fwd(const ocf_tensor4* img1, const ocf_tensor4* im
 extern "C" int ocf_photo_loss_bwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const ocf_tensor4* flow,
                                   const ocf_tensor4* occ, const float* scale, const ocf_tensor4* gflow,
                                   const ocf_tensor4* gpred, int B, int C, int H, int W, void* stream) {
+  ocf::clear_stale_error();
   if (!img1 || !img2 || !scale || !img1->data || !img2->data) return OCF_EINVAL;
   if ((flow && !flow->data) || (occ && !occ->data) || (gflow && !gflow->data) || (gpred && !gpred->data)) return OCF_EINVAL;
   if ((flow && !gflow) || (!flow && !gpred)) return OCF_EINVAL;
@@ -331,6 +333,7 @@ extern "C" int ocf_photo_loss_bwd(const ocf_tensor4* img1, const ocf_tensor4* im
 
 extern "C" int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, double* sums, int B, int C, int H, int W,
                                    float alpha, void* stream) {
+  ocf::clear_stale_error();
   if (!img || !flow || !sums || !img->data || !flow->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -342,6 +345,7 @@ extern "C" int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* fl
 
 extern "C" int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const float* coef, const ocf_tensor4* gflow,
                                    int B, int C, int H, int W, float alpha, void* stream) {
+  ocf::clear_stale_error();
   if (!img || !flow || !coef || !gflow || !img->data || !flow->data || !gflow->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
@@ -351,6 +355,7 @@ extern "C" int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* fl
 }
 
 extern "C" int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, int B, int H, int W, void* stream) {
+  ocf::clear_stale_error();
   if (!flow || !flow->data || !range) return OCF_EINVAL;
   if (B <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -362,6 +367,7 @@ extern "C" int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, 
 }
 
 extern "C" int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int H, int W, int dtype, void* stream) {
+  ocf::clear_stale_error();
   if (!f || !f->data || !sums) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;

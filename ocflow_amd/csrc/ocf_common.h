@@ -157,6 +157,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// hipGetLastError() is sticky per thread: a failed query inside the caller's framework (e.g. hipPointerGetAttributes
+// on pageable host memory during a torch H2D copy) would otherwise be reported as OUR launch failing.
+static inline void clear_stale_error() { (void)hipGetLastError(); }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? OCF_OK : OCF_ELAUNCH; }
 
 }  // namespace ocf

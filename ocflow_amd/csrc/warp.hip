@@ -152,6 +152,7 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
 
 extern "C" int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* out, int B, int C, int H,
                             int W, float flow_scale, int align_corners, int dtype, void* stream) {
+  ocf::clear_stale_error();
   if (!img || !flow || !out || !img->data || !flow->data || !out->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -163,6 +164,7 @@ extern "C" int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, con
 extern "C" int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
                             const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners,
                             int dtype, void* stream) {
+  ocf::clear_stale_error();
   if (!img || !flow || !gout || !img->data || !flow->data || !gout->data) return OCF_EINVAL;
   if ((gimg && !gimg->data) || (gflow && !gflow->data) || (!gimg && !gflow)) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;

@@ -28,6 +28,23 @@ __all__ = [
 
 MAX_DISPLACEMENT = 4
 
+_KERNEL_TIMER = None
+
+
+def set_kernel_timer(timer):
+    """Install (or remove with None) a runtime.KernelTimer: the cost-volume launches are then bracketed by HIP events
+    on the launch stream and tagged with their algorithmic bytes / FLOPs (bench.py's roofline leg)."""
+    global _KERNEL_TIMER
+    _KERNEL_TIMER = timer
+
+
+def corr_fwd_algorithmic(B, C, H, W, d, elem_size, has_flow, has_occ):
+    """Bytes one fused correlation launch must move: read f1 and f2 once (2*C*s), the flow (8 B/px) and
+    occlusion (4 B/px) fields when present, write (2d+1)^2 outputs (s each); FLOPs = 2*C per output."""
+    n = (2 * d + 1) ** 2
+    px = B * H * W
+    return px * (2 * C * elem_size + (8 if has_flow else 0) + (4 if has_occ else 0) + n * elem_size), px * n * 2 * C
+
 
 # ------------------------------------------------------------------------------------------------ plumbing
 def _require_hip(*tensors):
@@ -119,10 +136,17 @@ class _CorrWarpFn(Function):
         B, C_, H, W = f1.shape
         n = 2 * d + 1
         out = _empty_like_layout(f1, (B, n * n, H, W))
-        with torch.cuda.device(f1.device):
-            _lib.check(_lib.load().ocf_corr_fwd(_t4(f1), _t4(f2), _t4(flow), _t4(occ), _t4(out), B, C_, H, W, d,
-                                                float(flow_scale), int(bool(align_corners)), _dtype_code(f1), _stream(f1)),
-                       "ocf_corr_fwd")
+        def launch():
+            with torch.cuda.device(f1.device):
+                _lib.check(_lib.load().ocf_corr_fwd(_t4(f1), _t4(f2), _t4(flow), _t4(occ), _t4(out), B, C_, H, W, d,
+                                                    float(flow_scale), int(bool(align_corners)), _dtype_code(f1),
+                                                    _stream(f1)), "ocf_corr_fwd")
+
+        if _KERNEL_TIMER is not None:
+            nbytes, flops = corr_fwd_algorithmic(B, C_, H, W, d, f1.element_size(), flow is not None, occ is not None)
+            _KERNEL_TIMER.launch("corr_fwd", {"bytes": nbytes, "flops": flops, "shape": f"B{B}xC{C_}x{H}x{W}"}, launch)
+        else:
+            launch()
         ctx.save_for_backward(f1, f2, flow, occ)
         ctx.cfg = (d, float(flow_scale), bool(align_corners))
         return out

@@ -1,0 +1,210 @@
+"""Process-level runtime around the hot path: one process per GPU (`torch.distributed`, backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" on CPU-only hosts), data-parallel sharding of image pairs, synthetic Sintel-shaped batches
+generated on the device, a bf16 / channels_last training stepper, and a HIP-event kernel timer.
+
+Sharding: image pairs are independent; a global batch is split into contiguous per-rank shards;
+the only exchange is the gradient all-reduce (mean) that DistributedDataParallel overlaps with backward.  Batch-coupled
+statistics (BatchNorm in the FPN, the feature-normalisation scalars of FlowNetCV) stay per-rank, as they would under
+the reference's own (commented-out) Lightning DDP, test_unsupervised.py:123,134."""
+from __future__ import annotations
+
+import os
+from contextlib import nullcontext
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------ distributed
+@dataclass
+class DistEnv:
+    rank: int = 0
+    local_rank: int = 0
+    world_size: int = 1
+    device: torch.device = torch.device("cpu")
+    backend: Optional[str] = None
+
+    @property
+    def is_main(self):
+        return self.rank == 0
+
+
+def init_distributed(force_cpu: bool = False) -> DistEnv:
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract) and join the process group."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_gpu = torch.cuda.is_available() and not force_cpu
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    backend = None
+    if world > 1:
+        backend = "nccl" if use_gpu else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if not dist.is_initialized():
+            kw = {"device_id": device} if use_gpu else {}
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return DistEnv(rank, local_rank, world, device, backend)
+
+
+def shutdown_distributed():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def barrier(env: DistEnv):
+    if env.world_size > 1:
+        if env.device.type == "cuda":
+            dist.barrier(device_ids=[env.local_rank])
+        else:
+            dist.barrier()
+
+
+def all_reduce_max(env: DistEnv, value: float) -> float:
+    if env.world_size == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=env.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_range(global_batch: int, env: DistEnv) -> Tuple[int, int]:
+    """contiguous shard [lo, hi) of a global batch for this rank (DistributedSampler-style, no padding)"""
+    per, rem = divmod(global_batch, env.world_size)
+    lo = env.rank * per + min(env.rank, rem)
+    return lo, lo + per + (1 if env.rank < rem else 0)
+
+
+def wrap_ddp(module: torch.nn.Module, env: DistEnv, bucket_cap_mb: int = 32) -> torch.nn.Module:
+    """DistributedDataParallel with bucket views: gradients are all-reduced (averaged) in ~32 MB buckets while the
+    rest of backward is still running.  The whole FlowOccNet gradient is 27.6 MB fp32 => one or two RCCL all-reduces per
+    step; ring over xGMI moves 2(N-1)/N * S per GPU."""
+    if env.world_size == 1:
+        return module
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if env.device.type == "cuda":
+        return DDP(module, device_ids=[env.local_rank], output_device=env.local_rank, gradient_as_bucket_view=True,
+                   bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
+    return DDP(module, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
+
+
+# ------------------------------------------------------------------------------------------ synthetic data
+def _lowpass(x: torch.Tensor, passes: int = 3) -> torch.Tensor:
+    for _ in range(passes):
+        x = F.avg_pool2d(F.pad(x, (2, 2, 2, 2), mode="reflect"), 5, stride=1)
+    return x
+
+
+def synthetic_batch(batch: int, height: int, width: int, device, seed: int = 42, index_offset: int = 0):
+    """Sintel-shaped synthetic sample(s) generated on `device`: frame1 = low-pass filtered uniform noise in
+    [-1,1], frame2 = frame1 displaced by a smooth flow field (sigma ~ 4 px) built from the same generator, plus the
+    ground-truth flow [B,2,H,W] and a Bernoulli(0.3)-like blob occlusion mask [B,1,H,W].  Sample i of the GLOBAL batch
+    depends only on (seed, index_offset + i), so shards are reproducible for any world size."""
+    imgs, flows, occs = [], [], []
+    for i in range(batch):
+        g = torch.Generator(device="cpu").manual_seed(seed * 1000003 + index_offset + i)
+        base = torch.rand((1, 3, height // 4 + 8, width // 4 + 8), generator=g) * 2 - 1
+        coarse = torch.randn((1, 2, height // 32 + 2, width // 32 + 2), generator=g) * 4.0
+        blob = torch.rand((1, 1, height // 16 + 2, width // 16 + 2), generator=g)
+        base, coarse, blob = base.to(device), coarse.to(device), blob.to(device)
+        f1 = F.interpolate(_lowpass(base, 1), size=(height, width), mode="bicubic", align_corners=False).clamp(-1, 1)
+        flow = F.interpolate(coarse, size=(height, width), mode="bicubic", align_corners=False)
+        ys, xs = torch.meshgrid(torch.arange(height, device=device, dtype=torch.float32),
+                                torch.arange(width, device=device, dtype=torch.float32), indexing="ij")
+        gx = 2.0 * (xs + flow[:, 0]) / max(width - 1, 1) - 1.0
+        gy = 2.0 * (ys + flow[:, 1]) / max(height - 1, 1) - 1.0
+        f2 = F.grid_sample(f1, torch.stack((gx, gy), dim=-1), mode="bilinear", padding_mode="border", align_corners=True)
+        occ = (F.interpolate(blob, size=(height, width), mode="bilinear", align_corners=False) > 0.62).float()
+        imgs.append(torch.cat((f1, f2), dim=1))
+        flows.append(flow)
+        occs.append(occ)
+    return torch.cat(imgs), torch.cat(flows), torch.cat(occs)
+
+
+# ------------------------------------------------------------------------------------------ training stepper
+class TrainStepper:
+    """One optimisation step of a Lightning-style module: forward + loss (module.training_step) + backward + Adam,
+    under bf16 autocast when `amp_dtype` is given (convs on MFMA via MIOpen, HIP ops bf16-in / fp32-accumulate)."""
+
+    def __init__(self, module: torch.nn.Module, env: DistEnv, amp_dtype: Optional[torch.dtype] = torch.bfloat16,
+                 channels_last: bool = True):
+        self.env = env
+        self.amp_dtype = amp_dtype if env.device.type == "cuda" else None
+        self.channels_last = channels_last
+        module = module.to(env.device)
+        if channels_last:
+            module = module.to(memory_format=torch.channels_last)
+        self.raw = module
+        self.optimizer = module.configure_optimizers()
+        self.module = wrap_ddp(_StepAdapter(module), env)
+
+    def prepare(self, batch):
+        out = []
+        for t in batch:
+            t = t.to(self.env.device, non_blocking=True)
+            if self.channels_last and t.dim() == 4 and t.size(1) > 2:
+                t = t.contiguous(memory_format=torch.channels_last)
+            out.append(t)
+        return tuple(out)
+
+    def step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        self.optimizer.zero_grad(set_to_none=True)
+        ctx = torch.autocast(self.env.device.type, dtype=self.amp_dtype) if self.amp_dtype is not None else nullcontext()
+        with ctx:
+            loss = self.module(batch, batch_idx)
+        loss.backward()
+        self.optimizer.step()
+        self.raw.global_step = getattr(self.raw, "global_step", 0) + 1
+        return loss.detach()
+
+
+class _StepAdapter(torch.nn.Module):
+    """DDP hooks fire on `forward`; route it to the module's `training_step` so the reference's step code is what runs."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.inner = module
+
+    def forward(self, batch, batch_idx):
+        return self.inner.training_step(batch, batch_idx)
+
+
+# ------------------------------------------------------------------------------------------ kernel timer
+@dataclass
+class KernelTimer:
+    """HIP-event timing of individual kernel launches on the stream they are launched on (the ops launch on torch's
+    current stream, so torch.cuda.Event brackets exactly the kernel).  Installed with ops.set_kernel_timer()."""
+    enabled: bool = True
+    records: List[tuple] = field(default_factory=list)
+
+    def launch(self, name: str, meta: Dict, fn):
+        if not self.enabled:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.records.append((name, meta, e0, e1))
+        return r
+
+    def summary(self) -> Dict[str, Dict]:
+        """name -> {launches, ms_total, bytes_total, flops_total, by_shape}; call after torch.cuda.synchronize()"""
+        out: Dict[str, Dict] = {}
+        for name, meta, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            s = out.setdefault(name, {"launches": 0, "ms_total": 0.0, "bytes_total": 0, "flops_total": 0, "by_shape": {}})
+            s["launches"] += 1
+            s["ms_total"] += ms
+            s["bytes_total"] += meta.get("bytes", 0)
+            s["flops_total"] += meta.get("flops", 0)
+            key = meta.get("shape", "")
+            b = s["by_shape"].setdefault(key, {"launches": 0, "ms_total": 0.0, "bytes": meta.get("bytes", 0)})
+            b["launches"] += 1
+            b["ms_total"] += ms
+        return out

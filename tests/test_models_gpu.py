@@ -1,0 +1,115 @@
+"""GPU end-to-end parity: the model surfaces with the REAL HIP operators (through the C ABI) against golden outputs
+of the reference's PyTorch CPU path, fp32, deterministic RNG-free weights.  north_star bar: flow EPE and
+occlusion-mask L1 within 1e-4 (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import rngfree_fill
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+@pytest.fixture(autouse=True)
+def _deterministic():
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+
+
+def d(a):
+    return T(a).to(DEV)
+
+
+def epe(a, b):
+    return float(torch.sqrt(((a.float().cpu() - T(b)) ** 2).sum(1)).mean())
+
+
+def close(a, b, tol):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), b, rtol=tol, atol=tol)
+
+
+def test_flow_model_pwc_flownet(golden):
+    from ocflow_amd.models.flow_model import FlowModel
+    g = golden("nets")
+    m = rngfree_fill(FlowModel({"learning_rate": 1e-3, "model": "pwc", "displacement": 4})).to(DEV)
+    with torch.no_grad():
+        assert epe(m(d(g["x64"])), g["flowmodel_pwc_train"]) < 1e-4
+        full, quarter = m.flow_pred(d(g["x64"]))
+    close(quarter, g["flownetcv_quarter"], 1e-4)
+    m = rngfree_fill(FlowModel({"learning_rate": 1e-3, "model": "flownet"})).to(DEV).eval()
+    with torch.no_grad():
+        assert epe(m(d(g["x96"])), g["flowmodel_flownet_eval"]) < 1e-4
+    # same network in channels_last (the bf16 throughput layout) gives the same fp32 answer
+    m = m.to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert epe(m(d(g["x96"]).contiguous(memory_format=torch.channels_last)), g["flowmodel_flownet_eval"]) < 1e-4
+
+
+def test_flow_occ_models(golden):
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    g = golden("nets")
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"})).to(DEV).eval().to(memory_format=fmt)
+        with torch.no_grad():
+            fl, oc = m(d(g["x96"]).contiguous(memory_format=fmt))
+        assert epe(fl, g["flowoccmodel_flowoccnet_eval_flow"]) < 1e-4
+        assert float((oc.cpu() - T(g["flowoccmodel_flowoccnet_eval_occ"])).abs().mean()) < 1e-4
+    m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "pwoc"})).to(DEV)
+    with torch.no_grad():
+        fl, oc = m(d(g["x64"]))
+    assert epe(fl, g["flowoccmodel_pwoc_train_flow"]) < 1e-4
+    assert float((oc.cpu() - T(g["flowoccmodel_pwoc_train_occ"])).abs().mean()) < 1e-4
+
+
+def test_supervised_step_grads(golden):
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    g = golden("nets")
+    m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "pwoc"})).to(DEV)
+    fl_loss, oc_loss = m.general_step((d(g["x64"]), d(g["pwoc_step_gt_flow"]), d(g["pwoc_step_gt_occ"])), 0, "train")
+    close(fl_loss, g["pwoc_step_flow_loss"], 2e-5)
+    close(oc_loss, g["pwoc_step_occ_loss"], 2e-5)
+    (fl_loss + oc_loss).backward()
+    close(m.model.conv2_0[0].weight.grad[:4, :8], g["pwoc_step_grad_conv2_0"], 1e-4)
+    close(m.model.conv1a[0].weight.grad, g["pwoc_step_grad_conv1a"], 1e-3)
+
+
+@pytest.mark.parametrize("occ_aware,tag", [(True, "occaware"), (False, "plain")])
+def test_unsupervised_stage_step(golden, occ_aware, tag):
+    from ocflow_amd.models.model import FlowStageModel
+    g = golden("nets")
+    hp = dict(learning_rate=1e-5, model="pwc", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0,
+              with_occ=False, occ_aware=occ_aware)
+    m = rngfree_fill(FlowStageModel(hp)).to(DEV)
+    batch = (d(g["stage_x"]), d(g["stage_gt_flow"]), d(g["stage_gt_occ"]))
+    res = m.general_step_occ_aware(batch, 0, "train") if occ_aware else m.general_step(batch, 0, "train")
+    close(torch.stack([r.detach() for r in res]), g[f"stage_{tag}_scalars"], 1e-4)
+    loss = m.training_step(batch, 0)
+    close(loss, g[f"stage_{tag}_loss"], 1e-4)
+    loss.backward()
+    close(m.flow_pred.predict_flow2.weight.grad[:, :16], g[f"stage_{tag}_grad_predict_flow2"], 2e-4)
+
+
+def test_bf16_autocast_step_runs():
+    """throughput mode: bf16 autocast + channels_last; checks the step runs, is finite and stays near the fp32 flow"""
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    torch.manual_seed(0)
+    m = FlowOccModel({"learning_rate": 1e-4, "model": "flowoccnet"}).to(DEV).to(memory_format=torch.channels_last)
+    x = (torch.rand((2, 6, 128, 192), device=DEV) * 2 - 1).contiguous(memory_format=torch.channels_last)
+    gt_flow = torch.randn((2, 2, 128, 192), device=DEV)
+    gt_occ = (torch.rand((2, 1, 128, 192), device=DEV) < 0.3).float()
+    opt = m.configure_optimizers()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = m.training_step((x, gt_flow, gt_occ), 0)
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss)
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    m.eval()
+    with torch.no_grad():
+        f32, _ = m(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            fbf, _ = m(x)
+    assert float((f32 - fbf.float()).abs().mean()) < 0.25 * float(f32.abs().mean()) + 0.05
