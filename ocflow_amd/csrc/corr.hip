@@ -14,7 +14,9 @@
 //   store      = 1/C scaling fused; 4 pixels x (2d+1) dx per lane, vector stores when NCHW.
 //
 // reference semantics: models/networks/correlation_layer.py:7-40 (+ warp cost_volume_flow_net.py:121-151)
+#include <stdlib.h>
 #include "ocf_common.h"
+#include "corr_internal.h"
 
 namespace ocf {
 
@@ -22,21 +24,43 @@ constexpr int TW = 32, TH = 8, PX = 4, NU = 4, NQP = 10;
 
 template <int D> struct Geo {
   static constexpr int N = 2 * D + 1;
+  static constexpr int NK = N * N;
   static constexpr int HH = TH + 2 * D, HW = TW + 2 * D;
   static constexpr int F2_SLOTS = NU * HH * 4 * NQP;
   static constexpr int F1_SLOTS = NU * TH * 4 * NQP;
   static constexpr int NT = 64 * N;
+  static constexpr int F2_ITEMS = HH * HW * NU, F1_ITEMS = TH * TW * NU;
+  static constexpr int F2_PER = (F2_ITEMS + NT - 1) / NT, F1_PER = (F1_ITEMS + NT - 1) / NT;
 };
 
-template <typename T, bool VEC, bool WARP, int D>
+// output modes of the epilogue
+enum { OUT_DIRECT = 0, OUT_DIRECT_VEC = 1, OUT_LDS = 2, OUT_LDS_VEC = 3 };
+
+// Staging = "one wave per tile row": the row index is wave-uniform (scalar address math), the 64 lanes sweep the row's
+// (pixel, unit) items.  VEC != 0 (channels_last): item = 4*pixel + unit, i.e. consecutive lanes read consecutive 16-byte
+// units (a 32-channel bf16 pixel is 64 contiguous bytes, pixels are contiguous along x => 1 KiB per wave-instruction);
+// VEC == 0 (NCHW / arbitrary strides): item = unit*ROWLEN + pixel, lanes sweep x within a channel plane.
+template <int VEC, int ROWLEN>
+__device__ __forceinline__ void row_item(int it, int& u, int& xl) {
+  if (VEC != 0) { u = it & (NU - 1); xl = it >> 2; }
+  else          { u = it / ROWLEN; xl = it - u * ROWLEN; }
+}
+
+// MODE 0: plain copy staging; 1: f2 scaled by occ while staged; 2: f2 gathered through the warp (occ optional)
+template <typename T, int VEC, int MODE, int D>
 __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C,
                                                                   int H, int W, float fs, WarpGeom wg, int tiles_x,
-                                                                  int tiles_y, int out_vec) {
+                                                                  int tiles_y, int out_mode) {
   using G = Geo<D>;
   constexpr int U = Unit<T>::U;
-  __shared__ u32x4 s_f2[G::F2_SLOTS];
-  __shared__ u32x4 s_f1[G::F1_SLOTS];
+  constexpr int ES = (int)sizeof(T);
+  // ONE shared array (staging tiles, later reused as the output transposition buffer)
+  __shared__ u32x4 smem[G::F2_SLOTS + G::F1_SLOTS];
+  u32x4* s_f2 = smem;
+  u32x4* s_f1 = smem + G::F2_SLOTS;
 
+  const int ablate = out_mode >> 8;  // tuning aid: bit0 no compute, bit1 no global loads, bit2 no output
+  out_mode &= 0xff;
   const int tid = threadIdx.x;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tpi = tiles_x * tiles_y;
@@ -44,7 +68,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2,
   const int trem = tile - b * tpi;
   const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
 
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int sx = lane & 7, ry = lane >> 3;
 
   float acc[PX][G::N];
@@ -55,76 +79,87 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2,
 
   const int ncb = (C + NU * U - 1) / (NU * U);
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // per-image bases (64-bit once); everything inside an image is 32-bit element arithmetic (host checks the range)
+  const char* f1b = f1.p + (long)b * f1.sb * ES;
+  const char* f2b = f2.p + (long)b * f2.sb * ES;
+  const float* flb = MODE == 2 ? (const float*)flow.p + (long)b * flow.sb : nullptr;
+  const float* ocb = (MODE >= 1 && occ.p) ? (const float*)occ.p + (long)b * occ.sb : nullptr;
+  const int f1sh = (int)f1.sh, f1sw = (int)f1.sw, f1sc = (int)f1.sc;
+  const int f2sh = (int)f2.sh, f2sw = (int)f2.sw, f2sc = (int)f2.sc;
+  T4 f1i = f1, f2i = f2;  // image-local views for the unit loaders
+  f1i.p = (char*)f1b; f2i.p = (char*)f2b;
 
   for (int cb = 0; cb < ncb; cb++) {
     const int cbase = cb * NU * U;
-    // ---------------- stage f2 halo tile (plain copy, or bilinear gather when WARP) -------------
-    for (int it = tid; it < G::HH * G::HW * NU; it += G::NT) {
-      int u, xl, r;
-      if (VEC) { u = it % NU; int pos = it / NU; xl = pos % G::HW; r = pos / G::HW; }
-      else     { xl = it % G::HW; int q = it / G::HW; r = q % G::HH; u = q / G::HH; }
-      const int gy = ty0 - D + r, gx = tx0 - D + xl, c0 = cbase + u * U;
-      u32x4 val = zero4;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C) {
-        if (!WARP) {
-          const long po = (long)b * f2.sb + (long)gy * f2.sh + (long)gx * f2.sw;
-          if (occ.p == nullptr) {
-            val = load_unit<T, VEC>(f2, po, c0, C);
-          } else {
-            float f[U];
-            load_unit_f<T, VEC>(f2, po, c0, C, f);
-            const float o = ((const float*)occ.p)[(long)b * occ.sb + (long)gy * occ.sh + (long)gx * occ.sw];
+    // ---------------- stage the f2 halo tile: wave w takes rows w, w+N, ... -------------------------
+    for (int r = wave; r < G::HH; r += G::N) {
+      const int gy = ty0 - D + r;
+      const bool rowok = gy >= 0 && gy < H;
 #pragma unroll
-            for (int j = 0; j < U; j++) f[j] *= o;
-            val = f_to_unit<T>(f);
-          }
-        } else {
-          const float* fl = (const float*)flow.p;
-          const long fo = (long)b * flow.sb + (long)gy * flow.sh + (long)gx * flow.sw;
-          const float uu = fl[fo] * fs, vv = fl[fo + flow.sc] * fs;
-          const Bilin s = bilin_setup(((float)gx + uu) * wg.ax + wg.bx, ((float)gy + vv) * wg.ay + wg.by, H, W);
-          float a[U];
+      for (int k = 0; k < (G::HW * NU + 63) / 64; k++) {
+        const int it = lane + 64 * k;
+        if (it < G::HW * NU) {
+          int u, xl;
+          row_item<VEC, G::HW>(it, u, xl);
+          const int gx = tx0 - D + xl, c0 = cbase + u * U;
+          u32x4 val = zero4;
+          if (rowok && gx >= 0 && gx < W && c0 < C && !(ablate & 2)) {
+            if (MODE == 0) {
+              val = load_unit<T, VEC>(f2i, gy * f2sh + gx * f2sw, c0, C);
+            } else {
+              float a[U];
+              if (MODE == 1) {
+                load_unit_f<T, VEC>(f2i, gy * f2sh + gx * f2sw, c0, C, a);
+              } else {
+                const int fo = gy * (int)flow.sh + gx * (int)flow.sw;
+                const float uu = flb[fo] * fs, vv = flb[fo + flow.sc] * fs;
+                const Bilin sm = bilin_setup(((float)gx + uu) * wg.ax + wg.bx, ((float)gy + vv) * wg.ay + wg.by, H, W);
 #pragma unroll
-          for (int j = 0; j < U; j++) a[j] = 0.f;
-          const long pb = (long)b * f2.sb;
+                for (int j = 0; j < U; j++) a[j] = 0.f;
 #pragma unroll
-          for (int n = 0; n < 4; n++) {
-            const int ddx = n & 1, ddy = n >> 1;
-            const bool ok = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
-            if (ok) {
-              const float w = (ddx ? s.wx1 : 1.f - s.wx1) * (ddy ? s.wy1 : 1.f - s.wy1);
-              float f[U];
-              load_unit_f<T, VEC>(f2, pb + (long)(s.y0 + ddy) * f2.sh + (long)(s.x0 + ddx) * f2.sw, c0, C, f);
+                for (int n = 0; n < 4; n++) {
+                  const int ddx = n & 1, ddy = n >> 1;
+                  const bool ok = (ddx ? sm.vx1 : sm.vx0) & (ddy ? sm.vy1 : sm.vy0);
+                  if (ok) {
+                    const float w = (ddx ? sm.wx1 : 1.f - sm.wx1) * (ddy ? sm.wy1 : 1.f - sm.wy1);
+                    float f[U];
+                    load_unit_f<T, VEC>(f2i, (sm.y0 + ddy) * f2sh + (sm.x0 + ddx) * f2sw, c0, C, f);
 #pragma unroll
-              for (int j = 0; j < U; j++) a[j] = __builtin_fmaf(w, f[j], a[j]);
+                    for (int j = 0; j < U; j++) a[j] = __builtin_fmaf(w, f[j], a[j]);
+                  }
+                }
+              }
+              if (ocb) {
+                const float o = ocb[gy * (int)occ.sh + gx * (int)occ.sw];
+#pragma unroll
+                for (int j = 0; j < U; j++) a[j] *= o;
+              }
+              val = f_to_unit<T>(a);
             }
           }
-          if (occ.p != nullptr) {
-            const float o = ((const float*)occ.p)[(long)b * occ.sb + (long)gy * occ.sh + (long)gx * occ.sw];
-#pragma unroll
-            for (int j = 0; j < U; j++) a[j] *= o;
-          }
-          val = f_to_unit<T>(a);
+          s_f2[((u * G::HH + r) * 4 + (xl & 3)) * NQP + (xl >> 2)] = val;
         }
       }
-      s_f2[((u * G::HH + r) * 4 + (xl & 3)) * NQP + (xl >> 2)] = val;
     }
-    // ---------------- stage f1 tile -------------------------------------------------------------
-    for (int it = tid; it < TH * TW * NU; it += G::NT) {
-      int u, xl, r;
-      if (VEC) { u = it % NU; int pos = it / NU; xl = pos % TW; r = pos / TW; }
-      else     { xl = it % TW; int q = it / TW; r = q % TH; u = q / TH; }
-      const int gy = ty0 + r, gx = tx0 + xl, c0 = cbase + u * U;
-      u32x4 val = zero4;
-      if (gy < H && gx < W && c0 < C)
-        val = load_unit<T, VEC>(f1, (long)b * f1.sb + (long)gy * f1.sh + (long)gx * f1.sw, c0, C);
-      s_f1[((u * TH + r) * 4 + (xl & 3)) * NQP + (xl >> 2)] = val;
+    // ---------------- stage the f1 tile -----------------------------------------------------------
+    for (int r = wave; r < TH; r += G::N) {
+      const int gy = ty0 + r;
+#pragma unroll
+      for (int k = 0; k < (TW * NU) / 64; k++) {
+        const int it = lane + 64 * k;
+        int u, xl;
+        row_item<VEC, TW>(it, u, xl);
+        const int gx = tx0 + xl, c0 = cbase + u * U;
+        u32x4 val = zero4;
+        if (gy < H && gx < W && c0 < C && !(ablate & 2)) val = load_unit<T, VEC>(f1i, gy * f1sh + gx * f1sw, c0, C);
+        s_f1[((u * TH + r) * 4 + (xl & 3)) * NQP + (xl >> 2)] = val;
+      }
     }
     __syncthreads();
     // ---------------- compute: wave = dy row, lane = 4-pixel strip ----------------------------
 #pragma unroll
     for (int u = 0; u < NU; u++) {
-      if (cbase + u * U < C) {
+      if (cbase + u * U < C && !(ablate & 1)) {
         u32x4 a[PX];
 #pragma unroll
         for (int i = 0; i < PX; i++) a[i] = s_f1[((u * TH + ry) * 4 + i) * NQP + sx];
@@ -146,9 +181,53 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2,
   // ---------------- epilogue: scale by 1/C and store ---------------------------------------------
   const float invC = 1.f / (float)C;
   const int y = ty0 + ry, x0 = tx0 + PX * sx;
+  if ((ablate & 4) && acc[0][0] != 123.f) return;
+  if (out_mode == OUT_LDS || out_mode == OUT_LDS_VEC) {
+    // channels_last output: transpose through LDS so that global stores are whole contiguous pixel runs
+    // (NK contiguous outputs per pixel, TW*NK per tile row when the tensor is dense).
+    constexpr int ROWS = (sizeof(T) == 2) ? TH : TH / 2;  // rows per pass that fit the staging buffer
+    static_assert(ROWS * TW * G::NK * sizeof(T) <= (G::F2_SLOTS + G::F1_SLOTS) * 16, "output tile does not fit LDS");
+    T* s_out = (T*)smem;
+    const int vrows = min(TH, H - ty0), vcols = min(TW, W - tx0);
+#pragma unroll
+    for (int pass = 0; pass < TH / ROWS; pass++) {
+      const int r0 = pass * ROWS;
+      if (ry >= r0 && ry < r0 + ROWS) {
+        T* dst = s_out + ((ry - r0) * TW + PX * sx) * G::NK + wave * G::N;
+#pragma unroll
+        for (int i = 0; i < PX; i++)
+#pragma unroll
+          for (int dxi = 0; dxi < G::N; dxi++) dst[i * G::NK + dxi] = (T)(acc[i][dxi] * invC);
+      }
+      __syncthreads();
+      const int nrows = min(ROWS, vrows - r0);
+      if (out_mode == OUT_LDS_VEC) {
+        // dense channels_last: each tile row is ONE contiguous run of vcols*NK elements, 16-byte aligned at both ends
+        const int row_elems = vcols * G::NK;
+        const int nvec = (row_elems * (int)sizeof(T)) / 16;
+        const int tail0 = nvec * (16 / (int)sizeof(T));
+        for (int r = 0; r < nrows; r++) {
+          char* gp = out.p + ((long)b * out.sb + (long)(ty0 + r0 + r) * out.sh + (long)tx0 * out.sw) * (long)sizeof(T);
+          const u32x4* lp = (const u32x4*)(s_out + r * TW * G::NK);
+          for (int v = tid; v < nvec; v += G::NT) ((u32x4*)gp)[v] = lp[v];
+          for (int e = tail0 + tid; e < row_elems; e += G::NT) ((T*)gp)[e] = s_out[r * TW * G::NK + e];
+        }
+      } else {
+        const int per_row = vcols * G::NK;
+        for (int e = tid; e < nrows * per_row; e += G::NT) {
+          const int r = e / per_row, q = e - r * per_row;
+          const int xx = q / G::NK, k = q - xx * G::NK;
+          ((T*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r0 + r) * out.sh + (long)(tx0 + xx) * out.sw] =
+              s_out[(r * TW + xx) * G::NK + k];
+        }
+      }
+      if (pass + 1 < TH / ROWS) __syncthreads();
+    }
+    return;
+  }
   if (y >= H || x0 >= W) return;
   const long ob = (long)b * out.sb + (long)y * out.sh;
-  if (out_vec && x0 + PX <= W) {
+  if (out_mode == OUT_DIRECT_VEC && x0 + PX <= W) {
 #pragma unroll
     for (int dxi = 0; dxi < G::N; dxi++) {
       const long o = ob + (long)(wave * G::N + dxi) * out.sc + x0;
@@ -222,21 +301,18 @@ __global__ __launch_bounds__(256) void corr_bwd_gather(T4 f1, T4 w2, T4 g, T4 g1
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <typename T> static bool vec_ok(const ocf_tensor4* t) {
-  constexpr int U = Unit<T>::U;
-  return t->sc == 1 && ((uintptr_t)t->data % 16 == 0) && t->sw % U == 0 && t->sh % U == 0 && t->sb % U == 0;
-}
+template <typename T> static bool vec_ok(const ocf_tensor4* t) { return vec_width<T>(t) == 16; }
 
-template <typename T, bool VEC, bool WARP>
+template <typename T, int VEC, int MODE>
 static int launch_fwd_d(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
-                        int d, float fs, int ac, int out_vec, hipStream_t st) {
+                        int d, float fs, int ac, int out_mode, hipStream_t st) {
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
   const WarpGeom wg(H, W, ac);
   const dim3 grid((unsigned)(B * tx * ty));
 #define OCF_LAUNCH_D(DD)                                                                                   \
   case DD:                                                                                                 \
-    hipLaunchKernelGGL((corr_fwd_tiled<T, VEC, WARP, DD>), grid, dim3(64 * (2 * DD + 1)), 0, st, f1, f2, flow, occ, out, \
-                       B, C, H, W, fs, wg, tx, ty, out_vec);                                               \
+    hipLaunchKernelGGL((corr_fwd_tiled<T, VEC, MODE, DD>), grid, dim3(64 * (2 * DD + 1)), 0, st, f1, f2, flow, occ, out, \
+                       B, C, H, W, fs, wg, tx, ty, out_mode);                                              \
     break;
   switch (d) {
     OCF_LAUNCH_D(1) OCF_LAUNCH_D(2) OCF_LAUNCH_D(3) OCF_LAUNCH_D(4)
@@ -249,17 +325,33 @@ static int launch_fwd_d(const T4& f1, const T4& f2, const T4& flow, const T4& oc
 template <typename T>
 static int corr_fwd_t(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                       const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st) {
-  const bool vec = vec_ok<T>(f1) && vec_ok<T>(f2);
-  // 4-pixel vector store per (strip, dx): needs unit x-stride and 4-element aligned rows
-  const int out_vec = out->sw == 1 && ((uintptr_t)out->data % (PX * sizeof(T)) == 0) && out->sc % PX == 0 &&
-                      out->sh % PX == 0 && out->sb % PX == 0;
-  const T4 a = mk(f1), bq = mk(f2), fl = mk(flow), oc = mk(occ), o = mk(out);
-  if (flow) {
-    return vec ? launch_fwd_d<T, true, true>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_vec, st)
-               : launch_fwd_d<T, false, true>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_vec, st);
+  // in-image offsets are 32-bit in the kernels
+  auto span = [&](const ocf_tensor4* t, long c) { return (labs(t->sh) * H + labs(t->sw) * W + labs(t->sc) * c) * (long)sizeof(T); };
+  if (span(f1, C) >= (1L << 31) || span(f2, C) >= (1L << 31)) return OCF_EUNSUPPORTED;
+  const int vec = min_vec(vec_width<T>(f1), vec_width<T>(f2));
+  const int nk = (2 * d + 1) * (2 * d + 1);
+  const long es = sizeof(T);
+  int out_mode;
+  if (out->sc == 1 && out->sw != 1) {
+    // channels_last-like output: LDS-transposed epilogue; vector copy when the tensor is dense and rows are 16-B aligned
+    const bool dense = out->sw == nk && ((uintptr_t)out->data % 16 == 0) && (out->sh * es) % 16 == 0 && (out->sb * es) % 16 == 0 &&
+                       ((long)TW * nk * es) % 16 == 0;
+    out_mode = dense ? OUT_LDS_VEC : OUT_LDS;
+  } else {
+    const bool v = out->sw == 1 && ((uintptr_t)out->data % (PX * sizeof(T)) == 0) && out->sc % PX == 0 && out->sh % PX == 0 &&
+                   out->sb % PX == 0;
+    out_mode = v ? OUT_DIRECT_VEC : OUT_DIRECT;
   }
-  return vec ? launch_fwd_d<T, true, false>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_vec, st)
-             : launch_fwd_d<T, false, false>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_vec, st);
+  if (const char* ab = getenv("OCF_ABLATE")) out_mode |= atoi(ab) << 8;  // kernel-tuning aid (tools/kbench), 0 in production
+  const T4 a = mk(f1), bq = mk(f2), fl = mk(flow), oc = mk(occ), o = mk(out);
+#define OCF_DISPATCH(V)                                                                                              \
+  (flow ? launch_fwd_d<T, V, 2>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)                               \
+        : (occ ? launch_fwd_d<T, V, 1>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)                        \
+               : launch_fwd_d<T, V, 0>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)))
+  if (vec == 16) return OCF_DISPATCH(16);
+  if (vec == 8) return OCF_DISPATCH(8);
+  return OCF_DISPATCH(0);
+#undef OCF_DISPATCH
 }
 
 template <typename T>
@@ -293,7 +385,7 @@ extern "C" int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const 
   if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OCF_F32) return ocf::corr_fwd_t<float>(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, st);
-  if (dtype == OCF_BF16) return ocf::corr_fwd_t<ocf::bf16>(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, st);
+  if (dtype == OCF_BF16) return ocf::corr_fwd_bf16_mfma(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, st);
   return OCF_EINVAL;
 }
 

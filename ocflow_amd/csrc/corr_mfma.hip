@@ -1,0 +1,356 @@
+// K1+K2 forward for bf16 features on the CDNA4 matrix cores.
+//
+// Why MFMA: with v_dot2c_f32_bf16 the vector-ALU formulation of this kernel measured 14 us of pure dot-product issue at
+// the level-2 shape (B=8, C=32, 109x256: 1.16 GFLOP) -- the measured v_dot2c rate (~8 cycles per wave64 instruction) caps it
+// at ~1.6 TB/s of algorithmic traffic, BELOW the HBM roofline.  Arithmetic intensity is 17-34 FLOP/B, right at the fp32
+// vector ridge (hard parts), so the contraction is moved to the matrix pipe to make the kernel
+// memory-bound again.
+//
+// Band-GEMM formulation: for one image row y, one displacement row dy and a strip of 16 pixels x0..x0+15,
+//     P[m][n] = sum_c f1[y, x0+m, c] * f2[y+dy, xh+n, c]          (16 x 16, K = channels)
+// is one v_mfma_f32_16x16x32_bf16 per 32 channels; the 2d+1 needed outputs of pixel m are the band n-m in [0, 2d] of two
+// adjacent 16-column tiles (28 % of the MACs are useful at d=4 -- still ~9x the useful v_dot2c rate).
+//
+// Work decomposition (gfx950, wave64):
+//   workgroup  = 32 x 4 pixel tile, 2d+1 waves; wave w owns displacement row dy = w - d (4 rows x 4 MFMA per 32 channels).
+//   LDS image  = pixel-major [row][x][4 units of 16 B], unit order XOR-permuted by ((x>>2)&3) so that BOTH the staging
+//                ds_write_b128 (8-lane groups = 2 whole pixels = 128 contiguous bytes) and the MFMA fragment
+//                ds_read_b128 (lane = (pixel l&15, k-group l>>4)) are bank-conflict free.
+//   staging    = one wave per tile row (wave-uniform row math), lanes sweep 16-byte units; channels_last reads are whole
+//                64-byte pixels, 1 KiB per wave instruction; MODE 1 scales by occ, MODE 2 gathers through the warp.
+//   multi-block (C > 32): accumulate in registers across 32-channel blocks; the next block's global loads are issued
+//                before the MFMAs of the current one (register prefetch).
+//   epilogue   = band elements (x 1/C) -> LDS [row][x][85-element pitch] (pitch chosen so the 4 k-groups of a wave hit
+//                disjoint banks), then whole contiguous pixel runs -> HBM with 16-byte stores (channels_last, dense).
+// reference semantics: models/networks/correlation_layer.py:7-40 (+ warp cost_volume_flow_net.py:121-151)
+#include <stdlib.h>
+#include "ocf_common.h"
+#include "corr_internal.h"
+
+namespace ocf {
+
+namespace mf {
+constexpr int TW = 32, TH = 4, NUM = 4;     // tile, units (of 8 bf16) per 32-channel block
+constexpr int ROWPX = 40;                   // halo row pitch in pixels (32 + 2*4); fragment reads of the 3rd tile may run
+constexpr int SLACK_PX = 8;                 // 8 px past the last row: harmless, those MFMA columns are never used
+
+template <int D> struct G {
+  static constexpr int N = 2 * D + 1, NK = N * N;
+  static constexpr int HH = TH + 2 * D;
+  static constexpr int F2_SLOTS = (HH * ROWPX + SLACK_PX) * NUM;
+  static constexpr int F1_SLOTS = TH * TW * NUM;
+  static constexpr int S = ((NK + 2) / 8) * 8 + 5;  // out pitch: (2S-2) mod 32 in {8, 24} => k-groups on disjoint banks
+  static constexpr int OUT_ELEMS = TH * TW * S;
+  static constexpr int NT = 64 * N;
+  static constexpr int F2_ROWS_PER_WAVE = (HH + N - 1) / N;
+  static constexpr int F2_IT = (ROWPX * NUM + 63) / 64;  // 160 items per row -> 3 lane sweeps
+  static constexpr int F1_IT = (TW * NUM) / 64;           // 128 items per row -> 2 lane sweeps
+};
+
+__device__ __forceinline__ int slot(int rowpx, int row, int x, int u) { return (row * rowpx + x) * NUM + (((x >> 2) & 3) ^ ((3 * u) & 3)); }
+
+template <int VEC, int ROWLEN>
+__device__ __forceinline__ void row_item(int it, int& u, int& x) {
+  if (VEC != 0) { u = it & (NUM - 1); x = it >> 2; }
+  else          { u = it / ROWLEN; x = it - u * ROWLEN; }
+}
+}  // namespace mf
+
+enum { MOUT_GENERIC = 0, MOUT_CL_VEC = 1 };
+
+template <int VEC, int MODE, int D, bool MULTI>
+__global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_mfma(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H,
+                                                                 int W, float fs, WarpGeom wg, int tiles_x, int tiles_y,
+                                                                 int out_mode) {
+  using namespace mf;
+  using GG = G<D>;
+  typedef bf16 T;
+  constexpr int U = 8, ES = 2;
+  typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+  __shared__ u32x4 smem[GG::F2_SLOTS + GG::F1_SLOTS + (GG::OUT_ELEMS * ES + 15) / 16];
+  u32x4* s_f2 = smem;
+  u32x4* s_f1 = smem + GG::F2_SLOTS;
+  unsigned short* s_out = (unsigned short*)(smem + GG::F2_SLOTS + GG::F1_SLOTS);
+
+  const int ablate = out_mode >> 8;  // tuning aid (tools/kbench): bit0 no MFMA, bit1 no global loads, bit2 no output
+  out_mode &= 0xff;
+  const int tid = threadIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi;
+  const int trem = tile - b * tpi;
+  const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int ln = lane & 15, lg = lane >> 4;
+
+  const int ncb = (C + 31) / 32;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  T4 f1i = f1, f2i = f2;
+  f1i.p = f1.p + (long)b * f1.sb * ES;
+  f2i.p = f2.p + (long)b * f2.sb * ES;
+  const float* flb = MODE == 2 ? (const float*)flow.p + (long)b * flow.sb : nullptr;
+  const float* ocb = (MODE >= 1 && occ.p) ? (const float*)occ.p + (long)b * occ.sb : nullptr;
+  const int f1sh = (int)f1.sh, f1sw = (int)f1.sw, f2sh = (int)f2.sh, f2sw = (int)f2.sw;
+
+  // ---- staging pieces: fetch (global -> registers) and commit (registers -> LDS) ---------------------------------
+  u32x4 pf2[GG::F2_ROWS_PER_WAVE][GG::F2_IT], pf1[GG::F1_IT];
+
+  auto fetch = [&](int cbase) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rr = 0; rr < GG::F2_ROWS_PER_WAVE; rr++) {
+      const int r = wave + rr * GG::N;
+      const int gy = ty0 - D + r;
+      const bool rowok = r < GG::HH && gy >= 0 && gy < H;
+#pragma unroll
+      for (int k = 0; k < GG::F2_IT; k++) {
+        const int it = lane + 64 * k;
+        int u, x;
+        row_item<VEC, ROWPX>(it, u, x);
+        const int gx = tx0 - D + x, c0 = cbase + u * U;
+        u32x4 val = zero4;
+        if (rowok && it < ROWPX * NUM && x < TW + 2 * D && gx >= 0 && gx < W && c0 < C && !(ablate & 2)) {
+          if (MODE == 0) {
+            val = load_unit_full<T, VEC>(f2i, gy * f2sh + gx * f2sw, c0, C);
+          } else {
+            float a[U];
+            if (MODE == 1) {
+              load_unit_full_f<T, VEC>(f2i, gy * f2sh + gx * f2sw, c0, C, a);
+            } else {
+              const int fo = gy * (int)flow.sh + gx * (int)flow.sw;
+              const float uu = flb[fo] * fs, vv = flb[fo + flow.sc] * fs;
+              const Bilin sm = bilin_setup(((float)gx + uu) * wg.ax + wg.bx, ((float)gy + vv) * wg.ay + wg.by, H, W);
+#pragma unroll
+              for (int j = 0; j < U; j++) a[j] = 0.f;
+#pragma unroll
+              for (int n = 0; n < 4; n++) {
+                const int ddx = n & 1, ddy = n >> 1;
+                const bool ok = (ddx ? sm.vx1 : sm.vx0) & (ddy ? sm.vy1 : sm.vy0);
+                if (ok) {
+                  const float w = (ddx ? sm.wx1 : 1.f - sm.wx1) * (ddy ? sm.wy1 : 1.f - sm.wy1);
+                  float f[U];
+                  load_unit_full_f<T, VEC>(f2i, (sm.y0 + ddy) * f2sh + (sm.x0 + ddx) * f2sw, c0, C, f);
+#pragma unroll
+                  for (int j = 0; j < U; j++) a[j] = __builtin_fmaf(w, f[j], a[j]);
+                }
+              }
+            }
+            if (ocb) {
+              const float o = ocb[gy * (int)occ.sh + gx * (int)occ.sw];
+#pragma unroll
+              for (int j = 0; j < U; j++) a[j] *= o;
+            }
+            val = f_to_unit<T>(a);
+          }
+        }
+        pf2[rr][k] = val;
+      }
+    }
+    {
+      const int r = wave, gy = ty0 + r;
+#pragma unroll
+      for (int k = 0; k < GG::F1_IT; k++) {
+        const int it = lane + 64 * k;
+        int u, x;
+        row_item<VEC, TW>(it, u, x);
+        const int gx = tx0 + x, c0 = cbase + u * U;
+        u32x4 val = zero4;
+        if (r < TH && gy < H && gx < W && c0 < C && !(ablate & 2)) val = load_unit_full<T, VEC>(f1i, gy * f1sh + gx * f1sw, c0, C);
+        pf1[k] = val;
+      }
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rr = 0; rr < GG::F2_ROWS_PER_WAVE; rr++) {
+      const int r = wave + rr * GG::N;
+      if (r < GG::HH) {
+#pragma unroll
+        for (int k = 0; k < GG::F2_IT; k++) {
+          const int it = lane + 64 * k;
+          int u, x;
+          row_item<VEC, ROWPX>(it, u, x);
+          if (it < ROWPX * NUM) s_f2[slot(ROWPX, r, x, u)] = pf2[rr][k];
+        }
+      }
+    }
+    if (wave < TH) {
+#pragma unroll
+      for (int k = 0; k < GG::F1_IT; k++) {
+        const int it = lane + 64 * k;
+        int u, x;
+        row_item<VEC, TW>(it, u, x);
+        s_f1[slot(TW, wave, x, u)] = pf1[k];
+      }
+    }
+  };
+
+  // ---- band write of one 16x16 MFMA result (strip s, column tile t) of tile row ry --------------------------------
+  const float invC = 1.f / (float)C;
+  auto band_write = [&](const f32x4& d, int ry, int s, int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = 4 * lg + r;
+      const int dxi = 16 * (t - s) + ln - m;
+      if (dxi >= 0 && dxi < GG::N) {
+        const bf16 v = (bf16)(d[r] * invC);
+        s_out[(ry * TW + 16 * s + m) * GG::S + wave * GG::N + dxi] = __builtin_bit_cast(unsigned short, v);
+      }
+    }
+  };
+
+  f32x4 acc[MULTI ? TH : 1][4];
+  if (MULTI) {
+#pragma unroll
+    for (int i = 0; i < TH; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  fetch(0);
+  for (int cb = 0; cb < ncb; cb++) {
+    commit();
+    __syncthreads();
+    if (MULTI && cb + 1 < ncb) fetch((cb + 1) * 32);  // next block's loads fly under this block's MFMAs
+    if (!(ablate & 1)) {
+#pragma unroll
+      for (int ry = 0; ry < TH; ry++) {
+        const bf16x8v a0 = __builtin_bit_cast(bf16x8v, s_f1[slot(TW, ry, ln, lg)]);
+        const bf16x8v a1 = __builtin_bit_cast(bf16x8v, s_f1[slot(TW, ry, 16 + ln, lg)]);
+        const int hr = ry + wave;
+        const bf16x8v b0 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, ln, lg)]);
+        const bf16x8v b1 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, 16 + ln, lg)]);
+        const bf16x8v b2 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, 32 + ln, lg)]);
+        if (MULTI) {
+          acc[ry][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[ry][0], 0, 0, 0);
+          acc[ry][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[ry][1], 0, 0, 0);
+          acc[ry][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[ry][2], 0, 0, 0);
+          acc[ry][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[ry][3], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);  // keep one row's fragments live at a time (register pressure)
+        } else {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, z, 0, 0, 0);
+          const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, z, 0, 0, 0);
+          const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, z, 0, 0, 0);
+          const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, z, 0, 0, 0);
+          if (!(ablate & 4)) {
+            band_write(d0, ry, 0, 0);
+            band_write(d1, ry, 0, 1);
+            band_write(d2, ry, 1, 1);
+            band_write(d3, ry, 1, 2);
+          }
+        }
+      }
+    }
+    if (MULTI && cb + 1 < ncb) __syncthreads();  // staging tiles are rewritten by the next commit
+  }
+  if (MULTI && !(ablate & 4)) {
+#pragma unroll
+    for (int ry = 0; ry < TH; ry++) {
+      band_write(acc[ry][0], ry, 0, 0);
+      band_write(acc[ry][1], ry, 0, 1);
+      band_write(acc[ry][2], ry, 1, 1);
+      band_write(acc[ry][3], ry, 1, 2);
+    }
+  }
+  if (ablate & 4) return;
+  __syncthreads();
+
+  // ---- copy-out: LDS [row][x][S] -> out[b, k, y, x] ------------------------------------------------------------
+  const int vrows = min(TH, H - ty0), vcols = min(TW, W - tx0);
+  if (out_mode == MOUT_CL_VEC) {
+    // dense channels_last: a tile row is one contiguous run of vcols*NK bf16, 16-byte aligned at the start
+    const int row_elems = vcols * GG::NK;
+    const int nvec = row_elems >> 3;
+    for (int r = 0; r < vrows; r++) {
+      char* gp = out.p + ((long)b * out.sb + (long)(ty0 + r) * out.sh + (long)tx0 * out.sw) * ES;
+      const unsigned short* lp = s_out + r * TW * GG::S;
+      for (int v = tid; v < nvec; v += GG::NT) {
+        const int e0 = v * 8;
+        int px = e0 / GG::NK, k = e0 - px * GG::NK;
+        unsigned short h[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          h[j] = lp[px * GG::S + k];
+          if (++k == GG::NK) { k = 0; px++; }
+        }
+        u32x4 pk = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+                    (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+        ((u32x4*)gp)[v] = pk;
+      }
+      for (int e = nvec * 8 + tid; e < row_elems; e += GG::NT) {
+        const int px = e / GG::NK, k = e - px * GG::NK;
+        ((unsigned short*)gp)[e] = lp[px * GG::S + k];
+      }
+    }
+  } else if (out.sw == 1) {
+    // NCHW-like: lanes sweep x inside a (k, row) line
+    const int per_k = vrows * vcols;
+    for (int e = tid; e < GG::NK * per_k; e += GG::NT) {
+      const int k = e / per_k, q = e - k * per_k;
+      const int r = q / vcols, x = q - r * vcols;
+      ((unsigned short*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r) * out.sh + (long)(tx0 + x)] =
+          s_out[(r * TW + x) * GG::S + k];
+    }
+  } else {
+    const int per_row = vcols * GG::NK;
+    for (int e = tid; e < vrows * per_row; e += GG::NT) {
+      const int r = e / per_row, q = e - r * per_row;
+      const int x = q / GG::NK, k = q - x * GG::NK;
+      ((unsigned short*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r) * out.sh + (long)(tx0 + x) * out.sw] =
+          s_out[(r * TW + x) * GG::S + k];
+    }
+  }
+}
+
+template <int VEC, int MODE, int D>
+static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
+                       float fs, int ac, int out_mode, hipStream_t st) {
+  const int tx = (W + mf::TW - 1) / mf::TW, ty = (H + mf::TH - 1) / mf::TH;
+  const WarpGeom wg(H, W, ac);
+  const dim3 grid((unsigned)(B * tx * ty)), block(64 * (2 * D + 1));
+  if (C > 32)
+    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, true>), grid, block, 0, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
+                       out_mode);
+  else
+    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, false>), grid, block, 0, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
+                       out_mode);
+  return launch_status();
+}
+
+template <int VEC, int MODE>
+static int launch_mfma_d(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
+                         int d, float fs, int ac, int out_mode, hipStream_t st) {
+  switch (d) {
+    case 1: return launch_mfma<VEC, MODE, 1>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+    case 2: return launch_mfma<VEC, MODE, 2>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+    case 3: return launch_mfma<VEC, MODE, 3>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+    case 4: return launch_mfma<VEC, MODE, 4>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+    default: return OCF_EUNSUPPORTED;
+  }
+}
+
+int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
+                       const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st) {
+  auto span = [&](const ocf_tensor4* t, long c) { return (labs(t->sh) * H + labs(t->sw) * W + labs(t->sc) * c) * 2L; };
+  if (span(f1, C) >= (1L << 31) || span(f2, C) >= (1L << 31)) return OCF_EUNSUPPORTED;
+  int vec = min_vec(vec_width<bf16>(f1), vec_width<bf16>(f2));
+  // the vector staging paths have no per-channel tail: 16-byte units need C % 8 == 0, 8-byte halves C % 4 == 0
+  if (vec == 16 && C % 8 != 0) vec = 8;
+  if (vec == 8 && C % 4 != 0) vec = 0;
+  const int nk = (2 * d + 1) * (2 * d + 1);
+  const bool dense = out->sc == 1 && out->sw == nk && ((uintptr_t)out->data % 16 == 0) && (out->sh * 2) % 16 == 0 &&
+                     (out->sb * 2) % 16 == 0 && ((long)mf::TW * nk * 2) % 16 == 0;
+  int out_mode = dense ? MOUT_CL_VEC : MOUT_GENERIC;
+  if (const char* ab = getenv("OCF_ABLATE")) out_mode |= atoi(ab) << 8;  // kernel-tuning aid (tools/kbench), 0 in production
+  const T4 a = mk(f1), bq = mk(f2), fl = mk(flow), oc = mk(occ), o = mk(out);
+#define OCF_DISPATCH(V)                                                                            \
+  (flow ? launch_mfma_d<V, 2>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)               \
+        : (occ ? launch_mfma_d<V, 1>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)        \
+               : launch_mfma_d<V, 0>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)))
+  if (vec == 16) return OCF_DISPATCH(16);
+  if (vec == 8) return OCF_DISPATCH(8);
+  return OCF_DISPATCH(0);
+#undef OCF_DISPATCH
+}
+
+}  // namespace ocf

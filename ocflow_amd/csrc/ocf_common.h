@@ -77,36 +77,83 @@ template <> __device__ __forceinline__ float unit_dot<bf16>(u32x4 a, u32x4 b, fl
 }
 
 // Load the unit holding channels [c0, c0+U) of pixel (b,y,x); channels >= C read as 0.
-// VEC: stride_c == 1 and the address is 16-byte aligned (checked on the host).
-template <typename T, bool VEC>
+// VEC = 16: stride_c == 1 and pixels are 16-byte aligned; VEC = 8: 8-byte aligned (e.g. C = 196 bf16 = 392-byte pixels);
+// VEC = 0: arbitrary strides, one scalar load per channel.  (bool true/false still mean 16/0.)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <typename T, int VEC>
 __device__ __forceinline__ u32x4 load_unit(const T4& t, long pix_off, int c0, int C) {
   constexpr int U = Unit<T>::U;
-  if (VEC) {
+  if (VEC == 16 || VEC == 1) {
     if (c0 + U <= C) return *(const u32x4*)(t.p + (pix_off + c0) * (long)sizeof(T));
+  } else if (VEC == 8) {
+    if (c0 + U <= C) {
+      const u32x2* q = (const u32x2*)(t.p + (pix_off + c0) * (long)sizeof(T));
+      const u32x2 lo = q[0], hi = q[1];
+      u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+      return r;
+    }
   }
   float f[U];
 #pragma unroll
   for (int j = 0; j < U; j++) f[j] = (c0 + j < C) ? ldf<T>(t.p, pix_off + (long)(c0 + j) * t.sc) : 0.f;
   return f_to_unit<T>(f);
 }
-template <typename T, bool VEC>
+template <typename T, int VEC>
 __device__ __forceinline__ void load_unit_f(const T4& t, long pix_off, int c0, int C, float* f) {
   constexpr int U = Unit<T>::U;
-  if (VEC) {
-    if (c0 + U <= C) { unit_to_f<T>(*(const u32x4*)(t.p + (pix_off + c0) * (long)sizeof(T)), f); return; }
+  if (VEC != 0) {
+    if (c0 + U <= C) { unit_to_f<T>(load_unit<T, VEC>(t, pix_off, c0, C), f); return; }
   }
 #pragma unroll
   for (int j = 0; j < U; j++) f[j] = (c0 + j < C) ? ldf<T>(t.p, pix_off + (long)(c0 + j) * t.sc) : 0.f;
 }
-template <typename T, bool VEC>
+template <typename T, int VEC>
 __device__ __forceinline__ void store_unit_f(const T4& t, long pix_off, int c0, int C, const float* f) {
   constexpr int U = Unit<T>::U;
-  if (VEC) {
+  if (VEC == 16 || VEC == 1) {
     if (c0 + U <= C) { *(u32x4*)(t.p + (pix_off + c0) * (long)sizeof(T)) = f_to_unit<T>(f); return; }
+  } else if (VEC == 8) {
+    if (c0 + U <= C) {
+      const u32x4 v = f_to_unit<T>(f);
+      u32x2* q = (u32x2*)(t.p + (pix_off + c0) * (long)sizeof(T));
+      u32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+      q[0] = lo; q[1] = hi;
+      return;
+    }
   }
 #pragma unroll
   for (int j = 0; j < U; j++) if (c0 + j < C) stf<T>(t.p, pix_off + (long)(c0 + j) * t.sc, f[j]);
 }
+
+// vector-only unit load for kernels whose host side guarantees C % U == 0 whenever VEC != 0 (no per-channel tail path:
+// the tail code costs ~100 VGPRs of live scalar loads in the staging loops)
+template <typename T, int VEC>
+__device__ __forceinline__ u32x4 load_unit_full(const T4& t, int pix_off, int c0, int C) {
+  if (VEC == 16) return *(const u32x4*)(t.p + (long)(pix_off + c0) * (long)sizeof(T));
+  if (VEC == 8) {
+    // 8-byte granularity: the host guarantees (C * sizeof(T)) % 8 == 0, so a partial last unit is exactly its first half
+    const u32x2* q = (const u32x2*)(t.p + (long)(pix_off + c0) * (long)sizeof(T));
+    const u32x2 lo = q[0];
+    u32x2 hi = {0u, 0u};
+    if ((c0 + Unit<T>::U / 2) < C) hi = q[1];
+    u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+    return r;
+  }
+  return load_unit<T, 0>(t, pix_off, c0, C);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void load_unit_full_f(const T4& t, int pix_off, int c0, int C, float* f) {
+  unit_to_f<T>(load_unit_full<T, VEC>(t, pix_off, c0, C), f);
+}
+
+// widest vector width (bytes) usable for the channel units of tensor t: 16, 8 or 0
+template <typename T> static inline int vec_width(const ocf_tensor4* t) {
+  if (!t || t->sc != 1) return 0;
+  const long es = sizeof(T);
+  auto ok = [&](long a) { return ((uintptr_t)t->data % a == 0) && (t->sw * es) % a == 0 && (t->sh * es) % a == 0 && (t->sb * es) % a == 0; };
+  return ok(16) ? 16 : (ok(8) ? 8 : 0);
+}
+static inline int min_vec(int a, int b) { return a < b ? a : b; }
 
 // Sampling geometry of the backward warp: source coordinate of output pixel (x,y).
 struct WarpGeom {
