@@ -58,8 +58,14 @@ __device__ __forceinline__ void row_item(int it, int& u, int& x) {
 
 enum { MOUT_GENERIC = 0, MOUT_CL_VEC = 1 };
 
+// MODE 0: plain; 1: occ given (applied to the band outputs: corr(f1, f2*occ)[dy,dx](x) = occ(x+d) * corr(f1,f2)[dy,dx](x));
+// MODE 2: f2 gathered through the warp while staged (occ optional, applied the same way).
+// MULTI: C > 32, accumulate over 32-channel blocks in registers.
+// The kernel is PERSISTENT: gridDim.x <= 2 workgroups per CU, each walks tiles of one XCD's contiguous tile range; the
+// global loads of the next tile (or channel block) are issued before the MFMAs of the current one, and the 16-byte output
+// stores of a tile drain while the next one is staged.
 template <int VEC, int MODE, int D, bool MULTI>
-__global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_mfma(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H,
+__global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H,
                                                                  int W, float fs, WarpGeom wg, int tiles_x, int tiles_y,
                                                                  int out_mode) {
   using namespace mf;
@@ -67,35 +73,38 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_mfma(T4 f1, T4 f2, 
   typedef bf16 T;
   constexpr int U = 8, ES = 2;
   typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
-  __shared__ u32x4 smem[GG::F2_SLOTS + GG::F1_SLOTS + (GG::OUT_ELEMS * ES + 15) / 16];
+  constexpr int OCC_W = 48;  // halo occlusion tile pitch (floats)
+  __shared__ u32x4 smem[GG::F2_SLOTS + GG::F1_SLOTS + (GG::OUT_ELEMS * ES + 15) / 16 + (MODE >= 1 ? (GG::HH * OCC_W * 4) / 16 : 0)];
   u32x4* s_f2 = smem;
   u32x4* s_f1 = smem + GG::F2_SLOTS;
   unsigned short* s_out = (unsigned short*)(smem + GG::F2_SLOTS + GG::F1_SLOTS);
+  float* s_occ = (float*)(smem + GG::F2_SLOTS + GG::F1_SLOTS + (GG::OUT_ELEMS * ES + 15) / 16);
 
   const int ablate = out_mode >> 8;  // tuning aid (tools/kbench): bit0 no MFMA, bit1 no global loads, bit2 no output
   out_mode &= 0xff;
   const int tid = threadIdx.x;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tpi = tiles_x * tiles_y;
-  const int b = tile / tpi;
-  const int trem = tile - b * tpi;
-  const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int ln = lane & 15, lg = lane >> 4;
+  const int tpi = tiles_x * tiles_y;
+  const int ntiles = B * tpi;
+  // XCD-affine persistent schedule: blocks b and b+8 share an XCD; XCD x owns tiles [x*per_xcd, (x+1)*per_xcd)
+  const int per_xcd = (ntiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, slots = gridDim.x >> 3;
 
-  const int ncb = (C + 31) / 32;
+  constexpr bool PF = MULTI;  // register prefetch of the next block/tile; SINGLE relies on 2 co-resident workgroups instead
+  const int ncb = MULTI ? (C + 31) / 32 : 1;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  T4 f1i = f1, f2i = f2;
-  f1i.p = f1.p + (long)b * f1.sb * ES;
-  f2i.p = f2.p + (long)b * f2.sb * ES;
-  const float* flb = MODE == 2 ? (const float*)flow.p + (long)b * flow.sb : nullptr;
-  const float* ocb = (MODE >= 1 && occ.p) ? (const float*)occ.p + (long)b * occ.sb : nullptr;
   const int f1sh = (int)f1.sh, f1sw = (int)f1.sw, f2sh = (int)f2.sh, f2sw = (int)f2.sw;
+  const float invC = 1.f / (float)C;
+  const bool has_occ = MODE >= 1 && occ.p != nullptr;
 
-  // ---- staging pieces: fetch (global -> registers) and commit (registers -> LDS) ---------------------------------
   u32x4 pf2[GG::F2_ROWS_PER_WAVE][GG::F2_IT], pf1[GG::F1_IT];
 
-  auto fetch = [&](int cbase) __attribute__((always_inline)) {
+  // ---- fetch: global -> registers for (tile at b, ty0, tx0; channel block cbase) -----------------------------------
+  auto fetch = [&](int b, int ty0, int tx0, int cbase) __attribute__((always_inline)) {
+    T4 f1i = f1, f2i = f2;
+    f1i.p = f1.p + (long)b * f1.sb * ES;
+    f2i.p = f2.p + (long)b * f2.sb * ES;
 #pragma unroll
     for (int rr = 0; rr < GG::F2_ROWS_PER_WAVE; rr++) {
       const int r = wave + rr * GG::N;
@@ -109,35 +118,27 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_mfma(T4 f1, T4 f2, 
         const int gx = tx0 - D + x, c0 = cbase + u * U;
         u32x4 val = zero4;
         if (rowok && it < ROWPX * NUM && x < TW + 2 * D && gx >= 0 && gx < W && c0 < C && !(ablate & 2)) {
-          if (MODE == 0) {
+          if (MODE != 2) {
             val = load_unit_full<T, VEC>(f2i, gy * f2sh + gx * f2sw, c0, C);
           } else {
+            const float* flb = (const float*)flow.p + (long)b * flow.sb;
+            const int fo = gy * (int)flow.sh + gx * (int)flow.sw;
+            const float uu = flb[fo] * fs, vv = flb[fo + flow.sc] * fs;
+            const Bilin sm = bilin_setup(((float)gx + uu) * wg.ax + wg.bx, ((float)gy + vv) * wg.ay + wg.by, H, W);
             float a[U];
-            if (MODE == 1) {
-              load_unit_full_f<T, VEC>(f2i, gy * f2sh + gx * f2sw, c0, C, a);
-            } else {
-              const int fo = gy * (int)flow.sh + gx * (int)flow.sw;
-              const float uu = flb[fo] * fs, vv = flb[fo + flow.sc] * fs;
-              const Bilin sm = bilin_setup(((float)gx + uu) * wg.ax + wg.bx, ((float)gy + vv) * wg.ay + wg.by, H, W);
 #pragma unroll
-              for (int j = 0; j < U; j++) a[j] = 0.f;
+            for (int j = 0; j < U; j++) a[j] = 0.f;
 #pragma unroll
-              for (int n = 0; n < 4; n++) {
-                const int ddx = n & 1, ddy = n >> 1;
-                const bool ok = (ddx ? sm.vx1 : sm.vx0) & (ddy ? sm.vy1 : sm.vy0);
-                if (ok) {
-                  const float w = (ddx ? sm.wx1 : 1.f - sm.wx1) * (ddy ? sm.wy1 : 1.f - sm.wy1);
-                  float f[U];
-                  load_unit_full_f<T, VEC>(f2i, (sm.y0 + ddy) * f2sh + (sm.x0 + ddx) * f2sw, c0, C, f);
+            for (int n = 0; n < 4; n++) {
+              const int ddx = n & 1, ddy = n >> 1;
+              const bool ok = (ddx ? sm.vx1 : sm.vx0) & (ddy ? sm.vy1 : sm.vy0);
+              if (ok) {
+                const float w = (ddx ? sm.wx1 : 1.f - sm.wx1) * (ddy ? sm.wy1 : 1.f - sm.wy1);
+                float f[U];
+                load_unit_full_f<T, VEC>(f2i, (sm.y0 + ddy) * f2sh + (sm.x0 + ddx) * f2sw, c0, C, f);
 #pragma unroll
-                  for (int j = 0; j < U; j++) a[j] = __builtin_fmaf(w, f[j], a[j]);
-                }
+                for (int j = 0; j < U; j++) a[j] = __builtin_fmaf(w, f[j], a[j]);
               }
-            }
-            if (ocb) {
-              const float o = ocb[gy * (int)occ.sh + gx * (int)occ.sw];
-#pragma unroll
-              for (int j = 0; j < U; j++) a[j] *= o;
             }
             val = f_to_unit<T>(a);
           }
@@ -183,123 +184,184 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_mfma(T4 f1, T4 f2, 
       }
     }
   };
+  // occlusion halo tile straight to LDS (tiny: HH x 48 floats), 0 outside the image
+  auto stage_occ = [&](int b, int ty0, int tx0) __attribute__((always_inline)) {
+    if (MODE >= 1) {
+      const float* ocb = has_occ ? (const float*)occ.p + (long)b * occ.sb : nullptr;
+      for (int e = tid; e < GG::HH * OCC_W; e += GG::NT) {
+        const int r = e / OCC_W, x = e - r * OCC_W;
+        const int gy = ty0 - D + r, gx = tx0 - D + x;
+        float o = has_occ ? 0.f : 1.f;
+        if (has_occ && gy >= 0 && gy < H && gx >= 0 && gx < W) o = ocb[gy * (int)occ.sh + gx * (int)occ.sw];
+        s_occ[e] = o;
+      }
+    }
+  };
 
-  // ---- band write of one 16x16 MFMA result (strip s, column tile t) of tile row ry --------------------------------
-  const float invC = 1.f / (float)C;
-  auto band_write = [&](const f32x4& d, int ry, int s, int t) __attribute__((always_inline)) {
+  // ---- merged band write of the two 16x16 results (column tiles s and s+1) of strip s, tile row ry ----------------
+  // lane (n = l&15, g = l>>4), reg r holds row m = 4g+r; column n of tile s is dx index n-m (if >= 0), column n of tile
+  // s+1 is dx index 16+n-m: the two cases are disjoint, so ONE masked 2-byte LDS store per register covers both tiles.
+  auto band_write = [&](const f32x4& dA, const f32x4& dB, int ry, int s) __attribute__((always_inline)) {
+    float oA = invC, oB = invC;
+    if (MODE >= 1) {
+      oA *= s_occ[(ry + wave) * OCC_W + 16 * s + ln];
+      oB *= s_occ[(ry + wave) * OCC_W + 16 * (s + 1) + ln];
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int m = 4 * lg + r;
-      const int dxi = 16 * (t - s) + ln - m;
-      if (dxi >= 0 && dxi < GG::N) {
-        const bf16 v = (bf16)(d[r] * invC);
-        s_out[(ry * TW + 16 * s + m) * GG::S + wave * GG::N + dxi] = __builtin_bit_cast(unsigned short, v);
+      const int dxi = (ln - m) & 15;
+      if (dxi < GG::N) {
+        const float v = (ln >= m) ? dA[r] * oA : dB[r] * oB;
+        const bf16 h = (bf16)v;
+        s_out[(ry * TW + 16 * s + m) * GG::S + wave * GG::N + dxi] = __builtin_bit_cast(unsigned short, h);
       }
     }
   };
 
   f32x4 acc[MULTI ? TH : 1][4];
-  if (MULTI) {
-#pragma unroll
-    for (int i = 0; i < TH; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
 
-  fetch(0);
-  for (int cb = 0; cb < ncb; cb++) {
-    commit();
-    __syncthreads();
-    if (MULTI && cb + 1 < ncb) fetch((cb + 1) * 32);  // next block's loads fly under this block's MFMAs
-    if (!(ablate & 1)) {
+  // first tile of this workgroup
+  int ti = slot_in_xcd;
+  int tile = xcd * per_xcd + ti;
+  bool have = ti < per_xcd && tile < ntiles;
+  int b = 0, ty0 = 0, tx0 = 0;
+  if (have) {
+    b = tile / tpi;
+    const int trem = tile - b * tpi;
+    ty0 = (trem / tiles_x) * TH; tx0 = (trem % tiles_x) * TW;
+    if (PF) fetch(b, ty0, tx0, 0);
+  }
+  while (have) {
+    // next tile of this workgroup (for the prefetch at the end of the channel loop)
+    const int nti = ti + slots;
+    const int ntile = xcd * per_xcd + nti;
+    const bool nhave = nti < per_xcd && ntile < ntiles;
+    int nb = 0, nty0 = 0, ntx0 = 0;
+    if (nhave) {
+      nb = ntile / tpi;
+      const int trem = ntile - nb * tpi;
+      nty0 = (trem / tiles_x) * TH; ntx0 = (trem % tiles_x) * TW;
+    }
+    if (MULTI) {
 #pragma unroll
-      for (int ry = 0; ry < TH; ry++) {
-        const bf16x8v a0 = __builtin_bit_cast(bf16x8v, s_f1[slot(TW, ry, ln, lg)]);
-        const bf16x8v a1 = __builtin_bit_cast(bf16x8v, s_f1[slot(TW, ry, 16 + ln, lg)]);
-        const int hr = ry + wave;
-        const bf16x8v b0 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, ln, lg)]);
-        const bf16x8v b1 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, 16 + ln, lg)]);
-        const bf16x8v b2 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, 32 + ln, lg)]);
-        if (MULTI) {
-          acc[ry][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[ry][0], 0, 0, 0);
-          acc[ry][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[ry][1], 0, 0, 0);
-          acc[ry][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[ry][2], 0, 0, 0);
-          acc[ry][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[ry][3], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);  // keep one row's fragments live at a time (register pressure)
-        } else {
-          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, z, 0, 0, 0);
-          const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, z, 0, 0, 0);
-          const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, z, 0, 0, 0);
-          const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, z, 0, 0, 0);
-          if (!(ablate & 4)) {
-            band_write(d0, ry, 0, 0);
-            band_write(d1, ry, 0, 1);
-            band_write(d2, ry, 1, 1);
-            band_write(d3, ry, 1, 2);
+      for (int i = 0; i < TH; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int cb = 0; cb < ncb; cb++) {
+      if (!PF) fetch(b, ty0, tx0, 0);
+      commit();
+      if (cb == 0) stage_occ(b, ty0, tx0);
+      __syncthreads();
+      // loads of the next channel block / next tile fly under the MFMAs, band writes and output stores
+      if (PF) {
+        if (cb + 1 < ncb) fetch(b, ty0, tx0, (cb + 1) * 32);
+        else if (nhave) fetch(nb, nty0, ntx0, 0);
+      }
+      if (!(ablate & 1)) {
+#pragma unroll(MULTI ? TH : 1)
+        for (int ry = 0; ry < TH; ry++) {
+          const bf16x8v a0 = __builtin_bit_cast(bf16x8v, s_f1[slot(TW, ry, ln, lg)]);
+          const bf16x8v a1 = __builtin_bit_cast(bf16x8v, s_f1[slot(TW, ry, 16 + ln, lg)]);
+          const int hr = ry + wave;
+          const bf16x8v b0 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, ln, lg)]);
+          const bf16x8v b1 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, 16 + ln, lg)]);
+          const bf16x8v b2 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, 32 + ln, lg)]);
+          if (MULTI) {
+            acc[ry][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[ry][0], 0, 0, 0);
+            acc[ry][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[ry][1], 0, 0, 0);
+            acc[ry][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[ry][2], 0, 0, 0);
+            acc[ry][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[ry][3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // keep one row's fragments live at a time (register pressure)
+          } else {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, z, 0, 0, 0);
+            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, z, 0, 0, 0);
+            const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, z, 0, 0, 0);
+            const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, z, 0, 0, 0);
+            if (!(ablate & 4)) {
+              band_write(d0, d1, ry, 0);
+              band_write(d2, d3, ry, 1);
+            }
           }
         }
       }
+      if (MULTI && cb + 1 < ncb) __syncthreads();  // staging tiles are rewritten by the next commit
     }
-    if (MULTI && cb + 1 < ncb) __syncthreads();  // staging tiles are rewritten by the next commit
-  }
-  if (MULTI && !(ablate & 4)) {
+    if (MULTI && !(ablate & 4)) {
 #pragma unroll
-    for (int ry = 0; ry < TH; ry++) {
-      band_write(acc[ry][0], ry, 0, 0);
-      band_write(acc[ry][1], ry, 0, 1);
-      band_write(acc[ry][2], ry, 1, 1);
-      band_write(acc[ry][3], ry, 1, 2);
+      for (int ry = 0; ry < TH; ry++) {
+        band_write(acc[ry][0], acc[ry][1], ry, 0);
+        band_write(acc[ry][2], acc[ry][3], ry, 1);
+      }
     }
-  }
-  if (ablate & 4) return;
-  __syncthreads();
+    __syncthreads();
 
-  // ---- copy-out: LDS [row][x][S] -> out[b, k, y, x] ------------------------------------------------------------
-  const int vrows = min(TH, H - ty0), vcols = min(TW, W - tx0);
-  if (out_mode == MOUT_CL_VEC) {
-    // dense channels_last: a tile row is one contiguous run of vcols*NK bf16, 16-byte aligned at the start
-    const int row_elems = vcols * GG::NK;
-    const int nvec = row_elems >> 3;
-    for (int r = 0; r < vrows; r++) {
-      char* gp = out.p + ((long)b * out.sb + (long)(ty0 + r) * out.sh + (long)tx0 * out.sw) * ES;
-      const unsigned short* lp = s_out + r * TW * GG::S;
-      for (int v = tid; v < nvec; v += GG::NT) {
-        const int e0 = v * 8;
-        int px = e0 / GG::NK, k = e0 - px * GG::NK;
-        unsigned short h[8];
+    // ---- copy-out: LDS [row][x][S] -> out[b, k, y, x]; the stores drain while the next tile is staged -------------
+    if (!(ablate & 4) && !(ablate & 8)) {
+      const int vrows = min(TH, H - ty0), vcols = min(TW, W - tx0);
+      if (out_mode == MOUT_CL_VEC) {
+        // dense channels_last: a tile row is one contiguous run of vcols*NK bf16, 16-byte aligned at the start
+        const int row_elems = vcols * GG::NK;
+        const int nvec = row_elems >> 3;
+        for (int r = 0; r < vrows; r++) {
+          char* gp = out.p + ((long)b * out.sb + (long)(ty0 + r) * out.sh + (long)tx0 * out.sw) * ES;
+          const unsigned short* lp = s_out + r * TW * GG::S;
+          for (int v = tid; v < nvec; v += GG::NT) {
+            const int e0 = v * 8;
+            int px = e0 / GG::NK, k = e0 - px * GG::NK;
+            unsigned short h[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          h[j] = lp[px * GG::S + k];
-          if (++k == GG::NK) { k = 0; px++; }
+            for (int j = 0; j < 8; j++) {
+              h[j] = lp[px * GG::S + k];
+              if (++k == GG::NK) { k = 0; px++; }
+            }
+            u32x4 pk = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+                        (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+            ((u32x4*)gp)[v] = pk;
+          }
+          for (int e = nvec * 8 + tid; e < row_elems; e += GG::NT) {
+            const int px = e / GG::NK, k = e - px * GG::NK;
+            ((unsigned short*)gp)[e] = lp[px * GG::S + k];
+          }
         }
-        u32x4 pk = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
-                    (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
-        ((u32x4*)gp)[v] = pk;
+      } else if (out.sw == 1) {
+        // NCHW-like: lanes sweep x inside a (k, row) line
+        const int per_k = vrows * vcols;
+        for (int e = tid; e < GG::NK * per_k; e += GG::NT) {
+          const int k = e / per_k, q = e - k * per_k;
+          const int r = q / vcols, x = q - r * vcols;
+          ((unsigned short*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r) * out.sh + (long)(tx0 + x)] =
+              s_out[(r * TW + x) * GG::S + k];
+        }
+      } else {
+        const int per_row = vcols * GG::NK;
+        for (int e = tid; e < vrows * per_row; e += GG::NT) {
+          const int r = e / per_row, q = e - r * per_row;
+          const int x = q / GG::NK, k = q - x * GG::NK;
+          ((unsigned short*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r) * out.sh + (long)(tx0 + x) * out.sw] =
+              s_out[(r * TW + x) * GG::S + k];
+        }
       }
-      for (int e = nvec * 8 + tid; e < row_elems; e += GG::NT) {
-        const int px = e / GG::NK, k = e - px * GG::NK;
-        ((unsigned short*)gp)[e] = lp[px * GG::S + k];
-      }
     }
-  } else if (out.sw == 1) {
-    // NCHW-like: lanes sweep x inside a (k, row) line
-    const int per_k = vrows * vcols;
-    for (int e = tid; e < GG::NK * per_k; e += GG::NT) {
-      const int k = e / per_k, q = e - k * per_k;
-      const int r = q / vcols, x = q - r * vcols;
-      ((unsigned short*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r) * out.sh + (long)(tx0 + x)] =
-          s_out[(r * TW + x) * GG::S + k];
-    }
-  } else {
-    const int per_row = vcols * GG::NK;
-    for (int e = tid; e < vrows * per_row; e += GG::NT) {
-      const int r = e / per_row, q = e - r * per_row;
-      const int x = q / GG::NK, k = q - x * GG::NK;
-      ((unsigned short*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r) * out.sh + (long)(tx0 + x) * out.sw] =
-          s_out[(r * TW + x) * GG::S + k];
-    }
+    // The next commit rewrites s_f1/s_f2 (every MFMA fragment read finished before the barrier above) and the next band
+    // writes to s_out happen after the next tile's staging barrier, i.e. after every thread's copy-out reads: no extra barrier.
+    ti = nti; tile = ntile; have = nhave; b = nb; ty0 = nty0; tx0 = ntx0;
   }
+}
+
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            ? p.multiProcessorCount : 256;
+    n = (n / 8) * 8;
+    if (n < 8) n = 8;
+  }
+  return n;
 }
 
 template <int VEC, int MODE, int D>
@@ -307,7 +369,21 @@ static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ
                        float fs, int ac, int out_mode, hipStream_t st) {
   const int tx = (W + mf::TW - 1) / mf::TW, ty = (H + mf::TH - 1) / mf::TH;
   const WarpGeom wg(H, W, ac);
-  const dim3 grid((unsigned)(B * tx * ty)), block(64 * (2 * D + 1));
+  // persistent grid: a multiple of 8 (XCD-affine schedule), as many workgroups as are co-resident (queried once per variant)
+  const int ntiles = B * tx * ty;
+  const dim3 block(64 * (2 * D + 1));
+  static int occ_multi = 0, occ_single = 0;
+  int& occ_blocks = (C > 32) ? occ_multi : occ_single;
+  if (occ_blocks == 0) {
+    int nb = 0;
+    hipError_t e = (C > 32) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, true>, (int)block.x, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, false>, (int)block.x, 0);
+    occ_blocks = (e == hipSuccess && nb >= 1) ? (nb > 2 ? 2 : nb) : 1;
+  }
+  int g = ((ntiles + 7) / 8) * 8;
+  const int cap = occ_blocks * num_cus();
+  if (g > cap) g = cap;
+  const dim3 grid((unsigned)g);
   if (C > 32)
     hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, true>), grid, block, 0, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
                        out_mode);
