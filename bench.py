@@ -35,8 +35,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--steps", type=int, default=40)
     p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--preroll", type=int, default=24,
+                   help="untimed lazy-initialisation steps BEFORE the W warm-up steps: the first step JIT-loads MIOpen/torch "
+                        "kernels on a fresh box (~45 s) and the runtime has a one-time ~80 ms event at step 20 (measured, "
+                        "scripts/step_trace.py); neither belongs to the steady state being measured")
     p.add_argument("--batch", type=int, default=8, help="image pairs per GPU per step")
     p.add_argument("--height", type=int, default=436)
     p.add_argument("--width", type=int, default=1024)
@@ -117,24 +121,34 @@ def main():
     from ocflow_amd import ops
     from ocflow_amd.runtime import (KernelTimer, all_reduce_max, barrier, init_distributed, shutdown_distributed,
                                     synthetic_batch)
+    from ocflow_amd.runtime import use_repo_miopen_db
+    use_repo_miopen_db(os.environ.get("OCFLOW_MIOPEN_CAPTURE"))  # before the first convolution
     env = init_distributed()
     if env.device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X: the OCFlow hot path has no CPU fallback")
     if args.gpus != env.world_size:
         if env.world_size == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.backends.cudnn.benchmark = False
+    # MIOpen immediate mode + the find-db / kernel cache the repo ships for this workload (ocflow_amd/miopen_db, produced by a
+    # find-mode run of this benchmark): the tuned solvers are picked without the 45 s search of a fresh box.  OCFLOW_MIOPEN_FIND=1
+    # re-runs the search (same throughput, measured), OCFLOW_MIOPEN_CAPTURE=<dir> regenerates the db.
+    torch.backends.cudnn.benchmark = os.environ.get("OCFLOW_MIOPEN_FIND", "0") == "1"
 
     stepper = build_stepper(args, env)
     B = args.batch
     batch = stepper.prepare(synthetic_batch(B, args.height, args.width, env.device, seed=42, index_offset=env.rank * B))
 
     t_w = time.perf_counter()
+    for i in range(args.preroll):
+        stepper.step(batch)
+        if env.is_main and i in (0, args.preroll - 1):  # the first step loads/JITs kernels on a fresh box: show progress
+            torch.cuda.synchronize()
+            print(f"[bench] init pre-roll step {i + 1}/{args.preroll} done at {time.perf_counter() - t_w:.1f} s", file=sys.stderr, flush=True)
     for i in range(args.warmup):
         stepper.step(batch)
-        if env.is_main:  # the first step JIT-compiles MIOpen kernels on a fresh box (tens of seconds): show progress
-            torch.cuda.synchronize()
-            print(f"[bench] warm-up step {i + 1}/{args.warmup} done at {time.perf_counter() - t_w:.1f} s", file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    if env.is_main:
+        print(f"[bench] {args.warmup} warm-up steps done at {time.perf_counter() - t_w:.1f} s", file=sys.stderr, flush=True)
     timer = KernelTimer()
     ops.set_kernel_timer(timer)
     barrier(env)

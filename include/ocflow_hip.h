@@ -51,6 +51,12 @@ const char* ocf_status_string(int status);
 /* device name + CU count of the current device; returns OCF_ENODEVICE when there is none. */
 int ocf_device_info(char* name, int name_len, int* compute_units);
 
+/* Profiling aid: the NEXT launcher call on this thread records `start_event` immediately before and `stop_event`
+ * immediately after its kernel launch(es) on the launch stream (hipEvent_t handles passed as void*; one-shot).  Events
+ * recorded from the host language sit tens of microseconds of interpreter time away from the launch and, when the GPU is
+ * waiting for the host, count that idle gap as kernel time. */
+int ocf_profile_next_launch(void* start_event, void* stop_event);
+
 /* ---- K1+K2  local cost volume, optionally fused with the backward warp of f2 -------------
  * out[b,(dy+d)(2d+1)+(dx+d),y,x] = 1/C * sum_c f1[b,c,y,x] * w2[b,c,y+dy,x+dx]   (0 outside)
  *   w2 = f2                                            when flow == NULL

@@ -32,6 +32,7 @@ _i, _f, _vp = C.c_int, C.c_float, C.c_void_p
 SIGNATURES = {
     "ocf_abi_version": [],
     "ocf_device_info": [C.c_char_p, _i, C.POINTER(_i)],
+    "ocf_profile_next_launch": [_vp, _vp],
     "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ocf_corr_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_warp_fwd": [_T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],

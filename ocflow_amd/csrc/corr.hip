@@ -384,6 +384,7 @@ extern "C" int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const 
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
   if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  ocf::ScopedProfile prof(st);
   if (dtype == OCF_F32) return ocf::corr_fwd_t<float>(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, st);
   if (dtype == OCF_BF16) return ocf::corr_fwd_bf16_mfma(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, st);
   return OCF_EINVAL;

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
         else if (nhave) fetch(nb, nty0, ntx0, 0);
       }
       if (!(ablate & 1)) {
-#pragma unroll(MULTI ? TH : 1)
+#pragma unroll
         for (int ry = 0; ry < TH; ry++) {
           const bf16x8v a0 = __builtin_bit_cast(bf16x8v, s_f1[slot(TW, ry, ln, lg)]);
           const bf16x8v a1 = __builtin_bit_cast(bf16x8v, s_f1[slot(TW, ry, 16 + ln, lg)]);

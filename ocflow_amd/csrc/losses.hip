@@ -385,6 +385,20 @@ extern "C" int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int
   return launch_status();
 }
 
+namespace ocf {
+ProfileSlot& profile_slot() {
+  static thread_local ProfileSlot slot = {nullptr, nullptr};
+  return slot;
+}
+}  // namespace ocf
+
+extern "C" int ocf_profile_next_launch(void* start_event, void* stop_event) {
+  ocf::ProfileSlot& p = ocf::profile_slot();
+  p.start = (hipEvent_t)start_event;
+  p.stop = (hipEvent_t)stop_event;
+  return OCF_OK;
+}
+
 extern "C" int ocf_abi_version(void) { return OCF_ABI_VERSION; }
 
 extern "C" const char* ocf_status_string(int s) {

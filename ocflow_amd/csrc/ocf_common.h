@@ -207,6 +207,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // hipGetLastError() is sticky per thread: a failed query inside the caller's framework (e.g. hipPointerGetAttributes
 // on pageable host memory during a torch H2D copy) would otherwise be reported as OUR launch failing.
 static inline void clear_stale_error() { (void)hipGetLastError(); }
+// one-shot event bracketing requested through ocf_profile_next_launch() (defined in losses.hip)
+struct ProfileSlot { hipEvent_t start, stop; };
+ProfileSlot& profile_slot();
+struct ScopedProfile {
+  hipStream_t st;
+  hipEvent_t stop;
+  explicit ScopedProfile(hipStream_t s) : st(s), stop(nullptr) {
+    ProfileSlot& p = profile_slot();
+    if (p.start) { (void)hipEventRecord(p.start, st); }
+    stop = p.stop;
+    p.start = nullptr; p.stop = nullptr;
+  }
+  ~ScopedProfile() { if (stop) (void)hipEventRecord(stop, st); }
+};
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? OCF_OK : OCF_ELAUNCH; }
 
 }  // namespace ocf
