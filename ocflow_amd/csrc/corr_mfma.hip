@@ -39,7 +39,10 @@ template <int D> struct G {
   static constexpr int HH = TH + 2 * D;
   static constexpr int F2_SLOTS = (HH * ROWPX + SLACK_PX) * NUM;
   static constexpr int F1_SLOTS = TH * TW * NUM;
-  static constexpr int S = ((NK + 2) / 8) * 8 + 5;  // out pitch: (2S-2) mod 32 in {8, 24} => k-groups on disjoint banks
+  // output staging image [pixel][dy][NG groups of 4 columns]: pixel m keeps the 4-column groups floor(m/4)..+NG-1 of its
+  // D row, its band element dx sits at (m&3)+dx inside them -- every lane writes ONE aligned 8-byte vector per MFMA pair
+  static constexpr int NG = (N + 6) / 4;
+  static constexpr int PDY = 4 * NG, S = N * PDY;  // element pitches: per dy, per pixel (108 at d=4)
   static constexpr int OUT_ELEMS = TH * TW * S;
   static constexpr int NT = 64 * N;
   static constexpr int F2_ROWS_PER_WAVE = (HH + N - 1) / N;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
   constexpr int U = 8, ES = 2;
   typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
   constexpr int OCC_W = 48;  // halo occlusion tile pitch (floats)
-  __shared__ u32x4 smem[GG::F2_SLOTS + GG::F1_SLOTS + (GG::OUT_ELEMS * ES + 15) / 16 + (MODE >= 1 ? (GG::HH * OCC_W * 4) / 16 : 0)];
+  extern __shared__ u32x4 smem[];  // lds_bytes<D>(MODE) dynamic bytes (> 64 KiB static limit at d=4)
   u32x4* s_f2 = smem;
   u32x4* s_f1 = smem + GG::F2_SLOTS;
   unsigned short* s_out = (unsigned short*)(smem + GG::F2_SLOTS + GG::F1_SLOTS);
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
   const int per_xcd = (ntiles + 7) >> 3;
   const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, slots = gridDim.x >> 3;
 
-  constexpr bool PF = MULTI;  // register prefetch of the next block/tile; SINGLE relies on 2 co-resident workgroups instead
+  constexpr bool PF = false && MULTI;  // register prefetch of the next block/tile; SINGLE relies on 2 co-resident workgroups instead
   const int ncb = MULTI ? (C + 31) / 32 : 1;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int f1sh = (int)f1.sh, f1sw = (int)f1.sw, f2sh = (int)f2.sh, f2sw = (int)f2.sw;
@@ -198,27 +201,34 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
     }
   };
 
-  // ---- merged band write of the two 16x16 results (column tiles s and s+1) of strip s, tile row ry ----------------
-  // lane (n = l&15, g = l>>4), reg r holds row m = 4g+r; column n of tile s is dx index n-m (if >= 0), column n of tile
-  // s+1 is dx index 16+n-m: the two cases are disjoint, so ONE masked 2-byte LDS store per register covers both tiles.
+  // ---- band write.  The MFMAs compute the TRANSPOSED product D[n][m] = sum_c f2[n][c] * f1[m][c] (f2 fragment as A, f1 as B),
+  // so lane (m = l&15, g = l>>4) holds, for ITS pixel m, the four consecutive columns n = 4g..4g+3 in its four registers:
+  // four consecutive dx of one (pixel, dy).  Column group g of tile s (resp. s+1) is group g - m/4 (resp. g + 4 - m/4) of the
+  // pixel's NG kept groups; the two tiles' valid lanes are disjoint, so ONE masked, 8-byte aligned ds_write_b64 per MFMA pair
+  // stores the whole band (the 16 lanes of a k-group hit 16 distinct bank pairs: pixel pitch 54 dwords).
+  const int gq = lg - (ln >> 2);                      // group index for tile s; tile s+1: gq + 4
+  const bool bvalA = gq >= 0 && gq < GG::NG, bvalB = gq + 4 >= 0 && gq + 4 < GG::NG;
+  const int boff = (ln * GG::S + wave * GG::PDY + (bvalA ? gq : gq + 4) * 4) * ES;
   auto band_write = [&](const f32x4& dA, const f32x4& dB, int ry, int s) __attribute__((always_inline)) {
-    float oA = invC, oB = invC;
-    if (MODE >= 1) {
-      oA *= s_occ[(ry + wave) * OCC_W + 16 * s + ln];
-      oB *= s_occ[(ry + wave) * OCC_W + 16 * (s + 1) + ln];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int m = 4 * lg + r;
-      const int dxi = (ln - m) & 15;
-      if (dxi < GG::N) {
-        const float v = (ln >= m) ? dA[r] * oA : dB[r] * oB;
-        const bf16 h = (bf16)v;
-        s_out[(ry * TW + 16 * s + m) * GG::S + wave * GG::N + dxi] = __builtin_bit_cast(unsigned short, h);
+    if (bvalA || bvalB) {
+      f32x4 v = bvalA ? dA : dB;
+      if (MODE >= 1) {
+        // occ of the f2 pixel = D row n = 4g + r of column tile s (A) or s+1 (B): four consecutive floats
+        const f32x4 o = *(const f32x4*)(s_occ + (ry + wave) * OCC_W + 16 * (bvalA ? s : s + 1) + 4 * lg);
+        v = v * o;
       }
+      v = v * invC;
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      const bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      *(bf16x4*)((char*)s_out + (ry * TW + 16 * s) * GG::S * ES + boff) = h;
     }
   };
 
+  // LDS element offset of output (pixel x of tile row r, k = dy*N + dx)
+  auto oidx = [&](int r, int x, int k) __attribute__((always_inline)) {
+    const int dy = k / GG::N, dx = k - dy * GG::N;
+    return (r * TW + x) * GG::S + dy * GG::PDY + (x & 3) + dx;
+  };
   f32x4 acc[MULTI ? TH : 1][4];
 
   // first tile of this workgroup
@@ -269,17 +279,17 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
           const bf16x8v b1 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, 16 + ln, lg)]);
           const bf16x8v b2 = __builtin_bit_cast(bf16x8v, s_f2[slot(ROWPX, hr, 32 + ln, lg)]);
           if (MULTI) {
-            acc[ry][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[ry][0], 0, 0, 0);
-            acc[ry][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[ry][1], 0, 0, 0);
-            acc[ry][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[ry][2], 0, 0, 0);
-            acc[ry][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[ry][3], 0, 0, 0);
+            acc[ry][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a0, acc[ry][0], 0, 0, 0);
+            acc[ry][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a0, acc[ry][1], 0, 0, 0);
+            acc[ry][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a1, acc[ry][2], 0, 0, 0);
+            acc[ry][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a1, acc[ry][3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep one row's fragments live at a time (register pressure)
           } else {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, z, 0, 0, 0);
-            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, z, 0, 0, 0);
-            const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, z, 0, 0, 0);
-            const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, z, 0, 0, 0);
+            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a0, z, 0, 0, 0);
+            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a0, z, 0, 0, 0);
+            const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a1, z, 0, 0, 0);
+            const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a1, z, 0, 0, 0);
             if (!(ablate & 4)) {
               band_write(d0, d1, ry, 0);
               band_write(d2, d3, ry, 1);
@@ -307,23 +317,28 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
         const int nvec = row_elems >> 3;
         for (int r = 0; r < vrows; r++) {
           char* gp = out.p + ((long)b * out.sb + (long)(ty0 + r) * out.sh + (long)tx0 * out.sw) * ES;
-          const unsigned short* lp = s_out + r * TW * GG::S;
           for (int v = tid; v < nvec; v += GG::NT) {
+            // 8 consecutive outputs starting at (pixel px, k).  In the grouped LDS image consecutive k are consecutive elements
+            // except for ONE possible jump inside the chunk, at the next dy boundary (element index w): +3 elements (group
+            // padding), or, when that boundary is also the pixel boundary, +4 + ((px+1)&3) - (px&3).
             const int e0 = v * 8;
-            int px = e0 / GG::NK, k = e0 - px * GG::NK;
+            const int px = e0 / GG::NK, k = e0 - px * GG::NK;
+            const int dy = k / GG::N, dx = k - dy * GG::N;
+            const int w = GG::N - dx;
+            const int jump = (dy == GG::N - 1) ? (GG::S - GG::N * GG::PDY) + (GG::PDY - GG::N) + 1 + (((px + 1) & 3) - (px & 3)) - 1
+                                               : GG::PDY - GG::N;
+            const char* lpA = (const char*)s_out + (((r * TW + px) * GG::S) + dy * GG::PDY + (px & 3) + dx) * ES;
+            const char* lpB = lpA + jump * ES;
             unsigned short h[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-              h[j] = lp[px * GG::S + k];
-              if (++k == GG::NK) { k = 0; px++; }
-            }
+            for (int j = 0; j < 8; j++) h[j] = *(const unsigned short*)((j >= w ? lpB : lpA) + j * ES);
             u32x4 pk = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
                         (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
             ((u32x4*)gp)[v] = pk;
           }
           for (int e = nvec * 8 + tid; e < row_elems; e += GG::NT) {
             const int px = e / GG::NK, k = e - px * GG::NK;
-            ((unsigned short*)gp)[e] = lp[px * GG::S + k];
+            ((unsigned short*)gp)[e] = s_out[oidx(r, px, k)];
           }
         }
       } else if (out.sw == 1) {
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
           const int k = e / per_k, q = e - k * per_k;
           const int r = q / vcols, x = q - r * vcols;
           ((unsigned short*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r) * out.sh + (long)(tx0 + x)] =
-              s_out[(r * TW + x) * GG::S + k];
+              s_out[oidx(r, x, k)];
         }
       } else {
         const int per_row = vcols * GG::NK;
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
           const int r = e / per_row, q = e - r * per_row;
           const int x = q / GG::NK, k = q - x * GG::NK;
           ((unsigned short*)out.p)[(long)b * out.sb + (long)k * out.sc + (long)(ty0 + r) * out.sh + (long)(tx0 + x) * out.sw] =
-              s_out[(r * TW + x) * GG::S + k];
+              s_out[oidx(r, x, k)];
         }
       }
     }
@@ -349,6 +364,11 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
     // writes to s_out happen after the next tile's staging barrier, i.e. after every thread's copy-out reads: no extra barrier.
     ti = nti; tile = ntile; have = nhave; b = nb; ty0 = nty0; tx0 = ntx0;
   }
+}
+
+template <int D> static size_t lds_bytes(int mode) {
+  using GG = mf::G<D>;
+  return (size_t)(GG::F2_SLOTS + GG::F1_SLOTS) * 16 + ((GG::OUT_ELEMS * 2 + 15) / 16) * 16 + (mode >= 1 ? GG::HH * 48 * 4 : 0);
 }
 
 static int num_cus() {
@@ -372,12 +392,19 @@ static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ
   // persistent grid: a multiple of 8 (XCD-affine schedule), as many workgroups as are co-resident (queried once per variant)
   const int ntiles = B * tx * ty;
   const dim3 block(64 * (2 * D + 1));
+  const size_t lds = lds_bytes<D>(MODE);
   static int occ_multi = 0, occ_single = 0;
   int& occ_blocks = (C > 32) ? occ_multi : occ_single;
   if (occ_blocks == 0) {
     int nb = 0;
-    hipError_t e = (C > 32) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, true>, (int)block.x, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, false>, (int)block.x, 0);
+    hipError_t e;
+    if (C > 32) {
+      (void)hipFuncSetAttribute((const void*)corr_fwd_mfma<VEC, MODE, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, true>, (int)block.x, lds);
+    } else {
+      (void)hipFuncSetAttribute((const void*)corr_fwd_mfma<VEC, MODE, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, false>, (int)block.x, lds);
+    }
     occ_blocks = (e == hipSuccess && nb >= 1) ? (nb > 2 ? 2 : nb) : 1;
   }
   int g = ((ntiles + 7) / 8) * 8;
@@ -385,10 +412,10 @@ static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ
   if (g > cap) g = cap;
   const dim3 grid((unsigned)g);
   if (C > 32)
-    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, true>), grid, block, 0, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
+    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, true>), grid, block, lds, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
                        out_mode);
   else
-    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, false>), grid, block, 0, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
+    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, false>), grid, block, lds, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
                        out_mode);
   return launch_status();
 }
