@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int cb = 0; cb < ncb; cb++) {
-      if (!PF) fetch(b, ty0, tx0, 0);
+      if (!PF) fetch(b, ty0, tx0, cb * 32);
       commit();
       if (cb == 0) stage_occ(b, ty0, tx0);
       __syncthreads();
