@@ -48,7 +48,7 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--layout", default="cl", choices=["cl", "nchw"])
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables it)")
-    p.add_argument("--ops-only", action="store_true", help="also time the correlation launches alone (no convs)")
+    p.add_argument("--graph", type=int, default=0, help="1: capture the whole training step in a hipGraph and replay it (N=1 only)")
     return p.parse_args()
 
 
@@ -116,6 +116,32 @@ def cpu_baseline(args, budget_s):
                       f"(pad-and-shift correlation, grid_sample warp), {dt:.2f} s/step"}
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per launch of the correlation kernel from the committed rocprofv3 PMC passes of THIS command
+    (scripts/profile_bench.sh -> profiles/latest_rocprof_ocf_kernels_summary.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, per
+    MI355X_MICROARCH.md), averaged over the five pyramid-level launches exactly like `achieved`.  PMC counters cannot be read
+    from inside the timed run, so this field is only as fresh as that file; None when it is absent."""
+    path = os.path.join(ROOT, "profiles", "latest_rocprof_ocf_kernels_summary.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+        total, launches, dur = 0, 0, 0.0
+        for name, grids in kernels.items():
+            if "corr_fwd" not in name:
+                continue
+            for g in grids.values():
+                if "FETCH_SIZE_bytes_corrected" in g and "WRITE_SIZE_bytes_corrected" in g:
+                    total += g["FETCH_SIZE_bytes_corrected"] + g["WRITE_SIZE_bytes_corrected"]
+                    dur += g.get("avg_us", 0.0)
+                    launches += 1
+        if launches == 0:
+            return {"traffic": None}
+        return {"traffic": int(total / launches), "traffic_source": "profiles/latest_rocprof_ocf_kernels_summary.json (rocprofv3 --pmc "
+                "FETCH_SIZE / WRITE_SIZE passes of this command)", "rocprof_avg_launch_us": round(dur / launches, 2)}
+    except (OSError, ValueError, KeyError):
+        return {"traffic": None}
+
+
 def main():
     args = parse()
     from ocflow_amd import ops
@@ -139,6 +165,9 @@ def main():
     batch = stepper.prepare(synthetic_batch(B, args.height, args.width, env.device, seed=42, index_offset=env.rank * B))
 
     t_w = time.perf_counter()
+    if args.graph:
+        stepper.enable_graph(batch)
+        batch = stepper._static_batch
     for i in range(args.preroll):
         stepper.step(batch)
         if env.is_main and i in (0, args.preroll - 1):  # the first step loads/JITs kernels on a fresh box: show progress
@@ -149,7 +178,7 @@ def main():
     torch.cuda.synchronize()
     if env.is_main:
         print(f"[bench] {args.warmup} warm-up steps done at {time.perf_counter() - t_w:.1f} s", file=sys.stderr, flush=True)
-    timer = KernelTimer()
+    timer = KernelTimer(enabled=not args.graph)  # events cannot be read back from inside a replayed graph
     ops.set_kernel_timer(timer)
     barrier(env)
     torch.cuda.synchronize()
@@ -173,9 +202,13 @@ def main():
                          "GBps": round(v["bytes"] / (1e-3 * v["ms_total"] / v["launches"]) / 1e9, 1)}
                      for k, v in summ["by_shape"].items()}
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "corr_fwd_tiled",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "ocf::corr_fwd_mfma (ocf_corr_fwd)",
                     "launches": summ["launches"], "avg_launch_us": round(1e3 * summ["ms_total"] / summ["launches"], 2),
+                    "algorithmic_bytes_per_launch": int(summ["bytes_total"] / summ["launches"]),
                     "tflops": round(summ["flops_total"] / (summ["ms_total"] * 1e-3) / 1e12, 2), "per_level": per_level}
+
+    if roofline is not None:
+        roofline.update(pmc_traffic_per_launch())
 
     cpu = None
     if env.is_main and env.world_size == 1 and args.cpu_seconds > 0:

@@ -170,6 +170,8 @@ class TrainStepper:
         self.raw = module
         self.optimizer = module.configure_optimizers()
         self.module = wrap_ddp(_StepAdapter(module), env)
+        self._graph = None
+        self._graph_pool = None
 
     def prepare(self, batch):
         out = []
@@ -181,7 +183,12 @@ class TrainStepper:
         return tuple(out)
 
     def step(self, batch, batch_idx: int = 0) -> torch.Tensor:
-        self.optimizer.zero_grad(set_to_none=True)
+        if self._graph is not None:
+            return self._replay(batch)
+        return self._eager_step(batch, batch_idx)
+
+    def _eager_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        self.optimizer.zero_grad(set_to_none=self._graph_pool is None)
         ctx = torch.autocast(self.env.device.type, dtype=self.amp_dtype) if self.amp_dtype is not None else nullcontext()
         with ctx:
             loss = self.module(batch, batch_idx)
@@ -189,6 +196,42 @@ class TrainStepper:
         self.optimizer.step()
         self.raw.global_step = getattr(self.raw, "global_step", 0) + 1
         return loss.detach()
+
+    # ---- whole-step hipGraph: the eager step issues ~1600 kernel launches and is host-bound (GPU busy ~60 %); capturing
+    # forward + loss + backward + Adam once and replaying it removes the launch path.  Single-GPU only for now (capturing
+    # DDP's RCCL all-reduce needs the side-stream construction + 11 eager iterations recipe and cannot be tested on one GPU).
+    def enable_graph(self, batch, warmup: int = 3):
+        if self.env.world_size != 1:
+            raise RuntimeError("TrainStepper.enable_graph: whole-step graph capture is single-GPU only")
+        if self.env.device.type != "cuda":
+            raise RuntimeError("TrainStepper.enable_graph needs a HIP device")
+        # Adam must keep its step counter on the device to be capturable
+        for g in self.optimizer.param_groups:
+            g["capturable"] = True
+        self._static_batch = tuple(t.clone() for t in batch)
+        self._graph_pool = torch.cuda.graph_pool_handle()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup):  # lazy initialisation (kernel attribute queries, allocator growth) outside the capture
+                self._eager_step(self._static_batch, i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=False)
+        with torch.cuda.graph(graph, pool=self._graph_pool):
+            self._static_loss = self._eager_step(self._static_batch, 0)
+        self._graph = graph
+        return self
+
+    def _replay(self, batch) -> torch.Tensor:
+        if batch is not self._static_batch:
+            for dst, src in zip(self._static_batch, batch):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        self.raw.global_step = getattr(self.raw, "global_step", 0) + 1
+        return self._static_loss
 
 
 class _StepAdapter(torch.nn.Module):

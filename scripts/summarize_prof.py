@@ -77,9 +77,12 @@ def main():
     if st:
         with open(st) as f, open(base + "_kernel_stats.csv", "w") as g:
             for i, line in enumerate(f):
-                if i > 60:
-                    break
-                g.write(line[:400].rstrip("\n") + "\n")
+                # keep every row, shorten the (templated) kernel names: '"name",calls,total,avg,pct,min,max,std'
+                line = line.rstrip("\n")
+                if line.startswith('"') and '",' in line:
+                    name, rest = line[1:].rsplit('",', 1)
+                    line = '"' + name[:160].replace('"', "'") + '",' + rest
+                g.write(line + "\n")
     if not keep:
         for d in (base, base + "_fetch", base + "_write"):
             for p in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
