@@ -44,7 +44,9 @@ def parse():
     p.add_argument("--batch", type=int, default=8, help="image pairs per GPU per step")
     p.add_argument("--height", type=int, default=436)
     p.add_argument("--width", type=int, default=1024)
-    p.add_argument("--model", default="flowoccnet", choices=["flowoccnet", "pwoc"])
+    p.add_argument("--model", default="flowoccnet", choices=["flowoccnet", "pwoc", "flownet", "pwc"],
+                   help="flowoccnet/pwoc: FlowOccModel supervised step (headline); flownet/pwc: FlowStageModel unsupervised "
+                        "occlusion-aware step (2 forwards + warp/photometric/smoothness/range-map loss kernels)")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--layout", default="cl", choices=["cl", "nchw"])
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables it)")
@@ -52,13 +54,21 @@ def parse():
     return p.parse_args()
 
 
+def build_module(args):
+    if args.model in ("flowoccnet", "pwoc"):
+        from ocflow_amd.models.flow_occ_model import FlowOccModel
+        return FlowOccModel({"model": args.model, "learning_rate": 1e-4})
+    from ocflow_amd.models.model import FlowStageModel
+    # config/unsupervised_config.yml weights with network_type 'flow' 
+    return FlowStageModel({"learning_rate": 1e-5, "model": args.model, "displacement": 4, "photo_weight": 4.0, "smooth1_weight": 0.5,
+                           "smooth2_weight": 0.0, "with_occ": False, "occ_aware": True})
+
+
 def build_stepper(args, env):
-    from ocflow_amd.models.flow_occ_model import FlowOccModel
     from ocflow_amd.runtime import TrainStepper
     torch.manual_seed(42)
-    module = FlowOccModel({"model": args.model, "learning_rate": 1e-4})
     amp = torch.bfloat16 if args.dtype == "bf16" else None
-    return TrainStepper(module, env, amp_dtype=amp, channels_last=(args.layout == "cl"))
+    return TrainStepper(build_module(args), env, amp_dtype=amp, channels_last=(args.layout == "cl"))
 
 
 def usable_cores() -> int:
@@ -88,7 +98,6 @@ def cpu_baseline(args, budget_s):
     training step, batch 1, fp32.  Bounded sample: the first step is the probe; further steps only while they fit the
     budget.  Progress goes to stderr (a silent GPU box is taken for hung)."""
     from oracle.backend import oracle_ops
-    from ocflow_amd.models.flow_occ_model import FlowOccModel
     from ocflow_amd.runtime import DistEnv, TrainStepper, synthetic_batch
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -96,8 +105,7 @@ def cpu_baseline(args, budget_s):
     times = []
     with oracle_ops():
         torch.manual_seed(42)
-        stepper = TrainStepper(FlowOccModel({"model": args.model, "learning_rate": 1e-4}), env, amp_dtype=None,
-                               channels_last=False)
+        stepper = TrainStepper(build_module(args), env, amp_dtype=None, channels_last=False)
         batch = synthetic_batch(1, args.height, args.width, "cpu", seed=42)
         t_start = time.perf_counter()
         while True:
@@ -112,7 +120,7 @@ def cpu_baseline(args, budget_s):
     dt = sum(timed) / len(timed)
     return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
             "sample": f"{len(timed)} training step(s){' after 1 warm-up' if len(times) > 1 else ' (cold)'} of "
-                      f"FlowOccModel('{args.model}') at batch 1, {args.height}x{args.width}, fp32, oracle ops "
+                      f"the same model ('{args.model}') at batch 1, {args.height}x{args.width}, fp32, oracle ops "
                       f"(pad-and-shift correlation, grid_sample warp), {dt:.2f} s/step"}
 
 
@@ -225,7 +233,8 @@ def main():
             "unit": "image-pairs/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"flow_occ_model FlowOccModel('{args.model}') full training step, {args.height}x{args.width} "
+            "config": {"workload": f"{'flow_occ_model FlowOccModel' if args.model in ('flowoccnet', 'pwoc') else 'unsupervised FlowStageModel'}"
+                                   f"('{args.model}') full training step, {args.height}x{args.width} "
                                    f"Sintel-style pairs, corr d=4, 5 pyramid levels, {B} pairs/GPU (BASELINE configs[1] "
                                    f"shape; per-rank share of configs[4])",
                        "global_batch": B * n, "height": args.height, "width": args.width, "layout": args.layout,

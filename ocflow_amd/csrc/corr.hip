@@ -299,6 +299,125 @@ __global__ __launch_bounds__(256) void corr_bwd_gather(T4 f1, T4 w2, T4 g, T4 g1
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward (v2, channels_last 16-byte units): LDS-tiled gather.  One workgroup = 16x4 pixel tile x 4 channel units
+// (32 bf16 / 16 fp32 channels per pass), 256 threads = (pixel, unit).  Per pass the +-d halo tile of the OTHER operand
+// (w2 for g1, f1 for g2) and the needed slice of grad_out are staged once in LDS:
+//   g1[p][c] = 1/C sum_k gout[p][k]        * w2[p + delta_k][c]     coefficients: the thread's own pixel (tile of gout)
+//   g2[p][c] = 1/C sum_k gout[q][K-1-k']   * f1[q][c], q = p + delta_k'   coefficients: the SOURCE pixel, mirrored tap (halo of gout)
+// so each (2d+1)^2-tap sum reads LDS only: one broadcast 2/4-byte coefficient + one 16-byte unit per tap, 8 FMAs.
+// v1 (corr_bwd_gather below) issued all 4*(2d+1)^2 loads per thread against L1/L2 and fetched 14x the algorithmic bytes from
+// HBM at the level-2 shape (rocprofv3 FETCH_SIZE 924 MB); it remains the fallback for strided layouts.
+// ------------------------------------------------------------------------------------------------
+constexpr int BTW = 16, BTH = 4, BNU = 4;
+
+template <typename T, bool G2, int D>
+__global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t, int B, int C, int H, int W, int tiles_x, int tiles_y,
+                                                      int gvec) {
+  constexpr int U = Unit<T>::U, ES = (int)sizeof(T);
+  constexpr int N = 2 * D + 1, NK = N * N;
+  constexpr int HH = BTH + 2 * D, HW = BTW + 2 * D;
+  constexpr int GROWS = G2 ? HH : BTH, GCOLS = G2 ? HW : BTW;   // region of grad_out staged
+  constexpr int GPITCH = NK;                                      // LDS row image == global row image (dense channels_last grad_out)
+  __shared__ u32x4 s_op[BNU * HH * HW];                           // [row][x][unit]
+  __shared__ __attribute__((aligned(16))) T s_g[GROWS * GCOLS * GPITCH + 8];
+
+  const int tid = threadIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi;
+  const int trem = tile - b * tpi;
+  const int ty0 = (trem / tiles_x) * BTH, tx0 = (trem % tiles_x) * BTW;
+  const int u = tid & (BNU - 1), px = tid >> 2;
+  const int lx = px & (BTW - 1), ly = px >> 4;
+  const int y = ty0 + ly, x = tx0 + lx;
+  const float invC = 1.f / (float)C;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // ---- stage the grad_out slice once (all channel passes reuse it): rows of GCOLS pixels x NK contiguous elements.
+  // Interior tiles of a dense, 8-byte aligned grad_out copy whole rows with 8-byte vectors; edge tiles go element by element.
+  {
+    const int gy0 = G2 ? ty0 - D : ty0, gx0 = G2 ? tx0 - D : tx0;
+    constexpr int ROWE = GCOLS * NK, VE = 8 / ES;  // elements per row / per 8-byte vector
+    if (gvec && gx0 >= 0 && gx0 + GCOLS <= W && ROWE % VE == 0) {
+      for (int v = tid; v < GROWS * (ROWE / VE); v += 256) {
+        const int r = v / (ROWE / VE), q = v - r * (ROWE / VE);
+        const int gy = gy0 + r;
+        u32x2 val = {0u, 0u};
+        if (gy >= 0 && gy < H) val = *(const u32x2*)(g.p + ((long)b * g.sb + (long)gy * g.sh + (long)gx0 * g.sw) * ES + (long)q * 8);
+        *(u32x2*)((char*)s_g + (long)r * ROWE * ES + q * 8) = val;
+      }
+    } else {
+      for (int e = tid; e < GROWS * ROWE; e += 256) {
+        const int r = e / ROWE, q = e - r * ROWE;
+        const int xx = q / NK, k = q - xx * NK;
+        const int gy = gy0 + r, gx = gx0 + xx;
+        T v = (T)0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ((const T*)g.p)[(long)b * g.sb + (long)gy * g.sh + (long)gx * g.sw + k];
+        s_g[(r * GCOLS + xx) * GPITCH + k] = v;
+      }
+    }
+  }
+  const int ncb = (C + BNU * U - 1) / (BNU * U);
+  for (int cb = 0; cb < ncb; cb++) {
+    const int cbase = cb * BNU * U;
+    if (cb > 0) __syncthreads();
+    // ---- stage the halo tile of the other operand for this channel block
+    for (int it = tid; it < HH * HW * BNU; it += 256) {
+      const int uu = it & (BNU - 1), pos = it >> 2;
+      const int xx = pos % HW, r = pos / HW;
+      const int gy = ty0 - D + r, gx = tx0 - D + xx, c0 = cbase + uu * U;
+      u32x4 v = zero4;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C)
+        v = *(const u32x4*)(other.p + ((long)b * other.sb + (long)gy * other.sh + (long)gx * other.sw + c0) * ES);
+      s_op[(r * HW + xx) * BNU + uu] = v;
+    }
+    __syncthreads();
+    float acc[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) acc[j] = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < N; r++) {
+      const u32x4* orow = &s_op[((ly + r) * HW + lx) * BNU + u];
+      // g1: own pixel, taps r*N .. r*N+N-1;  g2: source pixel (ly+r, lx+s) of the halo, mirrored tap NK-1-(r*N+s)
+      const T* grow = G2 ? &s_g[((ly + r) * GCOLS + lx) * GPITCH + (NK - 1 - r * N)] : &s_g[(ly * GCOLS + lx) * GPITCH + r * N];
+#pragma unroll
+      for (int sft = 0; sft < N; sft++) {
+        const float gk = (float)(G2 ? grow[sft * GPITCH - sft] : grow[sft]);
+        float f[U];
+        unit_to_f<T>(orow[sft * BNU], f);
+#pragma unroll
+        for (int j = 0; j < U; j++) acc[j] = __builtin_fmaf(gk, f[j], acc[j]);
+      }
+    }
+    const int c0 = cbase + u * U;
+    if (y < H && x < W && c0 < C) {
+#pragma unroll
+      for (int j = 0; j < U; j++) acc[j] *= invC;
+      *(u32x4*)(gout_t.p + ((long)b * gout_t.sb + (long)y * gout_t.sh + (long)x * gout_t.sw + c0) * ES) = f_to_unit<T>(acc);
+    }
+  }
+}
+
+template <typename T, bool G2>
+static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, const ocf_tensor4* dst, int B, int C, int H, int W, int d,
+                             hipStream_t st) {
+  const int tx = (W + BTW - 1) / BTW, ty = (H + BTH - 1) / BTH;
+  const dim3 grid((unsigned)(B * tx * ty)), block(256);
+  const int nk = (2 * d + 1) * (2 * d + 1);
+  const long es = sizeof(T);
+  // 8-byte vector staging of grad_out rows: dense channels_last, row starts 8-byte aligned ((gy*W + gx0)*nk*es % 8 == 0)
+  const long per = 8 / es;  // pixels offsets must be multiples of `per` when nk is odd
+  const int gvec = g->sc == 1 && g->sw == nk && g->sh == (long)W * nk && ((uintptr_t)g->data % 8 == 0) && (g->sb * es) % 8 == 0 &&
+                   ((nk % per == 0) || (W % per == 0 && (!G2 || d % per == 0) && BTW % per == 0));
+  switch (d) {
+    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <typename T> static bool vec_ok(const ocf_tensor4* t) { return vec_width<T>(t) == 16; }
@@ -361,6 +480,12 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
   bool vec = vec_ok<T>(f1) && vec_ok<T>(w2);
   if (g1) vec = vec && vec_ok<T>(g1);
   if (g2) vec = vec && vec_ok<T>(g2);
+  // tiled path: 16-byte units everywhere, whole units only, grad_out with unit channel stride
+  if (vec && C % U == 0 && g->sc == 1) {
+    if (g1) launch_bwd_tiled<T, false>(w2, g, g1, B, C, H, W, d, st);
+    if (g2) launch_bwd_tiled<T, true>(f1, g, g2, B, C, H, W, d, st);
+    return launch_status();
+  }
   const int nunits = (C + U - 1) / U;
   const long total = (long)B * H * W * nunits;
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);

@@ -97,7 +97,8 @@ class FlowStageModel(HotPathHelpers, LightningModule):
             photo_occ = ops.warp_photometric_error(img1, img2, flow_pred.detach(), 1.0 - occ_pred)
             if occ is not None:
                 # argument order as in the reference (input=occ, target=occ_pred): model.py:407, logged only
-                occ_error = F.binary_cross_entropy(occ.float(), occ_pred)
+                with torch.autocast(device_type=imgs.device.type, enabled=False):  # BCE refuses reduced-precision autocast
+                    occ_error = F.binary_cross_entropy(occ.float(), occ_pred.float())
                 return photo, smooth1, smooth2, flow_error, photo_occ, occ_error
         return photo, smooth1, smooth2, flow_error, photo_occ
 
