@@ -208,6 +208,9 @@ class TrainStepper:
         # Adam must keep its step counter on the device to be capturable
         for g in self.optimizer.param_groups:
             g["capturable"] = True
+        for st in self.optimizer.state.values():  # steps taken before the capture left host-side counters behind
+            if "step" in st and torch.is_tensor(st["step"]) and st["step"].device != self.env.device:
+                st["step"] = st["step"].to(self.env.device)
         self._static_batch = tuple(t.clone() for t in batch)
         self._graph_pool = torch.cuda.graph_pool_handle()
         side = torch.cuda.Stream()
