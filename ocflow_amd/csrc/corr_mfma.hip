@@ -48,6 +48,7 @@ template <int D> struct G {
   static constexpr int F2_ROWS_PER_WAVE = (HH + N - 1) / N;
   static constexpr int F2_IT = (ROWPX * NUM + 63) / 64;  // 160 items per row -> 3 lane sweeps
   static constexpr int F1_IT = (TW * NUM) / 64;           // 128 items per row -> 2 lane sweeps
+  static constexpr int F1_ROWS_PER_WAVE = (TH + N - 1) / N;  // 1 at d >= 2 (N >= TH waves), 2 at d = 1
 };
 
 __device__ __forceinline__ int slot(int rowpx, int row, int x, int u) { return (row * rowpx + x) * NUM + (((x >> 2) & 3) ^ ((3 * u) & 3)); }
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
   const float invC = 1.f / (float)C;
   const bool has_occ = MODE >= 1 && occ.p != nullptr;
 
-  u32x4 pf2[GG::F2_ROWS_PER_WAVE][GG::F2_IT], pf1[GG::F1_IT];
+  u32x4 pf2[GG::F2_ROWS_PER_WAVE][GG::F2_IT], pf1[GG::F1_ROWS_PER_WAVE][GG::F1_IT];
 
   // ---- fetch: global -> registers for (tile at b, ty0, tx0; channel block cbase) -----------------------------------
   auto fetch = [&](int b, int ty0, int tx0, int cbase) __attribute__((always_inline)) {
@@ -149,8 +150,9 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
         pf2[rr][k] = val;
       }
     }
-    {
-      const int r = wave, gy = ty0 + r;
+#pragma unroll
+    for (int rr = 0; rr < GG::F1_ROWS_PER_WAVE; rr++) {
+      const int r = wave + rr * GG::N, gy = ty0 + r;
 #pragma unroll
       for (int k = 0; k < GG::F1_IT; k++) {
         const int it = lane + 64 * k;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
         const int gx = tx0 + x, c0 = cbase + u * U;
         u32x4 val = zero4;
         if (r < TH && gy < H && gx < W && c0 < C && !(ablate & 2)) val = load_unit_full<T, VEC>(f1i, gy * f1sh + gx * f1sw, c0, C);
-        pf1[k] = val;
+        pf1[rr][k] = val;
       }
     }
   };
@@ -177,13 +179,17 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
         }
       }
     }
-    if (wave < TH) {
 #pragma unroll
-      for (int k = 0; k < GG::F1_IT; k++) {
-        const int it = lane + 64 * k;
-        int u, x;
-        row_item<VEC, TW>(it, u, x);
-        s_f1[slot(TW, wave, x, u)] = pf1[k];
+    for (int rr = 0; rr < GG::F1_ROWS_PER_WAVE; rr++) {
+      const int r = wave + rr * GG::N;
+      if (r < TH) {
+#pragma unroll
+        for (int k = 0; k < GG::F1_IT; k++) {
+          const int it = lane + 64 * k;
+          int u, x;
+          row_item<VEC, TW>(it, u, x);
+          s_f1[slot(TW, r, x, u)] = pf1[rr][k];
+        }
       }
     }
   };
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
     // ---- copy-out: LDS [row][x][S] -> out[b, k, y, x]; the stores drain while the next tile is staged -------------
     if (!(ablate & 4) && !(ablate & 8)) {
       const int vrows = min(TH, H - ty0), vcols = min(TW, W - tx0);
-      if (out_mode == MOUT_CL_VEC) {
+      if (out_mode == MOUT_CL_VEC && GG::N >= 7) {  // (a chunk of 8 crosses at most one dy boundary only when N >= 7)
         // dense channels_last: a tile row is one contiguous run of vcols*NK bf16, 16-byte aligned at the start
         const int row_elems = vcols * GG::NK;
         const int nvec = row_elems >> 3;

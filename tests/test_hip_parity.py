@@ -102,6 +102,63 @@ def test_corr_warp_fused(ops, ac, with_occ, cl):
         close(x, y, 1e-4)
 
 
+@pytest.mark.parametrize("shape,d", [((2, 32, 21, 45), 4), ((1, 64, 30, 70), 4), ((1, 196, 7, 16), 4), ((2, 96, 9, 33), 4), ((1, 32, 12, 40), 2),
+                                      ((1, 40, 8, 32), 3), ((1, 16, 5, 5), 1)])
+@pytest.mark.parametrize("mode", ["occ", "warp", "warp+occ"])
+@pytest.mark.parametrize("layout", ["cl", "nchw", "view"])
+def test_corr_bf16_matrix_core_modes(ops, shape, d, mode, layout):
+    """bf16 runs on the MFMA band-GEMM kernel (corr_mfma.hip): every staging mode (occlusion on the outputs, fused warp gather)
+    x every layout (dense channels_last fast path, NCHW, strided channel slice) x single / multi channel block / partial last
+    block (C=196, C=40) / d < 4, against the oracle on the same bf16-rounded inputs.  Tolerance 2e-2: bf16 output rounding
+    (+ the warp's bf16 rounding of the gathered features in the fused mode)."""
+    gen = torch.Generator().manual_seed((hash((shape, d, mode)) & 0xffff) + 1)
+    B, C, H, W = shape
+    f1 = torch.randn(shape, generator=gen).bfloat16()
+    f2 = torch.randn(shape, generator=gen).bfloat16()
+    flow = torch.randn((B, 2, H, W), generator=gen) * 2.0 if "warp" in mode else None
+    occ = torch.rand((B, 1, H, W), generator=gen) if "occ" in mode else None
+    if flow is not None:
+        w2 = O.warp(f2.float(), flow * 1.25, False).bfloat16().float()  # the kernel rounds the gathered features to bf16
+    else:
+        w2 = f2.float()
+    ref = O.compute_cost_volume(f1.float(), w2 * occ if occ is not None else w2, d)
+
+    def lay(t):
+        t = t.to(DEV)
+        if layout == "cl":
+            return t.contiguous(memory_format=torch.channels_last)
+        if layout == "view":
+            big = torch.zeros((B, C + 5, H, W + 3), device=DEV, dtype=t.dtype).contiguous(memory_format=torch.channels_last)
+            big[:, 3:3 + C, :, 2:2 + W] = t
+            return big[:, 3:3 + C, :, 2:2 + W]
+        return t.contiguous()
+
+    out = ops.corr_warp(lay(f1), lay(f2), None if flow is None else flow.to(DEV), None if occ is None else occ.to(DEV), d, 1.25, False)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    close(out, ref, 2e-2)
+
+
+def test_corr_bf16_output_into_concat_buffer(ops):
+    """the stride ABI lets the kernel write the cost volume straight into a channel slice of a wider channels_last buffer"""
+    gen = torch.Generator().manual_seed(77)
+    f1 = torch.randn((2, 32, 16, 48), generator=gen).bfloat16()
+    f2 = torch.randn((2, 32, 16, 48), generator=gen).bfloat16()
+    ref = O.compute_cost_volume(f1.float(), f2.float(), 4)
+    from ocflow_amd import _lib
+    import ctypes as C
+    a = f1.to(DEV).contiguous(memory_format=torch.channels_last)
+    b = f2.to(DEV).contiguous(memory_format=torch.channels_last)
+    buf = torch.zeros((2, 81 + 32 + 4, 16, 48), device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dst = buf[:, 0:81]
+    T4 = lambda t: C.byref(_lib.Tensor4(t.data_ptr(), *t.stride()))
+    st = _lib.load().ocf_corr_fwd(T4(a), T4(b), None, None, T4(dst), 2, 32, 16, 48, 4, 1.0, 0, _lib.OCF_BF16,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    torch.cuda.synchronize()
+    close(buf[:, 0:81], ref, 2e-2)
+    assert float(buf[:, 81:].abs().max()) == 0.0  # neighbours in the buffer untouched
+
+
 def test_corr_occ_only(ops):
     """flow_occ_net.py:167-168:  warped2 *= occ ; corr(feat1, warped2)  with warped2 already materialised"""
     gen = torch.Generator().manual_seed(6)
