@@ -159,6 +159,26 @@ def test_corr_bf16_output_into_concat_buffer(ops):
     assert float(buf[:, 81:].abs().max()) == 0.0  # neighbours in the buffer untouched
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 21, 45), (1, 64, 12, 40), (1, 128, 14, 32), (1, 196, 7, 16)])
+@pytest.mark.parametrize("cl", [True, False])
+def test_corr_backward_bf16(ops, shape, cl):
+    """bf16 backward (LDS-tiled kernels on channels_last, gather fallback otherwise) vs fp32 autograd of the oracle on the same
+    bf16-rounded inputs; gradients are written in bf16 => 2e-2 of the gradient scale."""
+    gen = torch.Generator().manual_seed(31)
+    f1 = torch.randn(shape, generator=gen).bfloat16()
+    f2 = torch.randn(shape, generator=gen).bfloat16()
+    cot = torch.randn((shape[0], 81, shape[2], shape[3]), generator=gen).bfloat16()
+    a, b = f1.float().requires_grad_(), f2.float().requires_grad_()
+    g1r, g2r = torch.autograd.grad(O.compute_cost_volume(a, b, 4), (a, b), cot.float())
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    x = f1.to(DEV).contiguous(memory_format=fmt).requires_grad_()
+    y = f2.to(DEV).contiguous(memory_format=fmt).requires_grad_()
+    g1, g2 = torch.autograd.grad(ops.compute_cost_volume(x, y, 4), (x, y), cot.to(DEV).contiguous(memory_format=fmt))
+    for got, want in ((g1, g1r), (g2, g2r)):
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=2e-2, atol=2e-2 * scale)
+
+
 def test_corr_occ_only(ops):
     """flow_occ_net.py:167-168:  warped2 *= occ ; corr(feat1, warped2)  with warped2 already materialised"""
     gen = torch.Generator().manual_seed(6)
