@@ -129,6 +129,13 @@ int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, int B, int 
  * replaces: torch.var_mean(dim=(1,2,3)) in models/networks/correlation_layer.py:59-64 */
 int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int H, int W, int dtype, void* stream);
 
+/* ---- SSIM metric (first "next" row) --------------------------------------------
+ * Gaussian window (sigma 1.5) of `window_size` <= 16 taps, zero padding window_size/2 (even windows give an (H+1)x(W+1) map),
+ * C1 = 0.01^2, C2 = 0.03^2.  sums[b] = sum over (C, Ho, Wo) of the SSIM map of sample b (fp64).  img1/img2 fp32.
+ * replaces: ssim / _ssim  inpainting_metrics/ssim/ssim.py:17-75 (5 depthwise F.conv2d + elementwise chain) */
+int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W, int window_size,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,7 @@ SIGNATURES = {
     "ocf_smooth_loss_bwd": [_T4P, _T4P, _vp, _T4P, _i, _i, _i, _i, _f, _vp],
     "ocf_range_map": [_T4P, _vp, _vp, _i, _i, _i, _vp],
     "ocf_moments": [_T4P, _vp, _i, _i, _i, _i, _i, _vp],
+    "ocf_ssim_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
 }
 
 _lock = threading.Lock()

@@ -4,6 +4,7 @@
 // planes), wave-shuffle + LDS block reduction, one fp64 atomic per block and sum.
 // reference: models/model.py:27-46 (photometric), :53-66,93-114 (smoothness), :223-305,391 (range map),
 //            models/networks/correlation_layer.py:59-64 (moments)
+#include <math.h>
 #include "ocf_common.h"
 
 namespace ocf {
@@ -293,6 +294,48 @@ __global__ __launch_bounds__(LB) void moments_kernel(T4 f, double* sums, int C, 
   block_reduce_atomic<2>(acc, sums + 2 * b);
 }
 
+// ------------------------------------------------------------------------------------------- SSIM
+// One thread per output pixel of one (sample, channel) plane; the five windowed moments are accumulated in one sweep over
+// the window (zero padding), then the SSIM quotient; block reduce -> one fp64 atomic per block and sample.
+struct SsimWin { float w[16]; };
+
+__global__ __launch_bounds__(LB) void ssim_fwd_kernel(T4 a, T4 b, double* sums, int C, int H, int W, int Ho, int Wo, int ws, int pad,
+                                                      SsimWin win) {
+  const int bi = blockIdx.y;
+  const long per = (long)C * Ho * Wo;
+  double acc[1] = {0.0};
+  const float* pa = (const float*)a.p + (long)bi * a.sb;
+  const float* pb = (const float*)b.p + (long)bi * b.sb;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (long)gridDim.x * blockDim.x) {
+    const int xo = idx % Wo;
+    long r = idx / Wo;
+    const int yo = r % Ho, c = r / Ho;
+    float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    for (int i = 0; i < ws; i++) {
+      const int y = yo - pad + i;
+      if (y < 0 || y >= H) continue;
+      const float wy = win.w[i];
+      for (int j = 0; j < ws; j++) {
+        const int x = xo - pad + j;
+        if (x < 0 || x >= W) continue;
+        const float w = wy * win.w[j];
+        const float va = pa[(long)c * a.sc + (long)y * a.sh + (long)x * a.sw];
+        const float vb = pb[(long)c * b.sc + (long)y * b.sh + (long)x * b.sw];
+        m1 = __builtin_fmaf(w, va, m1);
+        m2 = __builtin_fmaf(w, vb, m2);
+        s11 = __builtin_fmaf(w, va * va, s11);
+        s22 = __builtin_fmaf(w, vb * vb, s22);
+        s12 = __builtin_fmaf(w, va * vb, s12);
+      }
+    }
+    const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+    const float v11 = s11 - m1 * m1, v22 = s22 - m2 * m2, v12 = s12 - m1 * m2;
+    const float q = ((2.f * m1 * m2 + c1) * (2.f * v12 + c2)) / ((m1 * m1 + m2 * m2 + c1) * (v11 + v22 + c2));
+    acc[0] += (double)q;
+  }
+  block_reduce_atomic<1>(acc, sums + bi);
+}
+
 static inline int rgrid(long n) {
   long blocks = (n + LB - 1) / LB;
   return (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
@@ -363,6 +406,25 @@ extern "C" int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, 
   if (hipMemsetAsync(range, 0, npix * sizeof(float), st) != hipSuccess) return OCF_ELAUNCH;
   hipLaunchKernelGGL(range_splat_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, mk(flow), range, B, H, W, npix);
   if (occ) hipLaunchKernelGGL(occ_from_range_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, (const float*)range, occ, npix);
+  return launch_status();
+}
+
+extern "C" int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W,
+                            int window_size, void* stream) {
+  ocf::clear_stale_error();
+  if (!img1 || !img2 || !sums || !img1->data || !img2->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || window_size < 1) return OCF_EINVAL;
+  if (window_size > 16) return OCF_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, (size_t)B * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
+  SsimWin win;
+  double tot = 0.0, g[16];
+  for (int i = 0; i < window_size; i++) { const double d = i - window_size / 2; g[i] = exp(-(d * d) / (2.0 * 1.5 * 1.5)); tot += g[i]; }
+  for (int i = 0; i < 16; i++) win.w[i] = i < window_size ? (float)(g[i] / tot) : 0.f;
+  const int pad = window_size / 2, Ho = H + 2 * pad - window_size + 1, Wo = W + 2 * pad - window_size + 1;
+  const long per = (long)C * Ho * Wo;
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3((unsigned)rgrid(per), (unsigned)B), dim3(LB), 0, st, mk(img1), mk(img2), sums, C, H, W, Ho, Wo,
+                     window_size, pad, win);
   return launch_status();
 }
 

@@ -23,7 +23,7 @@ from . import _lib
 __all__ = [
     "compute_cost_volume", "corr_warp", "warp", "normalize_features", "robust_l1", "photometric_error",
     "warp_photometric_error", "gradient", "first_order_smoothness_loss", "second_order_smoothness_loss",
-    "smoothness_losses", "compute_range_map", "occlusion_from_flow",
+    "smoothness_losses", "compute_range_map", "occlusion_from_flow", "ssim",
 ]
 
 MAX_DISPLACEMENT = 4
@@ -470,3 +470,27 @@ def compute_range_map(flow):
 def occlusion_from_flow(flow):
     """occ = 1 - clamp(range_map(flow), 0, 1)  (models/model.py:388-391) in the same launch sequence."""
     return _range_map(flow, True)[1]
+
+
+# -------------------------------------------------------------------------------------------------- SSIM
+def ssim(img1, img2, window_size=11, size_average=True):
+    """Drop-in for inpainting_metrics/ssim/ssim.py:65-75 (metric only: evaluated under no_grad by calculate_ssim,
+    inpainting_metrics/__init__.py:10-25; no gradient is implemented).  One kernel instead of five depthwise convolutions
+    and an elementwise chain.  Returns the mean SSIM, or the per-sample means when size_average is False."""
+    _check4(img1, "img1")
+    _check4(img2, "img2")
+    if img1.shape != img2.shape:
+        raise ValueError("ssim: image shapes differ")
+    ws = int(window_size)
+    if ws < 1 or ws > 16:
+        raise ValueError(f"ssim: window_size must be in [1, 16] for the MI355X kernel, got {ws}")
+    _require_hip(img1, img2)
+    a, b = _f32(img1.detach()), _f32(img2.detach())
+    B, C_, H, W = a.shape
+    sums = torch.empty(B, device=a.device, dtype=torch.float64)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().ocf_ssim_fwd(_t4(a), _t4(b), C.c_void_p(sums.data_ptr()), B, C_, H, W, ws, _stream(a)), "ocf_ssim_fwd")
+    pad = ws // 2
+    n = C_ * (H + 2 * pad - ws + 1) * (W + 2 * pad - ws + 1)
+    per_sample = (sums / n).float()
+    return per_sample.mean() if size_average else per_sample

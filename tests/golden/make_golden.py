@@ -316,14 +316,45 @@ def gold_epe():
     e0 = ref_flow_utils.flow_error(tu.copy(), tv.copy(), u.copy(), v.copy())
     # the occ path indexes the EPE map with a flattened mask (flow_utils.py:227-230) => 1-D inputs
     e1 = ref_flow_utils.flow_error(tu.reshape(-1).copy(), tv.reshape(-1).copy(), u.reshape(-1).copy(), v.reshape(-1).copy(), occ)
-    save("epe", tu=tu, tv=tv, u=u, v=v, occ=occ, epe=np.float64(e0), epe_occ=np.float64(e1))
+    # .flo wire format written by the reference's save_flow, read back by its read_flow (flow_utils.py:10-68)
+    import tempfile
+    flo = (rs.randn(7, 11, 2) * 4).astype(np.float32)
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, "x.flo")
+        ref_flow_utils.save_flow(fn, flo)
+        raw = np.frombuffer(open(fn, "rb").read(), dtype=np.uint8)
+        back = ref_flow_utils.read_flow(fn)
+    save("epe", tu=tu, tv=tv, u=u, v=v, occ=occ, epe=np.float64(e0), epe_occ=np.float64(e1), flo=flo, flo_bytes=raw, flo_read=back)
+
+
+# ------------------------------------------------------------- 9. SSIM metric
+def gold_ssim():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_ssim", os.path.join(REF, "inpainting_metrics", "ssim", "ssim.py"))
+    ref_ssim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_ssim)  # the package __init__ pulls FID/Inception; the file itself needs torch only
+    a = torch.rand((2, 3, 16, 20), generator=g(91)) * 2 - 1
+    b = (a + 0.2 * torch.randn(a.shape, generator=g(92))).clamp(-1, 1)
+    arrs = dict(a=a, b=b)
+    for ws in (4, 11):  # 4 = what calculate_ssim uses (inpainting_metrics/__init__.py:23): even window => (H+1)x(W+1) map
+        arrs[f"ssim_ws{ws}_mean"] = ref_ssim.ssim(a, b, window_size=ws, size_average=True)
+        arrs[f"ssim_ws{ws}_per_sample"] = ref_ssim.ssim(a, b, window_size=ws, size_average=False)
+    arrs["ssim_identical"] = ref_ssim.ssim(a, a, window_size=11)
+    save("ssim", **arrs)
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ssim":
+        gold_ssim()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "epe":
+        gold_epe()
+        sys.exit(0)
     gold_corr()
     gold_norm()
     gold_warp()
     gold_losses()
     gold_range()
     gold_epe()
+    gold_ssim()
     gold_nets()

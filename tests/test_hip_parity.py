@@ -319,3 +319,19 @@ def test_full_size_properties(ops):
     close(cvb, ops.compute_cost_volume(f1.bfloat16().float(), f2.bfloat16().float()), 2e-2)
     # NCHW and channels_last agree bit for bit on the same data (same arithmetic order)
     assert torch.equal(ops.compute_cost_volume(f1.contiguous(), f2.contiguous()), cv.contiguous())
+
+
+# --------------------------------------------------------------------------------------------------- SSIM
+def test_ssim_golden(ops, golden):
+    g = golden("ssim")
+    a, b = dev(g["a"]), dev(g["b"])
+    for ws in (4, 11):
+        close(ops.ssim(a, b, ws, True), g[f"ssim_ws{ws}_mean"], 1e-5)
+        close(ops.ssim(a, b, ws, False), g[f"ssim_ws{ws}_per_sample"], 1e-5)
+    close(ops.ssim(a, a, 11), np.float32(1.0), 1e-6)
+    # views of the [B,6,H,W] batch and a Sintel-sized frame against the oracle
+    gen = torch.Generator().manual_seed(4)
+    imgs = torch.rand((1, 6, 109, 256), generator=gen) * 2 - 1
+    close(ops.ssim(imgs.to(DEV)[:, :3], imgs.to(DEV)[:, 3:], 11), O.ssim(imgs[:, :3], imgs[:, 3:], 11), 1e-5)
+    with pytest.raises(ValueError):
+        ops.ssim(a, b, 17)
