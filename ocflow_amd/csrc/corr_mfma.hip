@@ -30,11 +30,11 @@
 namespace ocf {
 
 namespace mf {
-constexpr int TW = 32, TH = 4, NUM = 4;     // tile, units (of 8 bf16) per 32-channel block
+constexpr int TW = 32, NUM = 4;             // tile width, units (of 8 bf16) per 32-channel block; tile height TH is a template parameter
 constexpr int ROWPX = 40;                   // halo row pitch in pixels (32 + 2*4); fragment reads of the 3rd tile may run
 constexpr int SLACK_PX = 8;                 // 8 px past the last row: harmless, those MFMA columns are never used
 
-template <int D> struct G {
+template <int D, int TH> struct G {
   static constexpr int N = 2 * D + 1, NK = N * N;
   static constexpr int HH = TH + 2 * D;
   static constexpr int F2_SLOTS = (HH * ROWPX + SLACK_PX) * NUM;
@@ -68,17 +68,17 @@ enum { MOUT_GENERIC = 0, MOUT_CL_VEC = 1 };
 // The kernel is PERSISTENT: gridDim.x <= 2 workgroups per CU, each walks tiles of one XCD's contiguous tile range; the
 // global loads of the next tile (or channel block) are issued before the MFMAs of the current one, and the 16-byte output
 // stores of a tile drain while the next one is staged.
-template <int VEC, int MODE, int D, bool MULTI>
-__global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H,
+template <int VEC, int MODE, int D, bool MULTI, int TH>
+__global__ __launch_bounds__(64 * (2 * D + 1), (MULTI || TH > 4) ? 3 : 5) void corr_fwd_mfma(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H,
                                                                  int W, float fs, WarpGeom wg, int tiles_x, int tiles_y,
                                                                  int out_mode) {
   using namespace mf;
-  using GG = G<D>;
+  using GG = G<D, TH>;
   typedef bf16 T;
   constexpr int U = 8, ES = 2;
   typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
   constexpr int OCC_W = 48;  // halo occlusion tile pitch (floats)
-  extern __shared__ u32x4 smem[];  // lds_bytes<D>(MODE) dynamic bytes (> 64 KiB static limit at d=4)
+  extern __shared__ u32x4 smem[];  // lds_bytes<D, TH>(MODE) dynamic bytes
   u32x4* s_f2 = smem;
   u32x4* s_f1 = smem + GG::F2_SLOTS;
   unsigned short* s_out = (unsigned short*)(smem + GG::F2_SLOTS + GG::F1_SLOTS);
@@ -95,7 +95,9 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
   const int per_xcd = (ntiles + 7) >> 3;
   const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, slots = gridDim.x >> 3;
 
-  constexpr bool PF = false && MULTI;  // register prefetch of the next block/tile; SINGLE relies on 2 co-resident workgroups instead
+  // register prefetch of the next TILE in the single-block variant (1 workgroup per CU, 137-160 VGPRs, no spills); the multi-block
+  // variant would spill with 32 more live registers beside its 64 accumulators (measured: 25 -> 15 us at level 3 without it)
+  constexpr bool PF = !MULTI;
   const int ncb = MULTI ? (C + 31) / 32 : 1;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int f1sh = (int)f1.sh, f1sw = (int)f1.sw, f2sh = (int)f2.sh, f2sw = (int)f2.sw;
@@ -372,8 +374,8 @@ __global__ __launch_bounds__(64 * (2 * D + 1), MULTI ? 3 : 5) void corr_fwd_mfma
   }
 }
 
-template <int D> static size_t lds_bytes(int mode) {
-  using GG = mf::G<D>;
+template <int D, int TH> static size_t lds_bytes(int mode) {
+  using GG = mf::G<D, TH>;
   return (size_t)(GG::F2_SLOTS + GG::F1_SLOTS) * 16 + ((GG::OUT_ELEMS * 2 + 15) / 16) * 16 + (mode >= 1 ? GG::HH * 48 * 4 : 0);
 }
 
@@ -390,40 +392,40 @@ static int num_cus() {
   return n;
 }
 
-template <int VEC, int MODE, int D>
-static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
-                       float fs, int ac, int out_mode, hipStream_t st) {
-  const int tx = (W + mf::TW - 1) / mf::TW, ty = (H + mf::TH - 1) / mf::TH;
+// tile height: 8 rows for the single-block (C <= 32) variant -- half the tiles, 2/3 of the halo rows per pixel, one workgroup
+// per CU (116 KB LDS); 4 rows for the multi-block variant (64 accumulator registers per lane instead of 128)
+constexpr int TH_SINGLE = 8, TH_MULTI = 4;
+
+template <int VEC, int MODE, int D, bool MULTI>
+static int launch_mfma_th(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
+                          float fs, int ac, int out_mode, hipStream_t st) {
+  constexpr int TH = MULTI ? TH_MULTI : TH_SINGLE;
+  const int tx = (W + mf::TW - 1) / mf::TW, ty = (H + TH - 1) / TH;
   const WarpGeom wg(H, W, ac);
   // persistent grid: a multiple of 8 (XCD-affine schedule), as many workgroups as are co-resident (queried once per variant)
   const int ntiles = B * tx * ty;
   const dim3 block(64 * (2 * D + 1));
-  const size_t lds = lds_bytes<D>(MODE);
-  static int occ_multi = 0, occ_single = 0;
-  int& occ_blocks = (C > 32) ? occ_multi : occ_single;
+  const size_t lds = lds_bytes<D, TH>(MODE);
+  static int occ_blocks = 0;
   if (occ_blocks == 0) {
     int nb = 0;
-    hipError_t e;
-    if (C > 32) {
-      (void)hipFuncSetAttribute((const void*)corr_fwd_mfma<VEC, MODE, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, true>, (int)block.x, lds);
-    } else {
-      (void)hipFuncSetAttribute((const void*)corr_fwd_mfma<VEC, MODE, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, false>, (int)block.x, lds);
-    }
+    (void)hipFuncSetAttribute((const void*)corr_fwd_mfma<VEC, MODE, D, MULTI, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_mfma<VEC, MODE, D, MULTI, TH>, (int)block.x, lds);
     occ_blocks = (e == hipSuccess && nb >= 1) ? (nb > 2 ? 2 : nb) : 1;
   }
   int g = ((ntiles + 7) / 8) * 8;
   const int cap = occ_blocks * num_cus();
   if (g > cap) g = cap;
-  const dim3 grid((unsigned)g);
-  if (C > 32)
-    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, true>), grid, block, lds, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
-                       out_mode);
-  else
-    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, false>), grid, block, lds, st, f1, f2, flow, occ, out, B, C, H, W, fs, wg, tx, ty,
-                       out_mode);
+  hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, MULTI, TH>), dim3((unsigned)g), block, lds, st, f1, f2, flow, occ, out, B, C, H, W, fs,
+                     wg, tx, ty, out_mode);
   return launch_status();
+}
+
+template <int VEC, int MODE, int D>
+static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
+                       float fs, int ac, int out_mode, hipStream_t st) {
+  return C > 32 ? launch_mfma_th<VEC, MODE, D, true>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st)
+                : launch_mfma_th<VEC, MODE, D, false>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
 }
 
 template <int VEC, int MODE>
