@@ -24,6 +24,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # before the HIP runtime starts; see ocflow_amd/__init__.py
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -50,6 +51,9 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--layout", default="cl", choices=["cl", "nchw"])
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables it)")
+    p.add_argument("--fused-adam", type=int, default=1,
+                   help="1 (default): run the module's Adam (models/flow_occ_model.py:77-78) through torch's fused multi-tensor "
+                        "kernel -- same update rule, checked in tests/test_models_gpu.py::test_fused_adam_same_update; 0: foreach")
     p.add_argument("--graph", type=int, default=-1,
                    help="1: capture the whole training step (forward+loss+backward+Adam) in a hipGraph and replay it; 0: eager; "
                         "-1 (default): graph on one GPU (falls back to eager if capture fails), eager under DDP.  Same kernels "
@@ -72,7 +76,8 @@ def build_stepper(args, env):
     from ocflow_amd.runtime import TrainStepper
     torch.manual_seed(42)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
-    return TrainStepper(build_module(args), env, amp_dtype=amp, channels_last=(args.layout == "cl"))
+    return TrainStepper(build_module(args), env, amp_dtype=amp, channels_last=(args.layout == "cl"),
+                        fused_optimizer=bool(getattr(args, "fused_adam", 0)))
 
 
 def usable_cores() -> int:
@@ -212,6 +217,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     loss_val = float(loss)
+    # a throughput number is only worth reporting if the steps it timed were real training steps: finite loss, sane gradients
+    gmax = max(float(p.grad.detach().abs().max()) for p in stepper.raw.parameters() if p.grad is not None)
+    if not (loss_val == loss_val and abs(loss_val) < 1e6 and gmax == gmax and gmax < 1e4):
+        raise SystemExit(f"[bench] INVALID RUN: loss {loss_val} / max|grad| {gmax} after the timed steps")
     if use_graph:
         # roofline leg: the SAME step, eager, right after the timed replays (identical kernels and shapes), with the
         # correlation launches bracketed by HIP events on the launch stream
@@ -261,7 +270,8 @@ def main():
                                    f"shape; per-rank share of configs[4])",
                        "global_batch": B * n, "height": args.height, "width": args.width, "layout": args.layout,
                        "parallelism": f"dp{n}", "launch": "hipGraph replay of the whole step" if use_graph else "eager",
-                       "final_loss": round(loss_val, 5)},
+                       "final_loss": round(loss_val, 5),
+                       "optimizer": "adam(fused)" if args.fused_adam else "adam(foreach)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

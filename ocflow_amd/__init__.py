@@ -7,3 +7,13 @@ range-map losses) as hand-written HIP kernels behind the reference's own operato
     ocflow_amd.models.model            FlowStageModel + loss functions (reference: models/model.py)
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# ROCm 7.x hipGraph replays take a "packet capture" fast path (pre-baked AQL packets) by default.  On the ~2000-node graph of
+# one OCFlow training step that path replays with stale zero-fills (reduction semaphores / split-K workspaces keep their
+# previous contents) as soon as the host synchronises between two replays: gradients fill with garbage within 2-3 replays
+# (scripts/long_run.py --every 1 reproduces it; DESIGN.md "hipGraph").  The regular enqueue path is correct and just as fast
+# (measured 421 vs 426 pairs/s).  The flag is read when the HIP runtime initialises, so it is set at import, before any HIP
+# call; runtime.TrainStepper.enable_graph refuses to capture when it is not in effect.
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")

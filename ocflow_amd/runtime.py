@@ -160,7 +160,7 @@ class TrainStepper:
     under bf16 autocast when `amp_dtype` is given (convs on MFMA via MIOpen, HIP ops bf16-in / fp32-accumulate)."""
 
     def __init__(self, module: torch.nn.Module, env: DistEnv, amp_dtype: Optional[torch.dtype] = torch.bfloat16,
-                 channels_last: bool = True):
+                 channels_last: bool = True, fused_optimizer: bool = False):
         self.env = env
         self.amp_dtype = amp_dtype if env.device.type == "cuda" else None
         self.channels_last = channels_last
@@ -169,6 +169,11 @@ class TrainStepper:
             module = module.to(memory_format=torch.channels_last)
         self.raw = module
         self.optimizer = module.configure_optimizers()
+        if fused_optimizer and env.device.type == "cuda":
+            # same Adam update (models/flow_model.py:105-106 returns a plain Adam), one multi-tensor kernel instead of the
+            # per-tensor fallback torch's foreach path takes when parameter / gradient strides differ
+            for g in self.optimizer.param_groups:
+                g["fused"], g["foreach"] = True, False
         self.module = wrap_ddp(_StepAdapter(module), env)
         self._graph = None
         self._graph_pool = None
@@ -188,7 +193,9 @@ class TrainStepper:
         return self._eager_step(batch, batch_idx)
 
     def _eager_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
-        self.optimizer.zero_grad(set_to_none=self._graph_pool is None)
+        # gradients are dropped, not zero-filled: backward then writes them instead of accumulating (one fill and one add
+        # per parameter saved); inside a graph capture they are re-allocated from the graph's pool, so replays reuse them
+        self.optimizer.zero_grad(set_to_none=not getattr(self, "_static_grads", False))
         ctx = torch.autocast(self.env.device.type, dtype=self.amp_dtype) if self.amp_dtype is not None else nullcontext()
         with ctx:
             loss = self.module(batch, batch_idx)
@@ -205,6 +212,10 @@ class TrainStepper:
             raise RuntimeError("TrainStepper.enable_graph: whole-step graph capture is single-GPU only")
         if self.env.device.type != "cuda":
             raise RuntimeError("TrainStepper.enable_graph needs a HIP device")
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0" and os.environ.get("OCFLOW_UNSAFE_GRAPH", "0") != "1":
+            # OCFLOW_UNSAFE_GRAPH=1 exists only to reproduce the corruption (scripts/long_run.py)
+            raise RuntimeError("TrainStepper.enable_graph: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be set before the HIP runtime "
+                               "initialises (import ocflow_amd first); the packet-capture replay path of ROCm 7 corrupts this graph")
         # Adam must keep its step counter on the device to be capturable
         for g in self.optimizer.param_groups:
             g["capturable"] = True
@@ -221,7 +232,7 @@ class TrainStepper:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=False)
+        self._static_grads = os.environ.get("OCFLOW_GRAPH_STATIC_GRADS", "0") == "1"
         with torch.cuda.graph(graph, pool=self._graph_pool):
             self._static_loss = self._eager_step(self._static_batch, 0)
         self._graph = graph

@@ -4,6 +4,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # before the HIP runtime starts; see ocflow_amd/__init__.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -14,6 +15,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # environment only (no GPU touched): the conv solver db the repo ships, so full-size model tests do not spend a minute in
+    # MIOpen's search on a fresh box
+    from ocflow_amd.runtime import use_repo_miopen_db
+    use_repo_miopen_db()
 
 
 def load_golden(name):

@@ -113,3 +113,96 @@ def test_bf16_autocast_step_runs():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             fbf, _ = m(x)
     assert float((f32 - fbf.float()).abs().mean()) < 0.25 * float(f32.abs().mean()) + 0.05
+
+
+def _stepper(fused, graph, amp=None, batch=None, steps=6):
+    """train `steps` steps of the supervised FlowOccModel step on one fixed batch; returns (losses, parameters)"""
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.runtime import DistEnv, TrainStepper
+    torch.manual_seed(7)
+    env = DistEnv(device=torch.device(DEV))
+    st = TrainStepper(FlowOccModel({"learning_rate": 1e-4, "model": "flowoccnet"}), env, amp_dtype=amp,
+                      channels_last=amp is not None, fused_optimizer=fused)
+    b = st.prepare(batch)
+    losses = [float(st.step(b, 0))]
+    if graph:
+        st.enable_graph(b)
+        b = st._static_batch
+    for i in range(1, steps):
+        losses.append(float(st.step(b, i)))
+    torch.cuda.synchronize()
+    return losses, [p.detach().float().cpu().numpy().copy() for p in st.raw.parameters()]
+
+
+def test_fused_adam_same_update():
+    """TrainStepper(fused_optimizer=True) keeps the reference's optimiser (Adam(params, lr), models/flow_occ_model.py:77-78):
+    fed the SAME gradients, torch's fused multi-tensor kernel and the default foreach path produce the same parameters"""
+    import copy
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.runtime import DistEnv, TrainStepper, synthetic_batch
+    torch.manual_seed(7)
+    env = DistEnv(device=torch.device(DEV))
+    a = TrainStepper(FlowOccModel({"learning_rate": 1e-4, "model": "flowoccnet"}), env, amp_dtype=None, channels_last=False)
+    b = TrainStepper(copy.deepcopy(a.raw), env, amp_dtype=None, channels_last=False, fused_optimizer=True)
+    batch = a.prepare(synthetic_batch(2, 128, 192, torch.device(DEV), seed=3))
+    for it in range(3):
+        a.optimizer.zero_grad(set_to_none=True)
+        a.raw.training_step(batch, it).backward()
+        for pa, pb in zip(a.raw.parameters(), b.raw.parameters()):
+            pb.grad = None if pa.grad is None else pa.grad.clone()
+        a.optimizer.step(); b.optimizer.step()
+    for (n, pa), pb in zip(a.raw.named_parameters(), b.raw.parameters()):
+        np.testing.assert_allclose(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), rtol=1e-5, atol=2e-7, err_msg=n)
+
+
+def test_graph_replay_tracks_eager():
+    """whole-step hipGraph replay runs the same step as the eager loop.  Adam's first updates are ~lr*sign(g), so the float
+    atomics' low-bit noise in near-zero gradients makes two EAGER runs drift apart by ~1 % within a few steps too: the bar is
+    the identical first (pre-capture) loss, then the same trajectory within 3 % and a decreasing loss"""
+    from ocflow_amd.runtime import synthetic_batch
+    batch = synthetic_batch(2, 128, 192, torch.device(DEV), seed=3)
+    ref_l, _ = _stepper(fused=False, graph=False, batch=batch, steps=12)
+    for fused in (False, True):
+        l, p = _stepper(fused=fused, graph=True, batch=batch, steps=8)
+        assert abs(l[0] - ref_l[0]) <= 1e-5 * abs(ref_l[0]), (l[0], ref_l[0])
+        # enable_graph takes 3 untimed eager steps before the capture: replay k is training step k + 3
+        np.testing.assert_allclose(l[1:], ref_l[4:11], rtol=3e-2, err_msg=f"fused={fused}")
+        assert l[-1] < l[0] and all(np.isfinite(a).all() for a in p)
+
+
+def test_bf16_graph_step_finite():
+    """the benchmark configuration (bf16 autocast, channels_last, fused Adam, hipGraph replay) trains: finite, decreasing loss"""
+    from ocflow_amd.runtime import synthetic_batch
+    batch = synthetic_batch(2, 128, 192, torch.device(DEV), seed=3)
+    l, p = _stepper(fused=True, graph=True, amp=torch.bfloat16, batch=batch, steps=30)
+    assert all(np.isfinite(l)), l
+    assert all(np.isfinite(a).all() for a in p)
+    assert np.mean(l[-5:]) < np.mean(l[:5]), l
+
+
+def test_graph_replay_full_size_is_clean(monkeypatch):
+    """the benchmark step at the benchmark shape (8 x 436x1024, bf16, fused Adam) replayed from its hipGraph WITH a host sync and
+    a gradient read-back between replays.  This is the pattern that exposed ROCm's packet-capture replay path (stale zero-fills
+    -> garbage gradients within 3 replays, see ocflow_amd/__init__.py): every replay must leave finite, sanely scaled
+    gradients and a loss that follows the eager trajectory."""
+    import torch.nn.functional as F
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.runtime import DistEnv, TrainStepper, synthetic_batch
+
+    def soft_bce(x, t, *a, **k):  # F.binary_cross_entropy minus its device-side assert, which would take the process down
+        x = x.clamp(1e-30, 1 - 6e-8)
+        return -(t * torch.log(x) + (1 - t) * torch.log1p(-x)).mean()
+    monkeypatch.setattr(F, "binary_cross_entropy", soft_bce)
+    torch.manual_seed(42)
+    env = DistEnv(device=torch.device(DEV))
+    st = TrainStepper(FlowOccModel({"learning_rate": 1e-4, "model": "flowoccnet"}), env, amp_dtype=torch.bfloat16,
+                      channels_last=True, fused_optimizer=True)
+    batch = st.prepare(synthetic_batch(8, 436, 1024, env.device, seed=42))
+    first = float(st.step(batch, 0))
+    st.enable_graph(batch)
+    losses = []
+    for i in range(12):
+        losses.append(float(st.step(st._static_batch, i)))  # float() synchronises
+        gmax = max(float(p.grad.abs().max()) for p in st.raw.parameters() if p.grad is not None)
+        assert np.isfinite(losses[-1]) and np.isfinite(gmax) and gmax < 1e3, (i, losses, gmax)
+    assert max(losses) < first * 1.05 and losses[-1] < first, (first, losses)
