@@ -66,16 +66,19 @@ def init_distributed(force_cpu: bool = False) -> DistEnv:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_gpu = torch.cuda.is_available() and not force_cpu
-    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    # OCFLOW_DIST_REHEARSAL=1: rehearse the multi-rank launch path on a ONE-GPU box -- every rank uses cuda:0 and the process
+    # group is gloo (RCCL refuses two ranks on one device).  Exercises everything of an N-rank run except RCCL itself.
+    rehearsal = use_gpu and os.environ.get("OCFLOW_DIST_REHEARSAL", "0") == "1"
+    device = torch.device("cuda", 0 if rehearsal else local_rank) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
     backend = None
     if world > 1:
-        backend = "nccl" if use_gpu else "gloo"
+        backend = "nccl" if use_gpu and not rehearsal else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if not dist.is_initialized():
-            kw = {"device_id": device} if use_gpu else {}
+            kw = {"device_id": device} if backend == "nccl" else {}
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return DistEnv(rank, local_rank, world, device, backend)
 
@@ -87,8 +90,8 @@ def shutdown_distributed():
 
 def barrier(env: DistEnv):
     if env.world_size > 1:
-        if env.device.type == "cuda":
-            dist.barrier(device_ids=[env.local_rank])
+        if env.backend == "nccl":
+            dist.barrier(device_ids=[env.device.index])
         else:
             dist.barrier()
 
@@ -115,10 +118,13 @@ def wrap_ddp(module: torch.nn.Module, env: DistEnv, bucket_cap_mb: int = 32) -> 
     if env.world_size == 1:
         return module
     from torch.nn.parallel import DistributedDataParallel as DDP
+    # static_graph: the reference nets own parameters that never reach the loss (FlowOccNet's finest-level up-convolutions, like
+    # the reference's -- Lightning 1.1 ran them with find_unused_parameters=True); the step's autograd graph is the same every
+    # iteration, so DDP learns the unused set once instead of walking the graph each step.
     if env.device.type == "cuda":
-        return DDP(module, device_ids=[env.local_rank], output_device=env.local_rank, gradient_as_bucket_view=True,
-                   bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
-    return DDP(module, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
+        return DDP(module, device_ids=[env.device.index], output_device=env.device.index, gradient_as_bucket_view=True,
+                   bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False, static_graph=True)
+    return DDP(module, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False, static_graph=True)
 
 
 # ------------------------------------------------------------------------------------------ synthetic data

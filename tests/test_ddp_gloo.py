@@ -56,6 +56,44 @@ def _worker(rank, world, port, out_dir):
     shutdown_distributed()
 
 
+def _worker_steps(rank, world, port, out_dir):
+    """several consecutive optimisation steps of the HEADLINE model under DDP: FlowOccNet owns parameters that never reach the
+    loss, which DDP only trips over at the second forward ("Expected to have finished reduction in the prior iteration")"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from golden_util import rngfree_fill
+    from oracle.backend import patch_ops
+    patch_ops(None)
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.runtime import TrainStepper, init_distributed, shard_range, shutdown_distributed
+    env = init_distributed(force_cpu=True)
+    model = rngfree_fill(FlowOccModel({"model": "flowoccnet", "learning_rate": 1e-4}))
+    stepper = TrainStepper(model, env, amp_dtype=None, channels_last=False)
+    full = _make_batch(2 * world)
+    lo, hi = shard_range(2 * world, env)
+    batch = stepper.prepare(tuple(t[lo:hi] for t in full))
+    losses = [float(stepper.step(batch, i)) for i in range(3)]
+    unused = [k for k, p in model.named_parameters() if p.grad is None]
+    torch.save({"losses": losses, "unused": unused, "params": {k: p.detach().clone() for k, p in model.named_parameters()}},
+               os.path.join(out_dir, f"steps_rank{rank}.pt"))
+    shutdown_distributed()
+
+
+@pytest.mark.timeout(900)
+def test_ddp_world2_consecutive_steps_headline_model(tmp_path):
+    world = 2
+    mp.start_processes(_worker_steps, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "steps_rank0.pt")
+    r1 = torch.load(tmp_path / "steps_rank1.pt")
+    assert all(torch.isfinite(torch.tensor(r["losses"])).all() for r in (r0, r1))
+    assert r0["unused"] == r1["unused"]
+    # replicas stay in lock-step: same parameters on both ranks after three averaged-gradient Adam updates
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+
+
 @pytest.mark.timeout(600)
 def test_ddp_world2_matches_single_process(tmp_path, monkeypatch):
     world = 2
