@@ -56,20 +56,32 @@ def _compile(src: str, extra) -> str:
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    import fcntl
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     stamp_file = os.path.join(OBJ_DIR, "stamp")
     stamp = _stamp() + " " + " ".join(extra_flags)
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+
+    def fresh():
+        return os.path.exists(LIB_PATH) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp
+
+    if not force and fresh():
         return LIB_PATH
-    with cf.ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(lambda s: _compile(s, list(extra_flags)), _sources()))
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH, *objs]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    with open(stamp_file, "w") as f:
-        f.write(stamp)
+    # one builder at a time: the ranks of a multi-GPU launch all import the package at once
+    with open(os.path.join(OBJ_DIR, "lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():  # another rank built it while this one waited
+            return LIB_PATH
+        with cf.ThreadPoolExecutor(max_workers=4) as ex:
+            objs = list(ex.map(lambda s: _compile(s, list(extra_flags)), _sources()))
+        tmp = LIB_PATH + f".tmp{os.getpid()}"
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, LIB_PATH)
+        with open(stamp_file, "w") as f:
+            f.write(stamp)
     if verbose:
         print("built", LIB_PATH)
     return LIB_PATH

@@ -111,10 +111,12 @@ def shard_range(global_batch: int, env: DistEnv) -> Tuple[int, int]:
     return lo, lo + per + (1 if env.rank < rem else 0)
 
 
-def wrap_ddp(module: torch.nn.Module, env: DistEnv, bucket_cap_mb: int = 32) -> torch.nn.Module:
-    """DistributedDataParallel with bucket views: gradients are all-reduced (averaged) in ~32 MB buckets while the
-    rest of backward is still running.  The whole FlowOccNet gradient is 27.6 MB fp32 => one or two RCCL all-reduces per
-    step; ring over xGMI moves 2(N-1)/N * S per GPU."""
+def wrap_ddp(module: torch.nn.Module, env: DistEnv, bucket_cap_mb: int = 8) -> torch.nn.Module:
+    """DistributedDataParallel with bucket views: gradients are all-reduced (averaged) in ~8 MB buckets while the rest of
+    backward is still running.  The whole FlowOccNet gradient is 27.6 MB fp32: one 32 MB bucket would only start its
+    all-reduce when backward has finished (nothing left to overlap with); four 8 MB buckets put all but the last behind the
+    remaining ~6 ms of backward, and at 8 MB an xGMI ring step (2(N-1)/N * S per GPU over 7 point-to-point links) is still far
+    above the ~30 us launch latency of a collective."""
     if env.world_size == 1:
         return module
     from torch.nn.parallel import DistributedDataParallel as DDP
