@@ -136,6 +136,18 @@ int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int H, int W, 
 int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W, int window_size,
                  void* stream);
 
+/* ---- convolution epilogue of the estimator nets (second "next" row: the callers either side of the correlation) ----------
+ * forward, IN PLACE on x (the bias-free convolution output):   t = T(x + T(bias[c]));  y = t > 0 ? t : T(t * negative_slope)
+ * backward:  gx = y > 0 ? gy : T(gy * negative_slope);  gbias[c] = sum over (B,H,W) of gx   (fp32, zeroed by the launcher)
+ * x / y / gy / gx: dense channels_last or dense NCHW tensors of type `dtype` (anything else: OCF_EUNSUPPORTED); bias, gbias fp32 [C].
+ * replaces: nn.Sequential(nn.Conv2d(bias=True), nn.LeakyReLU(0.1)) epilogues -- conv() of cost_volume_flow_net.py:19-21,
+ *           cost_volume_flow_occ_net.py, flow_net.py, flow_occ_net.py, context_net.py, simple_flow_net.py:55-57
+ *           [aten add_(bias) + leaky_relu | leaky_relu_backward + sum((0,2,3)) + casts] */
+int ocf_bias_act_fwd(const ocf_tensor4* x, const float* bias, int B, int C, int H, int W, float negative_slope, int dtype,
+                     void* stream);
+int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, float* gbias, int B, int C, int H, int W,
+                     float negative_slope, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,215 @@
+// Convolution epilogue of the decoder / context / refinement nets: bias add + LeakyReLU in one pass, and its gradient
+// (LeakyReLU backward + per-channel bias-gradient reduction) in one pass.
+//
+// The reference writes  nn.Sequential(nn.Conv2d(..., bias=True), nn.LeakyReLU(0.1))  (cost_volume_flow_net.py:19-21,
+// flow_occ_net.py conv(), simple_flow_net.py:55-57); in PyTorch-ROCm that is conv -> add_(bias) -> leaky_relu forward (three
+// passes over the activation) and leaky_relu_backward -> sum over (N,H,W) -> two dtype casts backward.  ~60 such sites per
+// FlowOccNet step: 0.8 + 0.5 ms forward, 0.7 + 1.2 + 0.7 ms backward of a 19 ms step (profiles/r1_j_torch_op_profile.txt).
+//
+// Arithmetic matches the unfused chain bit for bit in the forward direction:
+//   t = T(x + T(b))         (the bias is rounded to the activation type first, as autocast's cast does; fp32: identity)
+//   y = t > 0 ? t : T(t * slope)
+// backward: gx = y > 0 ? gy : T(gy * slope)   (sign(y) == sign(t) for slope > 0),  gbias[c] = sum_{n,h,w} gx   (fp32 accumulate,
+// returned in fp32: one rounding less than the reference's bf16 sum followed by a cast).
+#include "ocf_common.h"
+
+namespace ocf {
+
+template <typename T> __device__ __forceinline__ float rnd(float v) { return (float)(T)v; }
+
+// U == Unit<T>::U: one 16-byte unit per access; U == 1: one element (channel counts that are not a multiple of the unit)
+template <typename T, int U> __device__ __forceinline__ void ld_u(const T* base, long i, float* f) {
+  if (U == 1) f[0] = (float)base[i];
+  else unit_to_f<T>(((const u32x4*)base)[i], f);
+}
+template <typename T, int U> __device__ __forceinline__ void st_u(T* base, long i, const float* f) {
+  if (U == 1) base[i] = (T)f[0];
+  else ((u32x4*)base)[i] = f_to_unit<T>(f);
+}
+
+// ---- channels_last dense: the tensor is a [R][C] matrix, C % U == 0.  Thread = one 16-byte unit; consecutive threads walk a row.
+template <typename T, int U>
+__global__ void __launch_bounds__(256) bias_act_fwd_cl(T* __restrict__ x, const float* __restrict__ bias, long n_units, int G, float slope) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_units; i += (long)gridDim.x * 256) {
+    const int cg = (int)(i % G);
+    float f[U];
+    ld_u<T, U>(x, i, f);
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const float t = rnd<T>(f[j] + rnd<T>(bias[cg * U + j]));
+      f[j] = t > 0.f ? t : rnd<T>(t * slope);
+    }
+    st_u<T, U>(x, i, f);
+  }
+}
+
+// rows_per_block rows of G units each per pass; thread (r = tid / G, cg = tid % G) keeps U fp32 partial sums of its channel
+// group, reduced over r through LDS at the end, one atomicAdd per channel per block.
+template <typename T, int U>
+__global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx,
+                                                       float* __restrict__ gbias, long R, int G, float slope) {
+  __shared__ float red[256][U + 1];
+  const int rpb = 256 / G;               // rows per pass
+  const int r = threadIdx.x / G, cg = threadIdx.x - r * G;
+  float acc[U];
+#pragma unroll
+  for (int j = 0; j < U; j++) acc[j] = 0.f;
+  if (r < rpb) {
+    for (long row = (long)blockIdx.x * rpb + r; row < R; row += (long)gridDim.x * rpb) {
+      const long i = row * G + cg;
+      float fy[U], fg[U];
+      ld_u<T, U>(y, i, fy);
+      ld_u<T, U>(gy, i, fg);
+#pragma unroll
+      for (int j = 0; j < U; j++) {
+        fg[j] = fy[j] > 0.f ? fg[j] : rnd<T>(fg[j] * slope);
+        acc[j] += fg[j];
+      }
+      st_u<T, U>(gx, i, fg);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < U; j++) red[threadIdx.x][j] = acc[j];
+  __syncthreads();
+  // thread t < G*U sums channel (t / U group, t % U lane) over the rpb row slots
+  for (int t = threadIdx.x; t < G * U; t += 256) {
+    const int g = t / U, j = t - g * U;
+    float s = 0.f;
+    for (int rr = 0; rr < rpb; rr++) s += red[rr * G + g][j];
+    atomicAdd(gbias + t, s);
+  }
+}
+
+// ---- NCHW (stride_w == 1, dense planes): block = a chunk of one (b, c) plane
+template <typename T>
+__global__ void __launch_bounds__(256) bias_act_fwd_nchw(T* __restrict__ x, const float* __restrict__ bias, int C, long HW, int chunks,
+                                                         float slope) {
+  const long plane = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - (int)(plane * chunks);
+  const int c = (int)(plane % C);
+  const float b = rnd<T>(bias[c]);
+  const long per = (HW + chunks - 1) / chunks;
+  const long lo = chunk * per, hi = lo + per < HW ? lo + per : HW;
+  T* p = x + plane * HW;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float t = rnd<T>((float)p[i] + b);
+    p[i] = (T)(t > 0.f ? t : rnd<T>(t * slope));
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bias_act_bwd_nchw(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx,
+                                                         float* __restrict__ gbias, int C, long HW, int chunks, float slope) {
+  const long plane = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - (int)(plane * chunks);
+  const int c = (int)(plane % C);
+  const long per = (HW + chunks - 1) / chunks;
+  const long lo = chunk * per, hi = lo + per < HW ? lo + per : HW;
+  const long base = plane * HW;
+  float acc = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float g = (float)gy[base + i];
+    const float v = (float)y[base + i] > 0.f ? g : rnd<T>(g * slope);
+    gx[base + i] = (T)v;
+    acc += v;
+  }
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(gbias + c, part[0] + part[1] + part[2] + part[3]);
+}
+
+enum { LAYOUT_NONE = 0, LAYOUT_CL = 1, LAYOUT_CL1 = 3, LAYOUT_NCHW = 2 };
+// dense channels_last ([B][H][W][C]; LAYOUT_CL: C a multiple of the 16-byte unit, LAYOUT_CL1: any C <= 256, element
+// accesses) or dense NCHW; anything else is refused: the operand is the fresh output of a convolution, never a view.
+template <typename T>
+static int dense_layout(const T4& t, int B, int C, int H, int W) {
+  constexpr int U = Unit<T>::U;
+  const bool cl = (t.sc == 1 || C == 1) && (t.sw == C || W == 1) && (t.sh == (long)W * C || H == 1) && (t.sb == (long)H * W * C || B == 1);
+  if (cl && C % U == 0 && C / U <= 256 && ((uintptr_t)t.p & 15) == 0) return LAYOUT_CL;
+  if (cl && C <= 256 && C > 1) return LAYOUT_CL1;
+  const bool nchw = (t.sw == 1 || W == 1) && (t.sh == W || H == 1) && (t.sc == (long)H * W || C == 1) && (t.sb == (long)C * H * W || B == 1);
+  if (nchw) return LAYOUT_NCHW;
+  return LAYOUT_NONE;
+}
+
+template <typename T>
+static int bias_act_fwd_t(const T4& x, const float* bias, int B, int C, int H, int W, float slope, hipStream_t st) {
+  constexpr int U = Unit<T>::U;
+  const int lay = dense_layout<T>(x, B, C, H, W);
+  if (lay == LAYOUT_CL) {
+    const long n_units = (long)B * H * W * (C / U);
+    const long want = (n_units + 255) / 256;
+    const int grid = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL((bias_act_fwd_cl<T, U>), dim3(grid), dim3(256), 0, st, (T*)x.p, bias, n_units, C / U, slope);
+  } else if (lay == LAYOUT_CL1) {
+    const long n = (long)B * H * W * C;
+    const long want = (n + 255) / 256;
+    const int grid = (int)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL((bias_act_fwd_cl<T, 1>), dim3(grid), dim3(256), 0, st, (T*)x.p, bias, n, C, slope);
+  } else if (lay == LAYOUT_NCHW) {
+    const long HW = (long)H * W;
+    int chunks = (int)((HW + 4095) / 4096);
+    const long blocks = (long)B * C * chunks;
+    if (blocks > 0x7fffffffL) return OCF_EUNSUPPORTED;
+    hipLaunchKernelGGL(bias_act_fwd_nchw<T>, dim3((unsigned)blocks), dim3(256), 0, st, (T*)x.p, bias, C, HW, chunks, slope);
+  } else {
+    return OCF_EUNSUPPORTED;
+  }
+  return launch_status();
+}
+
+template <typename T>
+static int bias_act_bwd_t(const T4& y, const T4& gy, const T4& gx, float* gbias, int B, int C, int H, int W, float slope, hipStream_t st) {
+  constexpr int U = Unit<T>::U;
+  const int lay = dense_layout<T>(y, B, C, H, W);
+  if (lay == LAYOUT_NONE || dense_layout<T>(gy, B, C, H, W) != lay || dense_layout<T>(gx, B, C, H, W) != lay) return OCF_EUNSUPPORTED;
+  if (hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return OCF_ELAUNCH;
+  if (lay == LAYOUT_CL || lay == LAYOUT_CL1) {
+    const int G = lay == LAYOUT_CL ? C / U : C;
+    const int rpb = 256 / G;
+    const long R = (long)B * H * W;
+    // enough rows per block to amortise the reduction + atomics (>= 64 passes), at most ~8 blocks per CU
+    long want = (R + (long)rpb * 64 - 1) / ((long)rpb * 64);
+    const int grid = (int)(want < 1 ? 1 : (want < 2048 ? want : 2048));
+    if (lay == LAYOUT_CL)
+      hipLaunchKernelGGL((bias_act_bwd_cl<T, U>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
+    else
+      hipLaunchKernelGGL((bias_act_bwd_cl<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
+  } else {
+    const long HW = (long)H * W;
+    int chunks = (int)((HW + 16383) / 16384);
+    const long blocks = (long)B * C * chunks;
+    if (blocks > 0x7fffffffL) return OCF_EUNSUPPORTED;
+    hipLaunchKernelGGL(bias_act_bwd_nchw<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, C, HW,
+                       chunks, slope);
+  }
+  return launch_status();
+}
+
+}  // namespace ocf
+
+using namespace ocf;
+
+extern "C" int ocf_bias_act_fwd(const ocf_tensor4* x, const float* bias, int B, int C, int H, int W, float negative_slope, int dtype,
+                                void* stream) {
+  if (!x || !x->data || !bias || B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  if (dtype != OCF_F32 && dtype != OCF_BF16) return OCF_EINVAL;
+  clear_stale_error();
+  ScopedProfile prof((hipStream_t)stream);
+  const T4 tx = mk(x);
+  return dtype == OCF_F32 ? bias_act_fwd_t<float>(tx, bias, B, C, H, W, negative_slope, (hipStream_t)stream)
+                          : bias_act_fwd_t<bf16>(tx, bias, B, C, H, W, negative_slope, (hipStream_t)stream);
+}
+
+extern "C" int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, float* gbias, int B, int C, int H,
+                                int W, float negative_slope, int dtype, void* stream) {
+  if (!y || !y->data || !gy || !gy->data || !gx || !gx->data || !gbias || B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  if (dtype != OCF_F32 && dtype != OCF_BF16) return OCF_EINVAL;
+  clear_stale_error();
+  ScopedProfile prof((hipStream_t)stream);
+  const T4 ty = mk(y), tg = mk(gy), tx = mk(gx);
+  return dtype == OCF_F32 ? bias_act_bwd_t<float>(ty, tg, tx, gbias, B, C, H, W, negative_slope, (hipStream_t)stream)
+                          : bias_act_bwd_t<bf16>(ty, tg, tx, gbias, B, C, H, W, negative_slope, (hipStream_t)stream);
+}

@@ -2,6 +2,8 @@
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._epilogue import conv_lrelu
+
 _PLAN = ((128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (2, 1))  # (out channels, dilation)
 
 
@@ -15,5 +17,5 @@ class ContextNetwork(nn.Module):
 
     def forward(self, x):
         for i in range(1, len(_PLAN)):
-            x = F.leaky_relu(getattr(self, f"conv{i}")(x), negative_slope=0.1)
+            x = conv_lrelu(getattr(self, f"conv{i}"), x, 0.1)
         return getattr(self, f"conv{len(_PLAN)}")(x)

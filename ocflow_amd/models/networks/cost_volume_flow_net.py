@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ocflow_amd import ops
+from ._epilogue import ConvLReLU
 
 ENC_WIDTHS = (3, 16, 32, 64, 96, 128, 196)
 DENSE_WIDTHS = (128, 128, 96, 64, 32)
@@ -17,8 +18,8 @@ WARP_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}
 
 
 def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
-    return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding,
-                                   dilation=dilation, bias=True), nn.LeakyReLU(0.1))
+    return ConvLReLU(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding,
+                               dilation=dilation, bias=True), nn.LeakyReLU(0.1))
 
 
 def predict_flow(in_planes):

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ocflow_amd import ops
+from ._epilogue import conv_lrelu
 from .context_net import ContextNetwork
 from .feature_pyramid_net import FeaturePyramidNet
 
@@ -40,7 +41,7 @@ class OpticalFlowEstimator(nn.Module):
 
     def forward(self, x, h_up=None, w_up=None):
         for i in range(1, 6):
-            x = F.leaky_relu(getattr(self, f"conv{i}")(x), negative_slope=0.1)
+            x = conv_lrelu(getattr(self, f"conv{i}"), x, 0.1)
         flow = self.conv6(x)
         if self.highest_res:
             return flow, x

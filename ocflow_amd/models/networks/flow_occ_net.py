@@ -9,6 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ocflow_amd import ops
+from ._epilogue import conv_lrelu
 from .context_net import ContextNetwork
 from .cost_volume_net import CostVolumeLayer
 from .feature_pyramid_net import FeaturePyramidNet
@@ -35,8 +36,8 @@ class OcclusionEstimator(nn.Module):
     def forward(self, features, h_up=None, w_up=None):
         x = features
         for i in range(1, 5):
-            x = F.leaky_relu(getattr(self, f"conv{i}")(x), negative_slope=0.1)
-        feat = F.leaky_relu(self.feat_layer(x), negative_slope=0.1)
+            x = conv_lrelu(getattr(self, f"conv{i}"), x, 0.1)
+        feat = conv_lrelu(self.feat_layer, x, 0.1)
         logit = self.mask_layer(feat)
         if self.highest_res:
             return torch.sigmoid(10 * logit)

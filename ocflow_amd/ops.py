@@ -494,3 +494,51 @@ def ssim(img1, img2, window_size=11, size_average=True):
     n = C_ * (H + 2 * pad - ws + 1) * (W + 2 * pad - ws + 1)
     per_sample = (sums / n).float()
     return per_sample.mean() if size_average else per_sample
+
+
+# ---------------------------------------------------------------------------------- convolution epilogue
+class _BiasActFn(Function):
+    @staticmethod
+    def forward(ctx, x, bias, negative_slope):
+        B, C_, H, W = x.shape
+        b32 = _f32(bias.detach()).contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().ocf_bias_act_fwd(_t4(x), C.c_void_p(b32.data_ptr()), B, C_, H, W, float(negative_slope),
+                                                    _dtype_code(x), _stream(x)), "ocf_bias_act_fwd")
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.slope = float(negative_slope)
+        ctx.bias_dtype = bias.dtype
+        return x
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        B, C_, H, W = y.shape
+        if gy.dtype != y.dtype:
+            gy = gy.to(y.dtype)
+        if gy.stride() != y.stride():  # e.g. the channel slice of a concatenation's gradient
+            gy = gy.contiguous(memory_format=torch.channels_last if _is_cl(y) else torch.contiguous_format)
+            if gy.stride() != y.stride():
+                gy = torch.empty_like(y).copy_(gy)
+        gx = torch.empty_like(y)
+        gb = torch.empty(C_, device=y.device, dtype=torch.float32)
+        with torch.cuda.device(y.device):
+            _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y), _t4(gy), _t4(gx), C.c_void_p(gb.data_ptr()), B, C_, H, W, ctx.slope,
+                                                    _dtype_code(y), _stream(y)), "ocf_bias_act_bwd")
+        return gx, (gb if ctx.bias_dtype == torch.float32 else gb.to(ctx.bias_dtype)), None
+
+
+def bias_leaky_relu(x, bias, negative_slope=0.1):
+    """`F.leaky_relu(x + bias[None, :, None, None], negative_slope)` for the bias-free output `x` of a convolution, IN PLACE
+    on `x` -- the epilogue of the reference's `conv()` blocks (nn.Conv2d(bias=True) + nn.LeakyReLU(0.1):
+    cost_volume_flow_net.py:19-21, simple_flow_net.py:55-57, ...).  One pass forward instead of add_ + leaky_relu, one pass
+    backward instead of leaky_relu_backward + sum((0,2,3)) + dtype casts; forward values are bit-identical to the unfused
+    chain in fp32 and under bf16 autocast (bias rounded to bf16, sum rounded, product rounded).  `x` must be a dense
+    channels_last or NCHW tensor this call may overwrite (a fresh convolution output)."""
+    _check4(x, "x")
+    if bias.dim() != 1 or bias.numel() != x.size(1):
+        raise ValueError(f"bias must have {x.size(1)} elements, got {tuple(bias.shape)}")
+    _require_hip(x, bias)
+    _dtype_code(x)
+    return _BiasActFn.apply(x, bias, float(negative_slope))

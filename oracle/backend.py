@@ -43,6 +43,7 @@ PATCHES = {
     "second_order_smoothness_loss": O.second_order_smoothness_loss,
     "compute_range_map": O.compute_range_map,
     "occlusion_from_flow": _occ_from_flow,
+    "bias_leaky_relu": O.bias_leaky_relu,
 }
 
 

@@ -335,3 +335,52 @@ def test_ssim_golden(ops, golden):
     close(ops.ssim(imgs.to(DEV)[:, :3], imgs.to(DEV)[:, 3:], 11), O.ssim(imgs[:, :3], imgs[:, 3:], 11), 1e-5)
     with pytest.raises(ValueError):
         ops.ssim(a, b, 17)
+
+
+# ------------------------------------------------------------------------------------- convolution epilogue
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,cl", [((2, 32, 33, 47), True), ((2, 96, 17, 30), True), ((1, 12, 9, 21), True), ((3, 2, 16, 16), True),
+                                      ((2, 32, 33, 47), False), ((2, 5, 20, 31), False), ((1, 1, 30, 40), False)])
+def test_bias_leaky_relu_matches_unfused_chain(ops, shape, cl, dtype):
+    """bias_leaky_relu == the oracle's `leaky_relu(x + bias)` (the two torch ops the reference's conv() epilogue runs): forward
+    bit for bit in fp32 AND bf16 (same roundings), input gradient bit for bit, bias gradient within the reordering error of a
+    fp32 sum (the oracle's bias gradient is additionally rounded to the activation dtype)"""
+    gen = torch.Generator().manual_seed(shape[1] * 7 + shape[2])
+    x0 = torch.randn(shape, generator=gen) * 2
+    b0 = torch.randn(shape[1], generator=gen)
+    go = torch.randn(shape, generator=gen)
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    xr = x0.to(DEV).to(dtype).contiguous(memory_format=fmt).requires_grad_()
+    br = b0.to(DEV).requires_grad_()
+    ref = O.bias_leaky_relu(xr, br, 0.1)
+    ref.backward(go.to(DEV).to(dtype).contiguous(memory_format=fmt))
+    x = x0.to(DEV).to(dtype).contiguous(memory_format=fmt).requires_grad_()
+    b = b0.to(DEV).requires_grad_()
+    out = ops.bias_leaky_relu(x * 1, b, 0.1)  # `x * 1`: a fresh non-leaf tensor, as a convolution output is
+    assert out.dtype == dtype and out.stride() == ref.stride()
+    assert torch.equal(out, ref)
+    out.backward(go.to(DEV).to(dtype).contiguous(memory_format=fmt))
+    assert torch.equal(x.grad, xr.grad)
+    n = shape[0] * shape[2] * shape[3]
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    np.testing.assert_allclose(b.grad.cpu().numpy(), br.grad.cpu().numpy(), rtol=tol, atol=tol * np.sqrt(n))
+    # the fp32 bias gradient against an fp64 sum of the (exact) input gradient
+    exact = xr.grad.double().sum((0, 2, 3)).cpu().numpy()
+    np.testing.assert_allclose(b.grad.double().cpu().numpy(), exact, rtol=2e-5, atol=2e-5 * np.sqrt(n))
+
+
+def test_bias_leaky_relu_full_size_and_errors(ops):
+    """level-2 decoder shape of the benchmark (8 x 128 x 109 x 256, bf16, channels_last) + argument checking"""
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.randn((8, 128, 109, 256), generator=gen).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(128, generator=gen).to(DEV)
+    ref = O.bias_leaky_relu(x0, b, 0.1)
+    out = ops.bias_leaky_relu(x0.clone(memory_format=torch.preserve_format), b, 0.1)
+    assert torch.equal(out, ref)
+    with pytest.raises(ValueError):
+        ops.bias_leaky_relu(x0, b[:5])
+    with pytest.raises(RuntimeError, match="no CPU fallback|HIP"):
+        ops.bias_leaky_relu(torch.zeros(1, 4, 8, 8), torch.zeros(4))
+    with pytest.raises(RuntimeError):  # a strided view is not a convolution output: refused, not copied
+        big = torch.zeros((2, 16, 8, 12), device=DEV)
+        ops.bias_leaky_relu(big[:, :8], torch.zeros(8, device=DEV))

