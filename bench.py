@@ -55,10 +55,10 @@ def parse():
                    help="1 (default): run the module's Adam (models/flow_occ_model.py:77-78) through torch's fused multi-tensor "
                         "kernel -- same update rule, checked in tests/test_models_gpu.py::test_fused_adam_same_update; 0: foreach")
     p.add_argument("--graph", type=int, default=-1,
-                   help="1: capture the whole training step (forward+loss+backward+Adam) in a hipGraph and replay it; 0: eager; "
-                        "-1 (default): graph on one GPU (falls back to eager if capture fails), eager under DDP.  Same kernels "
-                        "and same GPU time either way (the step is GPU-bound on ~2000 small kernels); replay only removes the "
-                        "host-launch jitter of the eager loop")
+                   help="1: capture the training step in hipGraphs and replay it (one GPU: forward+loss+backward+Adam in one graph; "
+                        "several: forward+loss+backward graph, one eager all-reduce of the flat gradient buffer, Adam graph); "
+                        "0: eager loop (torch DDP when several ranks); -1 (default): graphs, falling back to eager if the capture "
+                        "raises.  Same kernels either way; replay removes the host launch path (~3 ms of a 21 ms eager step)")
     return p.parse_args()
 
 
@@ -72,12 +72,12 @@ def build_module(args):
                            "smooth2_weight": 0.0, "with_occ": False, "occ_aware": True})
 
 
-def build_stepper(args, env):
+def build_stepper(args, env, dp_mode="ddp"):
     from ocflow_amd.runtime import TrainStepper
     torch.manual_seed(42)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
     return TrainStepper(build_module(args), env, amp_dtype=amp, channels_last=(args.layout == "cl"),
-                        fused_optimizer=bool(getattr(args, "fused_adam", 0)))
+                        fused_optimizer=bool(getattr(args, "fused_adam", 0)), dp_mode=dp_mode)
 
 
 def usable_cores() -> int:
@@ -177,24 +177,34 @@ def main():
     # re-runs the search (same throughput, measured), OCFLOW_MIOPEN_CAPTURE=<dir> regenerates the db.
     torch.backends.cudnn.benchmark = os.environ.get("OCFLOW_MIOPEN_FIND", "0") == "1"
 
-    stepper = build_stepper(args, env)
+    use_graph = args.graph != 0
+    # several ranks + graph replay: "flat" data parallelism (one all-reduce of a flat gradient buffer between two graphs);
+    # eager: torch DDP (bucketed all-reduce overlapped with backward)
+    stepper = build_stepper(args, env, dp_mode="flat" if use_graph else "ddp")
     B = args.batch
     batch = stepper.prepare(synthetic_batch(B, args.height, args.width, env.device, seed=42, index_offset=env.rank * B))
 
     t_w = time.perf_counter()
-    use_graph = args.graph == 1 or (args.graph == -1 and env.world_size == 1)
     if use_graph:
         stepper.step(batch)  # lazy initialisation (kernel JIT / db loads) must not happen inside a capture
+        failure = None
         try:
             stepper.enable_graph(batch)
-            batch = stepper._static_batch
         except Exception as e:  # noqa: BLE001 - any capture problem: measure the eager loop instead
             if args.graph == 1:
                 raise
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); using the eager loop", file=sys.stderr, flush=True)
+            failure = f"{type(e).__name__}: {e}"
+        # every rank takes the same branch: one rank replaying graphs while another waits in DDP's all-reduce would hang
+        if all_reduce_max(env, 1.0 if failure else 0.0) > 0.0:
+            print(f"[bench] rank {env.rank}: hipGraph capture failed ({failure or 'on another rank'}); using the eager loop",
+                  file=sys.stderr, flush=True)
             use_graph = False
-            stepper = build_stepper(args, env)
+            del stepper
+            torch.cuda.empty_cache()
+            stepper = build_stepper(args, env, dp_mode="ddp")
             batch = stepper.prepare(synthetic_batch(B, args.height, args.width, env.device, seed=42, index_offset=env.rank * B))
+        else:
+            batch = stepper._static_batch
     for i in range(args.preroll):
         stepper.step(batch)
         if env.is_main and i in (0, args.preroll - 1):  # the first step loads/JITs kernels on a fresh box: show progress
@@ -269,7 +279,8 @@ def main():
                                    f"Sintel-style pairs, corr d=4, 5 pyramid levels, {B} pairs/GPU (BASELINE configs[1] "
                                    f"shape; per-rank share of configs[4])",
                        "global_batch": B * n, "height": args.height, "width": args.width, "layout": args.layout,
-                       "parallelism": f"dp{n}", "launch": "hipGraph replay of the whole step" if use_graph else "eager",
+                       "parallelism": f"dp{n}" + ("" if n == 1 else (" (flat all-reduce between graphs)" if use_graph else " (torch DDP)")),
+                       "launch": "hipGraph replay of the whole step" if use_graph else "eager",
                        "final_loss": round(loss_val, 5),
                        "optimizer": "adam(fused)" if args.fused_adam else "adam(foreach)"},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -43,11 +43,14 @@ __global__ void __launch_bounds__(256) bias_act_fwd_cl(T* __restrict__ x, const 
   }
 }
 
-// rows_per_block rows of G units each per pass; thread (r = tid / G, cg = tid % G) keeps U fp32 partial sums of its channel
-// group, reduced over r through LDS at the end, one atomicAdd per channel per block.
+// rpb = 256 / G rows of G units each per pass; thread (r = tid / G, cg = tid % G) keeps U fp32 partial sums of its channel
+// group.  UNR passes are loaded before any is used (the loop is latency-bound otherwise: 2 loads + 1 store per pass); the
+// partial sums are reduced over r through LDS and leave the block as one atomicAdd per channel (consecutive threads ->
+// consecutive channels, i.e. whole-cache-line atomics), so the grid is kept at <= 512 blocks.
 template <typename T, int U>
 __global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx,
                                                        float* __restrict__ gbias, long R, int G, float slope) {
+  constexpr int UNR = (U == 1) ? 8 : 4;
   __shared__ float red[256][U + 1];
   const int rpb = 256 / G;               // rows per pass
   const int r = threadIdx.x / G, cg = threadIdx.x - r * G;
@@ -55,23 +58,35 @@ __global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, 
 #pragma unroll
   for (int j = 0; j < U; j++) acc[j] = 0.f;
   if (r < rpb) {
-    for (long row = (long)blockIdx.x * rpb + r; row < R; row += (long)gridDim.x * rpb) {
-      const long i = row * G + cg;
-      float fy[U], fg[U];
-      ld_u<T, U>(y, i, fy);
-      ld_u<T, U>(gy, i, fg);
+    const long step = (long)gridDim.x * rpb;
+    for (long row0 = (long)blockIdx.x * rpb + r; row0 < R; row0 += step * UNR) {
+      float fy[UNR][U], fg[UNR][U];
 #pragma unroll
-      for (int j = 0; j < U; j++) {
-        fg[j] = fy[j] > 0.f ? fg[j] : rnd<T>(fg[j] * slope);
-        acc[j] += fg[j];
+      for (int k = 0; k < UNR; k++) {
+        const long row = row0 + k * step;
+        if (row < R) {
+          ld_u<T, U>(y, row * G + cg, fy[k]);
+          ld_u<T, U>(gy, row * G + cg, fg[k]);
+        }
       }
-      st_u<T, U>(gx, i, fg);
+#pragma unroll
+      for (int k = 0; k < UNR; k++) {
+        const long row = row0 + k * step;
+        if (row < R) {
+#pragma unroll
+          for (int j = 0; j < U; j++) {
+            fg[k][j] = fy[k][j] > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
+            acc[j] += fg[k][j];
+          }
+          st_u<T, U>(gx, row * G + cg, fg[k]);
+        }
+      }
     }
   }
 #pragma unroll
   for (int j = 0; j < U; j++) red[threadIdx.x][j] = acc[j];
   __syncthreads();
-  // thread t < G*U sums channel (t / U group, t % U lane) over the rpb row slots
+  // thread t < G*U sums channel t (group t / U, lane t % U) over the rpb row slots
   for (int t = threadIdx.x; t < G * U; t += 256) {
     const int g = t / U, j = t - g * U;
     float s = 0.f;
@@ -170,9 +185,10 @@ static int bias_act_bwd_t(const T4& y, const T4& gy, const T4& gx, float* gbias,
     const int G = lay == LAYOUT_CL ? C / U : C;
     const int rpb = 256 / G;
     const long R = (long)B * H * W;
-    // enough rows per block to amortise the reduction + atomics (>= 64 passes), at most ~8 blocks per CU
-    long want = (R + (long)rpb * 64 - 1) / ((long)rpb * 64);
-    const int grid = (int)(want < 1 ? 1 : (want < 2048 ? want : 2048));
+    // one unrolled iteration (4-8 passes) per thread at least, at most 512 blocks (2 per CU): the block-level reduction and its
+    // per-channel atomics are paid per block
+    long want = (R + (long)rpb * 8 - 1) / ((long)rpb * 8);
+    const int grid = (int)(want < 1 ? 1 : (want < 512 ? want : 512));
     if (lay == LAYOUT_CL)
       hipLaunchKernelGGL((bias_act_bwd_cl<T, U>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
     else

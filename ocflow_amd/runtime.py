@@ -73,7 +73,9 @@ def init_distributed(force_cpu: bool = False) -> DistEnv:
     if use_gpu:
         torch.cuda.set_device(device)
     backend = None
-    if world > 1:
+    # OCFLOW_FORCE_DIST=1: join a process group even as a single rank (exercises the real RCCL code path -- stream ordering of
+    # the gradient all-reduce against hipGraph replays -- on a one-GPU box)
+    if world > 1 or os.environ.get("OCFLOW_FORCE_DIST", "0") == "1":
         backend = "nccl" if use_gpu and not rehearsal else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -168,8 +170,14 @@ class TrainStepper:
     under bf16 autocast when `amp_dtype` is given (convs on MFMA via MIOpen, HIP ops bf16-in / fp32-accumulate)."""
 
     def __init__(self, module: torch.nn.Module, env: DistEnv, amp_dtype: Optional[torch.dtype] = torch.bfloat16,
-                 channels_last: bool = True, fused_optimizer: bool = False):
+                 channels_last: bool = True, fused_optimizer: bool = False, dp_mode: str = "ddp"):
+        """dp_mode (world_size > 1 only): "ddp" = torch DistributedDataParallel (bucketed all-reduce overlapped with the eager
+        backward); "flat" = no DDP wrapper, gradients are averaged with ONE all-reduce of a flat fp32 buffer between backward
+        and the optimizer -- the mode `enable_graph` needs, because then nothing collective sits inside a captured graph."""
+        if dp_mode not in ("ddp", "flat"):
+            raise ValueError(f"dp_mode must be 'ddp' or 'flat', got {dp_mode!r}")
         self.env = env
+        self.dp_mode = dp_mode if (env.world_size > 1 or env.backend is not None) else "ddp"
         self.amp_dtype = amp_dtype if env.device.type == "cuda" else None
         self.channels_last = channels_last
         module = module.to(env.device)
@@ -182,9 +190,17 @@ class TrainStepper:
             # per-tensor fallback torch's foreach path takes when parameter / gradient strides differ
             for g in self.optimizer.param_groups:
                 g["fused"], g["foreach"] = True, False
-        self.module = wrap_ddp(_StepAdapter(module), env)
+        if self.dp_mode == "flat":
+            self.module = _StepAdapter(module)
+            with torch.no_grad():  # what DDP's constructor does: every replica starts from rank 0's parameters and buffers
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t, src=0)
+        else:
+            self.module = wrap_ddp(_StepAdapter(module), env)
         self._graph = None
+        self._graph_opt = None
         self._graph_pool = None
+        self._flat = None
 
     def prepare(self, batch):
         out = []
@@ -200,24 +216,58 @@ class TrainStepper:
             return self._replay(batch)
         return self._eager_step(batch, batch_idx)
 
-    def _eager_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+    # ---- the step in two halves: forward + loss + backward, then the optimizer; "flat" data parallelism averages the
+    # gradients between the two
+    def _forward_backward(self, batch, batch_idx: int = 0) -> torch.Tensor:
         # gradients are dropped, not zero-filled: backward then writes them instead of accumulating (one fill and one add
         # per parameter saved); inside a graph capture they are re-allocated from the graph's pool, so replays reuse them
         self.optimizer.zero_grad(set_to_none=not getattr(self, "_static_grads", False))
         ctx = torch.autocast(self.env.device.type, dtype=self.amp_dtype) if self.amp_dtype is not None else nullcontext()
         with ctx:
             loss = self.module(batch, batch_idx)
-        loss.backward()
-        self.optimizer.step()
-        self.raw.global_step = getattr(self.raw, "global_step", 0) + 1
+        if self.dp_mode == "flat":
+            (loss / self.env.world_size).backward()  # sum over ranks of grad(loss / N) = DDP's averaged gradient
+        else:
+            loss.backward()
         return loss.detach()
 
-    # ---- whole-step hipGraph: the eager step issues ~1600 kernel launches and is host-bound (GPU busy ~60 %); capturing
-    # forward + loss + backward + Adam once and replaying it removes the launch path.  Single-GPU only for now (capturing
-    # DDP's RCCL all-reduce needs the side-stream construction + 11 eager iterations recipe and cannot be tested on one GPU).
+    def _grad_params(self):
+        return [p for p in self.raw.parameters() if p.grad is not None]
+
+    def _flat_views(self, params):
+        """one fp32 buffer + per-parameter views with the parameters' own (dense, possibly channels_last) strides, so the
+        multi-tensor copy and the fused optimizer take their fast paths"""
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, device=self.env.device, dtype=torch.float32)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].as_strided(p.shape, p.stride()))
+            off += p.numel()
+        return flat, views
+
+    def _eager_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        loss = self._forward_backward(batch, batch_idx)
+        if self.dp_mode == "flat":
+            params = self._grad_params()
+            flat, views = self._flat_views(params)
+            torch._foreach_copy_(views, [p.grad for p in params])
+            dist.all_reduce(flat)
+            for p, v in zip(params, views):
+                p.grad = v
+        self.optimizer.step()
+        self.raw.global_step = getattr(self.raw, "global_step", 0) + 1
+        return loss
+
+    # ---- whole-step hipGraph: the eager step issues ~1700 kernel launches and is host-bound; capturing it once and replaying
+    # removes the launch path.  One GPU: a single graph (forward + loss + backward + Adam).  Several GPUs ("flat" mode): graph A
+    # = forward + loss + backward + gather of the gradients into one flat fp32 buffer, then ONE eager all-reduce of that buffer
+    # (27.6 MB for FlowOccNet) on the process group, then graph B = Adam reading the reduced gradients through views of the flat
+    # buffer.  No collective is ever captured, so the same code runs over RCCL and (in tests) gloo; the price is that the
+    # all-reduce is not overlapped with backward (~0.3 ms of a 17.7 ms step at 8 GPUs over xGMI).
     def enable_graph(self, batch, warmup: int = 3):
-        if self.env.world_size != 1:
-            raise RuntimeError("TrainStepper.enable_graph: whole-step graph capture is single-GPU only")
+        if self.env.world_size != 1 and self.dp_mode != "flat":  # (a single rank in "ddp" mode has no DDP wrapper at all)
+            raise RuntimeError("TrainStepper.enable_graph: with several ranks construct the stepper with dp_mode='flat' "
+                               "(a DDP-wrapped step has its all-reduces inside backward and is not captured)")
         if self.env.device.type != "cuda":
             raise RuntimeError("TrainStepper.enable_graph needs a HIP device")
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0" and os.environ.get("OCFLOW_UNSAFE_GRAPH", "0") != "1":
@@ -239,11 +289,28 @@ class TrainStepper:
                 self._eager_step(self._static_batch, i)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
         self._static_grads = os.environ.get("OCFLOW_GRAPH_STATIC_GRADS", "0") == "1"
+        graph = torch.cuda.CUDAGraph()
+        if self.dp_mode != "flat":
+            with torch.cuda.graph(graph, pool=self._graph_pool):
+                self._static_loss = self._eager_step(self._static_batch, 0)
+            self._graph = graph
+            return self
+        params = self._grad_params()  # after the warm-up steps: exactly the parameters that reach the loss
+        self._flat, views = self._flat_views(params)
         with torch.cuda.graph(graph, pool=self._graph_pool):
-            self._static_loss = self._eager_step(self._static_batch, 0)
-        self._graph = graph
+            self._static_loss = self._forward_backward(self._static_batch, 0)
+            got = self._grad_params()
+            if len(got) != len(params) or any(a is not b for a, b in zip(got, params)):
+                raise RuntimeError("TrainStepper.enable_graph: the set of parameters with gradients changed between steps")
+            torch._foreach_copy_(views, [p.grad for p in params])
+        dist.all_reduce(self._flat)  # keeps the replicas in step across the capture itself (the capture ran no kernels)
+        for p, v in zip(params, views):
+            p.grad = v
+        opt_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(opt_graph, pool=self._graph_pool):
+            self.optimizer.step()
+        self._graph, self._graph_opt = graph, opt_graph
         return self
 
     def _replay(self, batch) -> torch.Tensor:
@@ -252,6 +319,9 @@ class TrainStepper:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        if self._graph_opt is not None:
+            dist.all_reduce(self._flat)
+            self._graph_opt.replay()
         self.raw.global_step = getattr(self.raw, "global_step", 0) + 1
         return self._static_loss
 

@@ -209,3 +209,54 @@ def test_graph_replay_full_size_is_clean(monkeypatch):
         gmax = max(float(p.grad.abs().max()) for p in st.raw.parameters() if p.grad is not None)
         assert np.isfinite(losses[-1]) and np.isfinite(gmax) and gmax < 1e3, (i, losses, gmax)
     assert max(losses) < first * 1.05 and losses[-1] < first, (first, losses)
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      OCFLOW_DIST_REHEARSAL="1")
+    import ocflow_amd  # noqa: F401
+    import torch
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.runtime import TrainStepper, init_distributed, shutdown_distributed, synthetic_batch
+    env = init_distributed()
+    res = {}
+    for mode, graph in (("ddp", False), ("flat", False), ("flat", True)):
+        torch.manual_seed(7)
+        st = TrainStepper(FlowOccModel({"learning_rate": 1e-4, "model": "flowoccnet"}), env, amp_dtype=None, channels_last=False,
+                          fused_optimizer=True, dp_mode=mode)
+        batch = st.prepare(synthetic_batch(2, 128, 192, env.device, seed=3, index_offset=2 * rank))
+        losses = [float(st.step(batch, 0))]
+        if graph:
+            st.enable_graph(batch)
+            batch = st._static_batch
+        for i in range(1, 5):
+            losses.append(float(st.step(batch, i)))
+        res[f"{mode}{'_graph' if graph else ''}"] = {"losses": losses, "params": [p.detach().cpu().clone() for p in st.raw.parameters()]}
+        del st
+    torch.save(res, os.path.join(out_dir, f"dp_rank{rank}.pt"))
+    shutdown_distributed()
+
+
+@pytest.mark.timeout(600)
+def test_flat_data_parallel_graph_two_ranks(tmp_path):
+    """the three data-parallel modes of TrainStepper with two ranks sharing this GPU (OCFLOW_DIST_REHEARSAL: gloo process group):
+    torch DDP (eager), flat all-reduce (eager) and flat all-reduce between two hipGraphs.  Replicas stay bit-identical in every
+    mode; the flat mode follows DDP's trajectory (same averaged gradient, rounded differently: loss/N before backward instead
+    of gradient/N after); graph replay k is training step k + 3 (the capture's warm-up steps)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.start_processes(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "dp_rank0.pt"), torch.load(tmp_path / "dp_rank1.pt")
+    for mode in ("ddp", "flat", "flat_graph"):
+        for a, b in zip(r0[mode]["params"], r1[mode]["params"]):
+            assert torch.equal(a, b), mode
+        assert all(np.isfinite(r0[mode]["losses"])) and r0[mode]["losses"][-1] < r0[mode]["losses"][0], (mode, r0[mode]["losses"])
+    np.testing.assert_allclose(r0["flat"]["losses"], r0["ddp"]["losses"], rtol=2e-2)
+    assert abs(r0["flat"]["losses"][0] - r0["ddp"]["losses"][0]) < 1e-5 * abs(r0["ddp"]["losses"][0])
+    assert abs(r0["flat_graph"]["losses"][0] - r0["ddp"]["losses"][0]) < 1e-5 * abs(r0["ddp"]["losses"][0])
+    assert r0["flat_graph"]["losses"][-1] < r0["flat"]["losses"][1]
