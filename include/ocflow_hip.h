@@ -57,6 +57,11 @@ int ocf_device_info(char* name, int name_len, int* compute_units);
  * waiting for the host, count that idle gap as kernel time. */
 int ocf_profile_next_launch(void* start_event, void* stop_event);
 
+/* *id = identifier of the graph capture `stream` is currently recording into, 0 when it is not capturing.  Host-side caches of
+ * pre-initialised device buffers (the zeroed accumulators handed to ocf_bias_act_bwd) must not outlive the capture they were
+ * filled in: the fill is a node of THAT graph and is not replayed by another one. */
+int ocf_stream_capture_id(void* stream, unsigned long long* id);
+
 /* ---- K1+K2  local cost volume, optionally fused with the backward warp of f2 -------------
  * out[b,(dy+d)(2d+1)+(dx+d),y,x] = 1/C * sum_c f1[b,c,y,x] * w2[b,c,y+dy,x+dx]   (0 outside)
  *   w2 = f2                                            when flow == NULL
@@ -138,15 +143,20 @@ int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums,
 
 /* ---- convolution epilogue of the estimator nets (second "next" row: the callers either side of the correlation) ----------
  * forward, IN PLACE on x (the bias-free convolution output):   t = T(x + T(bias[c]));  y = t > 0 ? t : T(t * negative_slope)
- * backward:  gx = y > 0 ? gy : T(gy * negative_slope);  gbias[c] = sum over (B,H,W) of gx   (fp32, zeroed by the launcher)
+ *   negative_slope == 1: plain bias add (prediction layers, transposed convolutions).
+ * backward:  gx = y > 0 ? gy : T(gy * negative_slope);  gbias[c] (+)= sum over (B,H,W) of gx   (fp32)
+ *   gx == NULL (only with negative_slope == 1, where gx is gy itself): reduction only, y is not read and may be NULL.
+ *   accumulate == 0: the launcher zeroes gbias first; accumulate != 0: gbias already holds the value to add to (callers hand
+ *   out slices of one pre-zeroed buffer instead of paying a memset per layer).
  * x / y / gy / gx: dense channels_last or dense NCHW tensors of type `dtype` (anything else: OCF_EUNSUPPORTED); bias, gbias fp32 [C].
- * replaces: nn.Sequential(nn.Conv2d(bias=True), nn.LeakyReLU(0.1)) epilogues -- conv() of cost_volume_flow_net.py:19-21,
- *           cost_volume_flow_occ_net.py, flow_net.py, flow_occ_net.py, context_net.py, simple_flow_net.py:55-57
- *           [aten add_(bias) + leaky_relu | leaky_relu_backward + sum((0,2,3)) + casts] */
+ * replaces: nn.Sequential(nn.Conv2d(bias=True), nn.LeakyReLU(0.1)) and the bias of nn.Conv2d / nn.ConvTranspose2d --
+ *           conv(), predict_flow(), deconv() of cost_volume_flow_net.py:19-30, the estimators of flow_net.py / flow_occ_net.py,
+ *           context_net.py, feature_pyramid_net.py upsample blocks
+ *           [aten add_(bias) + leaky_relu | leaky_relu_backward + sum((0,2,3)) + dtype casts] */
 int ocf_bias_act_fwd(const ocf_tensor4* x, const float* bias, int B, int C, int H, int W, float negative_slope, int dtype,
                      void* stream);
 int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, float* gbias, int B, int C, int H, int W,
-                     float negative_slope, int dtype, void* stream);
+                     float negative_slope, int accumulate, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

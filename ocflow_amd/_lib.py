@@ -33,6 +33,7 @@ SIGNATURES = {
     "ocf_abi_version": [],
     "ocf_device_info": [C.c_char_p, _i, C.POINTER(_i)],
     "ocf_profile_next_launch": [_vp, _vp],
+    "ocf_stream_capture_id": [_vp, C.POINTER(C.c_ulonglong)],
     "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ocf_corr_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_warp_fwd": [_T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
@@ -45,7 +46,7 @@ SIGNATURES = {
     "ocf_moments": [_T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_ssim_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_bias_act_fwd": [_T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
-    "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
 }
 
 _lock = threading.Lock()

@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(256) bias_act_fwd_cl(T* __restrict__ x, const 
 // group.  UNR passes are loaded before any is used (the loop is latency-bound otherwise: 2 loads + 1 store per pass); the
 // partial sums are reduced over r through LDS and leave the block as one atomicAdd per channel (consecutive threads ->
 // consecutive channels, i.e. whole-cache-line atomics), so the grid is kept at <= 512 blocks.
-template <typename T, int U>
+// PASS: negative_slope == 1 (plain bias epilogue): gx == gy, nothing to read from y or write to gx, only the reduction runs.
+template <typename T, int U, bool PASS>
 __global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx,
                                                        float* __restrict__ gbias, long R, int G, float slope) {
   constexpr int UNR = (U == 1) ? 8 : 4;
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, 
       for (int k = 0; k < UNR; k++) {
         const long row = row0 + k * step;
         if (row < R) {
-          ld_u<T, U>(y, row * G + cg, fy[k]);
+          if (!PASS) ld_u<T, U>(y, row * G + cg, fy[k]);
           ld_u<T, U>(gy, row * G + cg, fg[k]);
         }
       }
@@ -75,10 +76,10 @@ __global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, 
         if (row < R) {
 #pragma unroll
           for (int j = 0; j < U; j++) {
-            fg[k][j] = fy[k][j] > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
+            if (!PASS) fg[k][j] = fy[k][j] > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
             acc[j] += fg[k][j];
           }
-          st_u<T, U>(gx, row * G + cg, fg[k]);
+          if (!PASS) st_u<T, U>(gx, row * G + cg, fg[k]);
         }
       }
     }
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(256) bias_act_fwd_nchw(T* __restrict__ x, cons
   }
 }
 
-template <typename T>
+template <typename T, bool PASS>
 __global__ void __launch_bounds__(256) bias_act_bwd_nchw(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx,
                                                          float* __restrict__ gbias, int C, long HW, int chunks, float slope) {
   const long plane = blockIdx.x / chunks;
@@ -124,8 +125,11 @@ __global__ void __launch_bounds__(256) bias_act_bwd_nchw(const T* __restrict__ y
   float acc = 0.f;
   for (long i = lo + threadIdx.x; i < hi; i += 256) {
     const float g = (float)gy[base + i];
-    const float v = (float)y[base + i] > 0.f ? g : rnd<T>(g * slope);
-    gx[base + i] = (T)v;
+    float v = g;
+    if (!PASS) {
+      v = (float)y[base + i] > 0.f ? g : rnd<T>(g * slope);
+      gx[base + i] = (T)v;
+    }
     acc += v;
   }
   acc = wave_sum(acc);
@@ -175,12 +179,14 @@ static int bias_act_fwd_t(const T4& x, const float* bias, int B, int C, int H, i
   return launch_status();
 }
 
-template <typename T>
-static int bias_act_bwd_t(const T4& y, const T4& gy, const T4& gx, float* gbias, int B, int C, int H, int W, float slope, hipStream_t st) {
+template <typename T, bool PASS>
+static int bias_act_bwd_t(const T4& y, const T4& gy, const T4& gx, float* gbias, int B, int C, int H, int W, float slope, bool accumulate,
+                          hipStream_t st) {
   constexpr int U = Unit<T>::U;
-  const int lay = dense_layout<T>(y, B, C, H, W);
-  if (lay == LAYOUT_NONE || dense_layout<T>(gy, B, C, H, W) != lay || dense_layout<T>(gx, B, C, H, W) != lay) return OCF_EUNSUPPORTED;
-  if (hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return OCF_ELAUNCH;
+  const int lay = dense_layout<T>(gy, B, C, H, W);
+  if (lay == LAYOUT_NONE) return OCF_EUNSUPPORTED;
+  if (!PASS && (dense_layout<T>(y, B, C, H, W) != lay || dense_layout<T>(gx, B, C, H, W) != lay)) return OCF_EUNSUPPORTED;
+  if (!accumulate && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return OCF_ELAUNCH;
   if (lay == LAYOUT_CL || lay == LAYOUT_CL1) {
     const int G = lay == LAYOUT_CL ? C / U : C;
     const int rpb = 256 / G;
@@ -190,16 +196,16 @@ static int bias_act_bwd_t(const T4& y, const T4& gy, const T4& gx, float* gbias,
     long want = (R + (long)rpb * 8 - 1) / ((long)rpb * 8);
     const int grid = (int)(want < 1 ? 1 : (want < 512 ? want : 512));
     if (lay == LAYOUT_CL)
-      hipLaunchKernelGGL((bias_act_bwd_cl<T, U>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
+      hipLaunchKernelGGL((bias_act_bwd_cl<T, U, PASS>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
     else
-      hipLaunchKernelGGL((bias_act_bwd_cl<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
+      hipLaunchKernelGGL((bias_act_bwd_cl<T, 1, PASS>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
   } else {
     const long HW = (long)H * W;
     int chunks = (int)((HW + 16383) / 16384);
     const long blocks = (long)B * C * chunks;
     if (blocks > 0x7fffffffL) return OCF_EUNSUPPORTED;
-    hipLaunchKernelGGL(bias_act_bwd_nchw<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, C, HW,
-                       chunks, slope);
+    hipLaunchKernelGGL((bias_act_bwd_nchw<T, PASS>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias,
+                       C, HW, chunks, slope);
   }
   return launch_status();
 }
@@ -220,12 +226,20 @@ extern "C" int ocf_bias_act_fwd(const ocf_tensor4* x, const float* bias, int B, 
 }
 
 extern "C" int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, float* gbias, int B, int C, int H,
-                                int W, float negative_slope, int dtype, void* stream) {
-  if (!y || !y->data || !gy || !gy->data || !gx || !gx->data || !gbias || B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+                                int W, float negative_slope, int accumulate, int dtype, void* stream) {
+  if (!gy || !gy->data || !gbias || B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   if (dtype != OCF_F32 && dtype != OCF_BF16) return OCF_EINVAL;
+  // the input gradient is only a separate tensor when the activation has a slope: with negative_slope == 1 it IS gy
+  const bool pass = (gx == nullptr || gx->data == nullptr);
+  if (pass && negative_slope != 1.0f) return OCF_EINVAL;
+  if (!pass && (!y || !y->data)) return OCF_EINVAL;
   clear_stale_error();
   ScopedProfile prof((hipStream_t)stream);
   const T4 ty = mk(y), tg = mk(gy), tx = mk(gx);
-  return dtype == OCF_F32 ? bias_act_bwd_t<float>(ty, tg, tx, gbias, B, C, H, W, negative_slope, (hipStream_t)stream)
-                          : bias_act_bwd_t<bf16>(ty, tg, tx, gbias, B, C, H, W, negative_slope, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OCF_F32)
+    return pass ? bias_act_bwd_t<float, true>(ty, tg, tx, gbias, B, C, H, W, negative_slope, accumulate != 0, st)
+                : bias_act_bwd_t<float, false>(ty, tg, tx, gbias, B, C, H, W, negative_slope, accumulate != 0, st);
+  return pass ? bias_act_bwd_t<bf16, true>(ty, tg, tx, gbias, B, C, H, W, negative_slope, accumulate != 0, st)
+              : bias_act_bwd_t<bf16, false>(ty, tg, tx, gbias, B, C, H, W, negative_slope, accumulate != 0, st);
 }

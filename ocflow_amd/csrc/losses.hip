@@ -454,6 +454,16 @@ ProfileSlot& profile_slot() {
 }
 }  // namespace ocf
 
+extern "C" int ocf_stream_capture_id(void* stream, unsigned long long* id) {
+  if (!id) return OCF_EINVAL;
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long cid = 0;
+  clear_stale_error();
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &status, &cid) != hipSuccess) { (void)hipGetLastError(); return OCF_ELAUNCH; }
+  *id = status == hipStreamCaptureStatusActive ? cid : 0ull;
+  return OCF_OK;
+}
+
 extern "C" int ocf_profile_next_launch(void* start_event, void* stop_event) {
   ocf::ProfileSlot& p = ocf::profile_slot();
   p.start = (hipEvent_t)start_event;

@@ -13,10 +13,31 @@ from ocflow_amd import ops
 
 def conv_lrelu(conv: nn.Conv2d, x, negative_slope: float = 0.1):
     # OCFLOW_UNFUSED_EPILOGUE=1: the reference's own op chain (A/B switch for measurements and bisecting, not a fallback)
-    if conv.bias is None or conv.padding_mode != "zeros" or os.environ.get("OCFLOW_UNFUSED_EPILOGUE", "0") == "1":
+    if conv.bias is None or conv.padding_mode != "zeros" or _unfused():
         return F.leaky_relu(conv(x), negative_slope)
     y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     return ops.bias_leaky_relu(y, conv.bias, negative_slope)
+
+
+def _unfused() -> bool:
+    return os.environ.get("OCFLOW_UNFUSED_EPILOGUE", "0") == "1"
+
+
+def conv_bias(conv: nn.Conv2d, x):
+    """nn.Conv2d(bias=True) without activation (prediction layers): bias-free convolution + in-place bias kernel"""
+    if conv.bias is None or conv.padding_mode != "zeros" or _unfused():
+        return conv(x)
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return ops.bias_add(y, conv.bias)
+
+
+def deconv_bias(deconv: nn.ConvTranspose2d, x, output_size=None):
+    """nn.ConvTranspose2d(bias=True)(x, output_size=...) as a bias-free transposed convolution + in-place bias kernel"""
+    if deconv.bias is None or deconv.padding_mode != "zeros" or _unfused():
+        return deconv(x, output_size=output_size)
+    output_padding = deconv._output_padding(x, output_size, deconv.stride, deconv.padding, deconv.kernel_size, 2, deconv.dilation)
+    y = F.conv_transpose2d(x, deconv.weight, None, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
+    return ops.bias_add(y, deconv.bias)
 
 
 class ConvLReLU(nn.Sequential):

@@ -2,7 +2,7 @@
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._epilogue import conv_lrelu
+from ._epilogue import conv_bias, conv_lrelu
 
 _PLAN = ((128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (2, 1))  # (out channels, dilation)
 
@@ -18,4 +18,4 @@ class ContextNetwork(nn.Module):
     def forward(self, x):
         for i in range(1, len(_PLAN)):
             x = conv_lrelu(getattr(self, f"conv{i}"), x, 0.1)
-        return getattr(self, f"conv{len(_PLAN)}")(x)
+        return conv_bias(getattr(self, f"conv{len(_PLAN)}"), x)

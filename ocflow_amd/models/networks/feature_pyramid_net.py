@@ -2,6 +2,8 @@
 (MIOpen -> MFMA); only the parameter names / shapes are contractual (state_dict compatibility)."""
 import torch.nn as nn
 
+from ._epilogue import deconv_bias
+
 _SLOPE = 0.1
 _WIDTHS = (3, 16, 32, 64, 96, 128, 196)
 
@@ -33,7 +35,7 @@ class Upsample(nn.Module):
         self.leaky = nn.LeakyReLU(negative_slope=_SLOPE)
 
     def forward(self, x, y):
-        return self.leaky(self.batchnorm(self.deconv(x, output_size=y.size()))) + y
+        return self.leaky(self.batchnorm(deconv_bias(self.deconv, x, y.size()))) + y
 
 
 class FeaturePyramidNet(nn.Module):

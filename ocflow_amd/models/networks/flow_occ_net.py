@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ocflow_amd import ops
-from ._epilogue import conv_lrelu
+from ._epilogue import conv_bias, conv_lrelu, deconv_bias
 from .context_net import ContextNetwork
 from .cost_volume_net import CostVolumeLayer
 from .feature_pyramid_net import FeaturePyramidNet
@@ -38,12 +38,12 @@ class OcclusionEstimator(nn.Module):
         for i in range(1, 5):
             x = conv_lrelu(getattr(self, f"conv{i}"), x, 0.1)
         feat = conv_lrelu(self.feat_layer, x, 0.1)
-        logit = self.mask_layer(feat)
+        logit = conv_bias(self.mask_layer, feat)
         if self.highest_res:
             return torch.sigmoid(10 * logit)
         size = (h_up, w_up)
         occ = torch.sigmoid(logit)
-        return occ, torch.sigmoid(self.upconv2(occ, output_size=size)), torch.sigmoid(self.upconv1(feat, output_size=size))
+        return occ, torch.sigmoid(deconv_bias(self.upconv2, occ, size)), torch.sigmoid(deconv_bias(self.upconv1, feat, size))
 
 
 class FlowOccNet(nn.Module):

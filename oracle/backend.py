@@ -44,6 +44,7 @@ PATCHES = {
     "compute_range_map": O.compute_range_map,
     "occlusion_from_flow": _occ_from_flow,
     "bias_leaky_relu": O.bias_leaky_relu,
+    "bias_add": O.bias_add,
 }
 
 

@@ -384,3 +384,58 @@ def test_bias_leaky_relu_full_size_and_errors(ops):
     with pytest.raises(RuntimeError):  # a strided view is not a convolution output: refused, not copied
         big = torch.zeros((2, 16, 8, 12), device=DEV)
         ops.bias_leaky_relu(big[:, :8], torch.zeros(8, device=DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,cl", [((2, 2, 33, 47), True), ((2, 1, 17, 30), True), ((2, 32, 9, 21), True), ((2, 2, 20, 31), False)])
+def test_bias_add_matches_reference(ops, shape, cl, dtype):
+    """bias_add == `x + bias` (nn.Conv2d / nn.ConvTranspose2d bias term): forward bit for bit, the input gradient IS the incoming
+    gradient, bias gradient = fp32 sum of it.  Two calls in a row check that the pooled zero accumulators are never reused."""
+    gen = torch.Generator().manual_seed(shape[1] * 11 + shape[3])
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    for rep in range(2):
+        x0 = torch.randn(shape, generator=gen)
+        b0 = torch.randn(shape[1], generator=gen)
+        go = torch.randn(shape, generator=gen).to(DEV).to(dtype).contiguous(memory_format=fmt)
+        xr = x0.to(DEV).to(dtype).contiguous(memory_format=fmt).requires_grad_()
+        br = b0.to(DEV).requires_grad_()
+        ref = O.bias_add(xr, br)
+        ref.backward(go)
+        x = x0.to(DEV).to(dtype).contiguous(memory_format=fmt).requires_grad_()
+        b = b0.to(DEV).requires_grad_()
+        out = ops.bias_add(x * 1, b)
+        assert torch.equal(out, ref)
+        out.backward(go)
+        assert torch.equal(x.grad, xr.grad)
+        exact = go.double().sum((0, 2, 3)).cpu().numpy()
+        n = shape[0] * shape[2] * shape[3]
+        np.testing.assert_allclose(b.grad.double().cpu().numpy(), exact, rtol=2e-5, atol=2e-5 * np.sqrt(n))
+
+
+def test_bias_epilogue_inside_graph_capture(ops):
+    """the pooled zero accumulators of the epilogue backward are re-zeroed by the graph they were captured in: replaying a
+    captured forward+backward three times gives the same bias gradient every time (an accumulator zeroed outside the capture
+    would keep growing)"""
+    gen = torch.Generator().manual_seed(9)
+    x0 = torch.randn((2, 32, 24, 40), generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(32, generator=gen).to(DEV).requires_grad_()
+    go = torch.randn((2, 32, 24, 40), generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    def run():
+        x = x0.clone(memory_format=torch.preserve_format).requires_grad_()
+        out = ops.bias_leaky_relu(x * 1, b, 0.1)
+        gx, gb = torch.autograd.grad(out, (x, b), go)
+        return gx, gb
+    ref_gx, ref_gb = run()       # eager: takes a slice of the eager pool, which the capture below must not continue
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gx, gb = run()
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gx, ref_gx)
+        np.testing.assert_allclose(gb.cpu().numpy(), ref_gb.cpu().numpy(), rtol=1e-5, atol=1e-4)
