@@ -54,6 +54,9 @@ def parse():
     p.add_argument("--fused-adam", type=int, default=1,
                    help="1 (default): run the module's Adam (models/flow_occ_model.py:77-78) through torch's fused multi-tensor "
                         "kernel -- same update rule, checked in tests/test_models_gpu.py::test_fused_adam_same_update; 0: foreach")
+    p.add_argument("--master-weights", type=int, default=1,
+                   help="1 (default): bf16 compute copies of the convolution weights refreshed from fp32 masters by one multi-tensor "
+                        "kernel per step instead of autocast's per-layer casts (same values; not with --graph 0 under DDP); 0: plain autocast")
     p.add_argument("--graph", type=int, default=-1,
                    help="1: capture the training step in hipGraphs and replay it (one GPU: forward+loss+backward+Adam in one graph; "
                         "several: forward+loss+backward graph, one eager all-reduce of the flat gradient buffer, Adam graph); "
@@ -77,7 +80,8 @@ def build_stepper(args, env, dp_mode="ddp"):
     torch.manual_seed(42)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
     return TrainStepper(build_module(args), env, amp_dtype=amp, channels_last=(args.layout == "cl"),
-                        fused_optimizer=bool(getattr(args, "fused_adam", 0)), dp_mode=dp_mode)
+                        fused_optimizer=bool(getattr(args, "fused_adam", 0)), dp_mode=dp_mode,
+                        master_weights=bool(getattr(args, "master_weights", 0)))
 
 
 def usable_cores() -> int:
@@ -282,7 +286,8 @@ def main():
                        "parallelism": f"dp{n}" + ("" if n == 1 else (" (flat all-reduce between graphs)" if use_graph else " (torch DDP)")),
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager",
                        "final_loss": round(loss_val, 5),
-                       "optimizer": "adam(fused)" if args.fused_adam else "adam(foreach)"},
+                       "optimizer": "adam(fused)" if args.fused_adam else "adam(foreach)",
+                       "weights": "fp32 masters + bf16 compute copies" if stepper._masters else "fp32 (autocast casts per use)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

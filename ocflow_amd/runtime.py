@@ -170,10 +170,16 @@ class TrainStepper:
     under bf16 autocast when `amp_dtype` is given (convs on MFMA via MIOpen, HIP ops bf16-in / fp32-accumulate)."""
 
     def __init__(self, module: torch.nn.Module, env: DistEnv, amp_dtype: Optional[torch.dtype] = torch.bfloat16,
-                 channels_last: bool = True, fused_optimizer: bool = False, dp_mode: str = "ddp"):
+                 channels_last: bool = True, fused_optimizer: bool = False, dp_mode: str = "ddp", master_weights: bool = False):
         """dp_mode (world_size > 1 only): "ddp" = torch DistributedDataParallel (bucketed all-reduce overlapped with the eager
         backward); "flat" = no DDP wrapper, gradients are averaged with ONE all-reduce of a flat fp32 buffer between backward
-        and the optimizer -- the mode `enable_graph` needs, because then nothing collective sits inside a captured graph."""
+        and the optimizer -- the mode `enable_graph` needs, because then nothing collective sits inside a captured graph.
+
+        master_weights (bf16 autocast only, not with "ddp" across ranks): the convolution weights the model computes with are
+        kept as bf16 tensors, refreshed from fp32 master copies (which the optimizer updates) by one multi-tensor kernel per
+        step.  Values are exactly autocast's -- it rounds the fp32 weight to bf16 at every use and widens the bf16 weight
+        gradient back to fp32 -- but as 2 multi-tensor launches instead of ~245 per-layer cast kernels (1.0 ms of a 17.6 ms
+        step).  `module_state_dict()` / `restore_fp32_weights()` give the fp32 view back."""
         if dp_mode not in ("ddp", "flat"):
             raise ValueError(f"dp_mode must be 'ddp' or 'flat', got {dp_mode!r}")
         self.env = env
@@ -197,10 +203,41 @@ class TrainStepper:
                     dist.broadcast(t, src=0)
         else:
             self.module = wrap_ddp(_StepAdapter(module), env)
+        self._masters = {}  # id(model parameter) -> fp32 master Parameter
+        if master_weights and self.amp_dtype == torch.bfloat16 and not (self.dp_mode == "ddp" and env.world_size > 1):
+            self._setup_master_weights()
+        self._manual = self.dp_mode == "flat" or bool(self._masters)  # gradients go through the flat buffer
         self._graph = None
         self._graph_opt = None
         self._graph_pool = None
         self._flat = None
+
+    # ---- fp32 masters / bf16 compute weights
+    def _setup_master_weights(self):
+        weights = [m.weight for m in self.raw.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
+        for p in weights:
+            if p.dtype != torch.float32 or id(p) in self._masters:
+                continue
+            self._masters[id(p)] = torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format))
+            p.data = p.data.to(torch.bfloat16)  # same strides (channels_last weights stay channels_last)
+        self._mw_model = [p for p in self.raw.parameters() if id(p) in self._masters]
+        self._mw_master = [self._masters[id(p)] for p in self._mw_model]
+        for g in self.optimizer.param_groups:  # the optimizer updates the masters
+            g["params"] = [self._masters.get(id(p), p) for p in g["params"]]
+
+    def module_state_dict(self):
+        """state_dict of the wrapped module with the fp32 master values in place of the bf16 compute weights"""
+        sd = self.raw.state_dict()
+        if self._masters:
+            by_id = {id(p): k for k, p in self.raw.named_parameters()}
+            for pid, m in self._masters.items():
+                sd[by_id[pid]] = m.detach().clone()
+        return sd
+
+    def restore_fp32_weights(self):
+        """put the fp32 masters back into the module (end of training with master_weights)"""
+        for p, m in zip(getattr(self, "_mw_model", []), getattr(self, "_mw_master", [])):
+            p.data = m.detach().clone(memory_format=torch.preserve_format)
 
     def prepare(self, batch):
         out = []
@@ -216,45 +253,64 @@ class TrainStepper:
             return self._replay(batch)
         return self._eager_step(batch, batch_idx)
 
-    # ---- the step in two halves: forward + loss + backward, then the optimizer; "flat" data parallelism averages the
-    # gradients between the two
+    # ---- the step in two halves: forward + loss + backward, then the optimizer; the "manual" path (flat data parallelism
+    # and/or master weights) moves the gradients through one flat fp32 buffer between the two
     def _forward_backward(self, batch, batch_idx: int = 0) -> torch.Tensor:
         # gradients are dropped, not zero-filled: backward then writes them instead of accumulating (one fill and one add
         # per parameter saved); inside a graph capture they are re-allocated from the graph's pool, so replays reuse them
-        self.optimizer.zero_grad(set_to_none=not getattr(self, "_static_grads", False))
+        self.raw.zero_grad(set_to_none=not getattr(self, "_static_grads", False))
         ctx = torch.autocast(self.env.device.type, dtype=self.amp_dtype) if self.amp_dtype is not None else nullcontext()
         with ctx:
             loss = self.module(batch, batch_idx)
-        if self.dp_mode == "flat":
+        if self.dp_mode == "flat" and self.env.world_size > 1:
             (loss / self.env.world_size).backward()  # sum over ranks of grad(loss / N) = DDP's averaged gradient
         else:
             loss.backward()
         return loss.detach()
 
     def _grad_params(self):
+        """model parameters that received a gradient, in a fixed order"""
         return [p for p in self.raw.parameters() if p.grad is not None]
 
     def _flat_views(self, params):
         """one fp32 buffer + per-parameter views with the parameters' own (dense, possibly channels_last) strides, so the
         multi-tensor copy and the fused optimizer take their fast paths"""
-        n = sum(p.numel() for p in params)
-        flat = torch.zeros(n, device=self.env.device, dtype=torch.float32)
+        pad = lambda n: (n + 63) & ~63  # 256-byte aligned views: the multi-tensor kernels only vectorise aligned operands
+        flat = torch.zeros(sum(pad(p.numel()) for p in params), device=self.env.device, dtype=torch.float32)
         views, off = [], 0
         for p in params:
             views.append(flat[off:off + p.numel()].as_strided(p.shape, p.stride()))
-            off += p.numel()
+            off += pad(p.numel())
         return flat, views
+
+    @staticmethod
+    def _gather(views, grads):
+        """views[i] <- grads[i] (fp32 <- fp32 or bf16): one multi-tensor copy per source dtype"""
+        for dt in (torch.float32, torch.bfloat16):
+            idx = [i for i, g in enumerate(grads) if g.dtype == dt]
+            if idx:
+                torch._foreach_copy_([views[i] for i in idx], [grads[i] for i in idx])
+
+    def _attach(self, params, views):
+        for p, v in zip(params, views):
+            self._masters.get(id(p), p).grad = v  # the optimizer's tensor for this parameter
+
+    def _optimizer_step(self):
+        self.optimizer.step()
+        if self._masters:
+            with torch.no_grad():
+                torch._foreach_copy_(self._mw_model, self._mw_master)  # bf16 compute weights <- updated fp32 masters
 
     def _eager_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         loss = self._forward_backward(batch, batch_idx)
-        if self.dp_mode == "flat":
+        if self._manual:
             params = self._grad_params()
             flat, views = self._flat_views(params)
-            torch._foreach_copy_(views, [p.grad for p in params])
-            dist.all_reduce(flat)
-            for p, v in zip(params, views):
-                p.grad = v
-        self.optimizer.step()
+            self._gather(views, [p.grad for p in params])
+            if self.dp_mode == "flat" and self.env.world_size > 1:
+                dist.all_reduce(flat)
+            self._attach(params, views)
+        self._optimizer_step()
         self.raw.global_step = getattr(self.raw, "global_step", 0) + 1
         return loss
 
@@ -291,11 +347,12 @@ class TrainStepper:
         torch.cuda.synchronize()
         self._static_grads = os.environ.get("OCFLOW_GRAPH_STATIC_GRADS", "0") == "1"
         graph = torch.cuda.CUDAGraph()
-        if self.dp_mode != "flat":
+        if not self._manual:
             with torch.cuda.graph(graph, pool=self._graph_pool):
                 self._static_loss = self._eager_step(self._static_batch, 0)
             self._graph = graph
             return self
+        split = self.dp_mode == "flat" and self.env.world_size > 1  # an all-reduce sits between backward and the optimizer
         params = self._grad_params()  # after the warm-up steps: exactly the parameters that reach the loss
         self._flat, views = self._flat_views(params)
         with torch.cuda.graph(graph, pool=self._graph_pool):
@@ -303,14 +360,18 @@ class TrainStepper:
             got = self._grad_params()
             if len(got) != len(params) or any(a is not b for a, b in zip(got, params)):
                 raise RuntimeError("TrainStepper.enable_graph: the set of parameters with gradients changed between steps")
-            torch._foreach_copy_(views, [p.grad for p in params])
-        dist.all_reduce(self._flat)  # keeps the replicas in step across the capture itself (the capture ran no kernels)
-        for p, v in zip(params, views):
-            p.grad = v
-        opt_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(opt_graph, pool=self._graph_pool):
-            self.optimizer.step()
-        self._graph, self._graph_opt = graph, opt_graph
+            self._gather(views, [p.grad for p in params])
+            if not split:
+                self._attach(params, views)
+                self._optimizer_step()
+        self._graph = graph
+        if split:
+            dist.all_reduce(self._flat)  # keeps the ranks' collective sequence aligned (the capture itself ran no kernels)
+            self._attach(params, views)
+            opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(opt_graph, pool=self._graph_pool):
+                self._optimizer_step()
+            self._graph_opt = opt_graph
         return self
 
     def _replay(self, batch) -> torch.Tensor:

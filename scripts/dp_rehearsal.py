@@ -17,7 +17,7 @@ env = init_distributed()
 for mode, graph in (("ddp", False), ("flat", False), ("flat", True)):
     torch.manual_seed(42)
     st = TrainStepper(bench.build_module(argparse.Namespace(model="flowoccnet")), env, amp_dtype=torch.bfloat16, channels_last=True,
-                      fused_optimizer=True, dp_mode=mode)
+                      fused_optimizer=True, dp_mode=mode, master_weights=(mode == "flat"))
     batch = st.prepare(synthetic_batch(a.batch, a.height, a.width, env.device, seed=42, index_offset=env.rank * a.batch))
     st.step(batch, 0)
     if graph:

@@ -14,7 +14,7 @@ use_repo_miopen_db()
 torch.cuda.set_device(0)
 env = DistEnv(device=torch.device("cuda", 0))
 torch.manual_seed(42)
-st = TrainStepper(bench.build_module(argparse.Namespace(model=a.model)), env, amp_dtype=torch.bfloat16, channels_last=True, fused_optimizer=True)
+st = TrainStepper(bench.build_module(argparse.Namespace(model=a.model)), env, amp_dtype=torch.bfloat16, channels_last=True, fused_optimizer=True, master_weights=bool(int(os.environ.get("MW", "1"))))
 batch = st.prepare(synthetic_batch(8, 436, 1024, env.device, seed=42))
 for i in range(26):
     st.step(batch, i)
