@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256) void corr_bwd_gather(T4 f1, T4 w2, T4 g, T4 g1
 // ------------------------------------------------------------------------------------------------
 constexpr int BTW = 16, BTH = 4, BNU = 4;
 
-template <typename T, bool G2, int D>
+// VEC = 16: whole 16-byte units (C % U == 0, 16-byte aligned pixels); VEC = 8: 8-byte granularity (pixel size a multiple of
+// 8 bytes, e.g. C = 196 bf16 = 392-byte pixels: two 8-byte accesses per unit, the last unit may be a half unit).
+template <typename T, bool G2, int D, int VEC>
 __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t, int B, int C, int H, int W, int tiles_x, int tiles_y,
                                                       int gvec) {
   constexpr int U = Unit<T>::U, ES = (int)sizeof(T);
@@ -367,8 +369,17 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
       const int xx = pos % HW, r = pos / HW;
       const int gy = ty0 - D + r, gx = tx0 - D + xx, c0 = cbase + uu * U;
       u32x4 v = zero4;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C)
-        v = *(const u32x4*)(other.p + ((long)b * other.sb + (long)gy * other.sh + (long)gx * other.sw + c0) * ES);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C) {
+        const char* src = other.p + ((long)b * other.sb + (long)gy * other.sh + (long)gx * other.sw + c0) * ES;
+        if (VEC == 16) {
+          v = *(const u32x4*)src;
+        } else {
+          const u32x2 lo = *(const u32x2*)src;
+          u32x2 hi = {0u, 0u};
+          if (c0 + U / 2 < C) hi = *(const u32x2*)(src + 8);
+          v = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
       s_op[(r * HW + xx) * BNU + uu] = v;
     }
     __syncthreads();
@@ -393,12 +404,19 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
     if (y < H && x < W && c0 < C) {
 #pragma unroll
       for (int j = 0; j < U; j++) acc[j] *= invC;
-      *(u32x4*)(gout_t.p + ((long)b * gout_t.sb + (long)y * gout_t.sh + (long)x * gout_t.sw + c0) * ES) = f_to_unit<T>(acc);
+      char* dstp = gout_t.p + ((long)b * gout_t.sb + (long)y * gout_t.sh + (long)x * gout_t.sw + c0) * ES;
+      const u32x4 o = f_to_unit<T>(acc);
+      if (VEC == 16) {
+        *(u32x4*)dstp = o;
+      } else {
+        *(u32x2*)dstp = u32x2{o[0], o[1]};
+        if (c0 + U / 2 < C) *(u32x2*)(dstp + 8) = u32x2{o[2], o[3]};
+      }
     }
   }
 }
 
-template <typename T, bool G2>
+template <typename T, bool G2, int VEC>
 static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, const ocf_tensor4* dst, int B, int C, int H, int W, int d,
                              hipStream_t st) {
   const int tx = (W + BTW - 1) / BTW, ty = (H + BTH - 1) / BTH;
@@ -410,10 +428,10 @@ static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, con
   const int gvec = g->sc == 1 && g->sw == nk && g->sh == (long)W * nk && ((uintptr_t)g->data % 8 == 0) && (g->sb * es) % 8 == 0 &&
                    ((nk % per == 0) || (W % per == 0 && (!G2 || d % per == 0) && BTW % per == 0));
   switch (d) {
-    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
-    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
-    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
-    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
   }
 }
 
@@ -482,8 +500,17 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
   if (g2) vec = vec && vec_ok<T>(g2);
   // tiled path: 16-byte units everywhere, whole units only, grad_out with unit channel stride
   if (vec && C % U == 0 && g->sc == 1) {
-    if (g1) launch_bwd_tiled<T, false>(w2, g, g1, B, C, H, W, d, st);
-    if (g2) launch_bwd_tiled<T, true>(f1, g, g2, B, C, H, W, d, st);
+    if (g1) launch_bwd_tiled<T, false, 16>(w2, g, g1, B, C, H, W, d, st);
+    if (g2) launch_bwd_tiled<T, true, 16>(f1, g, g2, B, C, H, W, d, st);
+    return launch_status();
+  }
+  // same kernel at 8-byte granularity: pixels that are a multiple of 8 bytes (C = 196 bf16 at the top pyramid level)
+  int v8 = min_vec(vec_width<T>(f1), vec_width<T>(w2));
+  if (g1) v8 = min_vec(v8, vec_width<T>(g1));
+  if (g2) v8 = min_vec(v8, vec_width<T>(g2));
+  if (v8 >= 8 && (C * (long)sizeof(T)) % 8 == 0 && g->sc == 1) {
+    if (g1) launch_bwd_tiled<T, false, 8>(w2, g, g1, B, C, H, W, d, st);
+    if (g2) launch_bwd_tiled<T, true, 8>(f1, g, g2, B, C, H, W, d, st);
     return launch_status();
   }
   const int nunits = (C + U - 1) / U;
