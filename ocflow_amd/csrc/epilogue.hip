@@ -169,7 +169,7 @@ static int bias_act_fwd_t(const T4& x, const float* bias, int B, int C, int H, i
     hipLaunchKernelGGL((bias_act_fwd_cl<T, 1>), dim3(grid), dim3(256), 0, st, (T*)x.p, bias, n, C, slope);
   } else if (lay == LAYOUT_NCHW) {
     const long HW = (long)H * W;
-    int chunks = (int)((HW + 4095) / 4096);
+    int chunks = (int)((HW + 2047) / 2048);
     const long blocks = (long)B * C * chunks;
     if (blocks > 0x7fffffffL) return OCF_EUNSUPPORTED;
     hipLaunchKernelGGL(bias_act_fwd_nchw<T>, dim3((unsigned)blocks), dim3(256), 0, st, (T*)x.p, bias, C, HW, chunks, slope);
@@ -201,7 +201,7 @@ static int bias_act_bwd_t(const T4& y, const T4& gy, const T4& gx, float* gbias,
       hipLaunchKernelGGL((bias_act_bwd_cl<T, 1, PASS>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
   } else {
     const long HW = (long)H * W;
-    int chunks = (int)((HW + 16383) / 16384);
+    int chunks = (int)((HW + 2047) / 2048);  // 8 elements per thread: these are 1- and 2-channel maps, parallelism comes from chunks
     const long blocks = (long)B * C * chunks;
     if (blocks > 0x7fffffffL) return OCF_EUNSUPPORTED;
     hipLaunchKernelGGL((bias_act_bwd_nchw<T, PASS>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias,
