@@ -181,6 +181,15 @@ def main():
     # re-runs the search (same throughput, measured), OCFLOW_MIOPEN_CAPTURE=<dir> regenerates the db.
     torch.backends.cudnn.benchmark = os.environ.get("OCFLOW_MIOPEN_FIND", "0") == "1"
 
+    if args.model in ("pwoc", "pwc"):
+        # the PWC-style pyramids need sides divisible by 64; the reference's datasets centre-crop to that (datasets.py:146-150)
+        from ocflow_amd.data.flow_io import render_size
+        h, w = render_size(args.height, args.width)
+        if (h, w) != (args.height, args.width):
+            if env.is_main:
+                print(f"[bench] model {args.model}: {args.height}x{args.width} cropped to the reference's render size {h}x{w}",
+                      file=sys.stderr, flush=True)
+            args.height, args.width = h, w
     use_graph = args.graph != 0
     # several ranks + graph replay: "flat" data parallelism (one all-reduce of a flat gradient buffer between two graphs);
     # eager: torch DDP (bucketed all-reduce overlapped with backward)

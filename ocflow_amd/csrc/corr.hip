@@ -359,10 +359,14 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
       }
     }
   }
+  // gridDim.y > 1: the channel blocks of a tile are spread over workgroups (small pyramid levels: too few tiles to fill the
+  // chip and a sequential channel loop per tile); each re-stages the grad_out slice, which is cheap at those sizes
   const int ncb = (C + BNU * U - 1) / (BNU * U);
-  for (int cb = 0; cb < ncb; cb++) {
+  const int cb_per = (ncb + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int cb_lo = (int)blockIdx.y * cb_per, cb_hi = min(ncb, cb_lo + cb_per);
+  for (int cb = cb_lo; cb < cb_hi; cb++) {
     const int cbase = cb * BNU * U;
-    if (cb > 0) __syncthreads();
+    if (cb > cb_lo) __syncthreads();
     // ---- stage the halo tile of the other operand for this channel block
     for (int it = tid; it < HH * HW * BNU; it += 256) {
       const int uu = it & (BNU - 1), pos = it >> 2;
@@ -420,7 +424,10 @@ template <typename T, bool G2, int VEC>
 static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, const ocf_tensor4* dst, int B, int C, int H, int W, int d,
                              hipStream_t st) {
   const int tx = (W + BTW - 1) / BTW, ty = (H + BTH - 1) / BTH;
-  const dim3 grid((unsigned)(B * tx * ty)), block(256);
+  const int ncb = (C + BNU * Unit<T>::U - 1) / (BNU * Unit<T>::U);
+  const int split = (B * tx * ty <= 128) ? ncb : 1;  // under half a tile per CU: one workgroup per (tile, channel block); measured
+                                                     // 81 -> 28 us and 60 -> 34 us (g1+g2) at the two top levels, slower from 224 tiles up
+  const dim3 grid((unsigned)(B * tx * ty), (unsigned)split), block(256);
   const int nk = (2 * d + 1) * (2 * d + 1);
   const long es = sizeof(T);
   // 8-byte vector staging of grad_out rows: dense channels_last, row starts 8-byte aligned ((gy*W + gx0)*nk*es % 8 == 0)
