@@ -12,6 +12,7 @@ accumulation); flow / occlusion / images of the losses are fp32.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -27,6 +28,7 @@ __all__ = [
 ]
 
 MAX_DISPLACEMENT = 4
+_FUSED_WARP = os.environ.get("OCFLOW_FUSED_WARP", "0") == "1"
 
 _KERNEL_TIMER = None
 
@@ -136,25 +138,35 @@ class _CorrWarpFn(Function):
         B, C_, H, W = f1.shape
         n = 2 * d + 1
         out = _empty_like_layout(f1, (B, n * n, H, W))
+        # with a flow: ocf_corr_fwd can gather the warped operand inside the correlation kernel (no warped tensor in HBM), but
+        # since the lane-per-unit warp kernel the two-launch form is faster at every pyramid level (level 2: 12.8 + 29.0 us vs
+        # 53.7 us fused; top level 4.9 + 14.0 vs 37.5) and backward needs the warped tensor anyway -- it is kept instead of
+        # being recomputed.  OCFLOW_FUSED_WARP=1 selects the single fused launch (same values: the fused kernel rounds the
+        # gathered operand to the feature dtype before the contraction, exactly what the materialised tensor holds).
+        w2 = None
+        if flow is not None and not _FUSED_WARP:
+            w2 = _warp_fwd_raw(f2, flow, flow_scale, align_corners)
+        op2, opflow = (f2, flow) if w2 is None else (w2, None)
+
         def launch():
             with torch.cuda.device(f1.device):
-                _lib.check(_lib.load().ocf_corr_fwd(_t4(f1), _t4(f2), _t4(flow), _t4(occ), _t4(out), B, C_, H, W, d,
+                _lib.check(_lib.load().ocf_corr_fwd(_t4(f1), _t4(op2), _t4(opflow), _t4(occ), _t4(out), B, C_, H, W, d,
                                                     float(flow_scale), int(bool(align_corners)), _dtype_code(f1),
                                                     _stream(f1)), "ocf_corr_fwd")
 
         if _KERNEL_TIMER is not None:
-            nbytes, flops = corr_fwd_algorithmic(B, C_, H, W, d, f1.element_size(), flow is not None, occ is not None)
+            nbytes, flops = corr_fwd_algorithmic(B, C_, H, W, d, f1.element_size(), opflow is not None, occ is not None)
             _KERNEL_TIMER.launch("corr_fwd", {"bytes": nbytes, "flops": flops, "shape": f"B{B}xC{C_}x{H}x{W}"}, launch)
         else:
             launch()
-        ctx.save_for_backward(f1, f2, flow, occ)
+        ctx.save_for_backward(f1, f2, flow, occ, w2)
         ctx.cfg = (d, float(flow_scale), bool(align_corners))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        f1, f2, flow, occ = ctx.saved_tensors
+        f1, f2, flow, occ, w2_saved = ctx.saved_tensors
         d, fs, ac = ctx.cfg
         B, C_, H, W = f1.shape
         need1, need2, needf, needo = ctx.needs_input_grad[:4]
@@ -165,8 +177,11 @@ class _CorrWarpFn(Function):
         # rows with 8-byte vectors only from a dense channels_last tensor -- one 36 MB copy is far cheaper than 2-byte staging.
         if _is_cl(f1) and not (gout.stride(1) == 1 and gout.stride(3) == gout.size(1) and gout.stride(2) == gout.size(1) * gout.size(3)):
             gout = gout.contiguous(memory_format=torch.channels_last)
-        # second operand of the plain correlation (recomputed: the fused forward never stored it)
-        w2 = _warp_fwd_raw(f2, flow, fs, ac) if flow is not None else f2
+        # second operand of the plain correlation (kept by the two-launch forward; recomputed after a fused forward)
+        if w2_saved is not None:
+            w2 = w2_saved
+        else:
+            w2 = _warp_fwd_raw(f2, flow, fs, ac) if flow is not None else f2
         w2o = w2 * occ.to(w2.dtype) if occ is not None else w2
         need_w2 = need2 or needf or needo
         g1 = _empty_like_layout(f1, f1.shape) if need1 else None

@@ -77,7 +77,10 @@ def test_corr_vs_oracle(ops, shape, d, dtype, cl):
 @pytest.mark.parametrize("ac", [False, True])
 @pytest.mark.parametrize("with_occ", [False, True])
 @pytest.mark.parametrize("cl", [False, True])
-def test_corr_warp_fused(ops, ac, with_occ, cl):
+@pytest.mark.parametrize("fused", [False, True])
+def test_corr_warp_fused(ops, ac, with_occ, cl, fused, monkeypatch):
+    """corr_warp with a flow, both forms: warp kernel + correlation kernel (default) and the single fused launch"""
+    monkeypatch.setattr(ops, "_FUSED_WARP", fused)
     gen = torch.Generator().manual_seed(5)
     B, C, H, W = 2, 24, 19, 37
     f1 = torch.randn((B, C, H, W), generator=gen).requires_grad_()
@@ -106,11 +109,12 @@ def test_corr_warp_fused(ops, ac, with_occ, cl):
                                       ((1, 40, 8, 32), 3), ((1, 16, 5, 5), 1)])
 @pytest.mark.parametrize("mode", ["occ", "warp", "warp+occ"])
 @pytest.mark.parametrize("layout", ["cl", "nchw", "view"])
-def test_corr_bf16_matrix_core_modes(ops, shape, d, mode, layout):
+def test_corr_bf16_matrix_core_modes(ops, shape, d, mode, layout, monkeypatch):
     """bf16 runs on the MFMA band-GEMM kernel (corr_mfma.hip): every staging mode (occlusion on the outputs, fused warp gather)
     x every layout (dense channels_last fast path, NCHW, strided channel slice) x single / multi channel block / partial last
     block (C=196, C=40) / d < 4, against the oracle on the same bf16-rounded inputs.  Tolerance 2e-2: bf16 output rounding
     (+ the warp's bf16 rounding of the gathered features in the fused mode)."""
+    monkeypatch.setattr(ops, "_FUSED_WARP", True)  # this test is about the kernel's staging modes: keep the warp inside it
     gen = torch.Generator().manual_seed((hash((shape, d, mode)) & 0xffff) + 1)
     B, C, H, W = shape
     f1 = torch.randn(shape, generator=gen).bfloat16()
@@ -136,6 +140,12 @@ def test_corr_bf16_matrix_core_modes(ops, shape, d, mode, layout):
     out = ops.corr_warp(lay(f1), lay(f2), None if flow is None else flow.to(DEV), None if occ is None else occ.to(DEV), d, 1.25, False)
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     close(out, ref, 2e-2)
+    if flow is not None and layout != "nchw":
+        # the default two-launch form (warp kernel, then the correlation kernel) produces the same cost volume bit for bit:
+        # both round the gathered operand to bf16 before the contraction
+        monkeypatch.setattr(ops, "_FUSED_WARP", False)
+        out2 = ops.corr_warp(lay(f1), lay(f2), flow.to(DEV), None if occ is None else occ.to(DEV), d, 1.25, False)
+        assert torch.equal(out2, out)
 
 
 def test_corr_bf16_output_into_concat_buffer(ops):
