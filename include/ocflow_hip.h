@@ -83,6 +83,16 @@ int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4
 int ocf_corr_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* gout, const ocf_tensor4* g1,
                  const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, void* stream);
 
+/* the same with the occlusion mask of the forward (out = corr(f1, w2 * occ), occ fp32 [B,1,H,W]) folded in: `w2` is the UNMASKED
+ * operand, the product w2*occ is formed while staging, g2 is the gradient w.r.t. w2 (= d/d(w2*occ) * occ) and
+ * gocc [B,1,H,W] fp32 dense (optional, zeroed by the launcher) receives sum_c d/d(w2*occ)[c] * w2[c].
+ * Only for layouts the LDS-tiled kernels take (channels_last, pixels a multiple of 8 bytes); otherwise OCF_EUNSUPPORTED and the
+ * caller composes it from ocf_corr_bwd and elementwise ops.
+ * replaces: autograd of `self.corr(f1, warped * occ)` flow_occ_net.py:167-168, cost_volume_flow_occ_net.py:204-206 */
+int ocf_corr_occ_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* occ, const ocf_tensor4* gout,
+                     const ocf_tensor4* g1, const ocf_tensor4* g2, const ocf_tensor4* gocc, int B, int C, int H, int W, int d,
+                     int dtype, void* stream);
+
 /* ---- K2  backward bilinear warp (zeros padding), both align_corners variants --------------
  * out[b,c,y,x] = bilinear(img[b,c], px, py), neighbours outside the image contribute 0
  *   align_corners=0: px = (x+s*u)*W/max(W-1,1) - 0.5, py likewise     (in-network feature warp)

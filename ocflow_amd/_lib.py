@@ -19,6 +19,7 @@ from . import build as _build
 
 OCF_F32, OCF_BF16 = 0, 1
 OCF_OK = 0
+OCF_EUNSUPPORTED = -2
 
 
 class Tensor4(C.Structure):
@@ -36,6 +37,7 @@ SIGNATURES = {
     "ocf_stream_capture_id": [_vp, C.POINTER(C.c_ulonglong)],
     "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ocf_corr_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_corr_occ_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_warp_fwd": [_T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ocf_warp_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ocf_photo_loss_fwd": [_T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _vp],

@@ -312,9 +312,15 @@ constexpr int BTW = 16, BTH = 4, BNU = 4;
 
 // VEC = 16: whole 16-byte units (C % U == 0, 16-byte aligned pixels); VEC = 8: 8-byte granularity (pixel size a multiple of
 // 8 bytes, e.g. C = 196 bf16 = 392-byte pixels: two 8-byte accesses per unit, the last unit may be a half unit).
+// Occlusion (forward was corr(f1, w2 * occ), occ [B,1,H,W] fp32; occ.p == nullptr: none):
+//   g1 pass (G2 = false): `other` is the UNMASKED w2; each staged halo unit is multiplied by occ of its pixel (the product
+//                         tensor w2*occ is never materialised),
+//   g2 pass (G2 = true):  acc is the gradient w.r.t. (w2*occ); the kernel stores acc * occ[q] (gradient w.r.t. w2) and, when
+//                         gocc.p != nullptr, adds sum_c acc[c] * w2[q][c] to gocc[q] (4 unit lanes of a pixel reduced by shuffle,
+//                         one fp32 atomic per pixel and channel block).  `w2own` = the unmasked w2 (read at the own pixel).
 template <typename T, bool G2, int D, int VEC>
-__global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t, int B, int C, int H, int W, int tiles_x, int tiles_y,
-                                                      int gvec) {
+__global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t, T4 occ, T4 w2own, T4 gocc, int B, int C, int H, int W,
+                                                      int tiles_x, int tiles_y, int gvec) {
   constexpr int U = Unit<T>::U, ES = (int)sizeof(T);
   constexpr int N = 2 * D + 1, NK = N * N;
   constexpr int HH = BTH + 2 * D, HW = BTW + 2 * D;
@@ -383,6 +389,14 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
           if (c0 + U / 2 < C) hi = *(const u32x2*)(src + 8);
           v = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
+        if (!G2 && occ.p) {
+          const float o = ((const float*)occ.p)[(long)b * occ.sb + (long)gy * occ.sh + (long)gx * occ.sw];
+          float f[U];
+          unit_to_f<T>(v, f);
+#pragma unroll
+          for (int j = 0; j < U; j++) f[j] = (float)(T)(f[j] * o);  // rounded like the materialised product w2 * occ
+          v = f_to_unit<T>(f);
+        }
       }
       s_op[(r * HW + xx) * BNU + uu] = v;
     }
@@ -405,9 +419,39 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
       }
     }
     const int c0 = cbase + u * U;
-    if (y < H && x < W && c0 < C) {
 #pragma unroll
-      for (int j = 0; j < U; j++) acc[j] *= invC;
+    for (int j = 0; j < U; j++) acc[j] *= invC;
+    if (G2 && occ.p) {
+      // all 4 unit lanes of a pixel take part in the shuffles; out-of-image / out-of-range lanes contribute 0
+      const bool live = y < H && x < W && c0 < C;
+      float o = 0.f, part = 0.f;
+      if (live) {
+        o = ((const float*)occ.p)[(long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw];
+        if (gocc.p) {
+          float f[U];
+          const char* src = w2own.p + ((long)b * w2own.sb + (long)y * w2own.sh + (long)x * w2own.sw + c0) * ES;
+          if (VEC == 16) {
+            unit_to_f<T>(*(const u32x4*)src, f);
+          } else {
+            const u32x2 lo = *(const u32x2*)src;
+            u32x2 hi = {0u, 0u};
+            if (c0 + U / 2 < C) hi = *(const u32x2*)(src + 8);
+            unit_to_f<T>(u32x4{lo[0], lo[1], hi[0], hi[1]}, f);
+          }
+          // the reference chain rounds the gradient w.r.t. (w2*occ) to the feature dtype before this product
+#pragma unroll
+          for (int j = 0; j < U; j++) part = __builtin_fmaf((float)(T)acc[j], f[j], part);
+        }
+      }
+      if (gocc.p) {
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        if (live && u == 0) atomicAdd((float*)gocc.p + ((long)b * gocc.sb + (long)y * gocc.sh + (long)x * gocc.sw), part);
+      }
+#pragma unroll
+      for (int j = 0; j < U; j++) acc[j] = (float)(T)acc[j] * o;
+    }
+    if (y < H && x < W && c0 < C) {
       char* dstp = gout_t.p + ((long)b * gout_t.sb + (long)y * gout_t.sh + (long)x * gout_t.sw + c0) * ES;
       const u32x4 o = f_to_unit<T>(acc);
       if (VEC == 16) {
@@ -422,7 +466,8 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
 
 template <typename T, bool G2, int VEC>
 static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, const ocf_tensor4* dst, int B, int C, int H, int W, int d,
-                             hipStream_t st) {
+                             hipStream_t st, const ocf_tensor4* occ = nullptr, const ocf_tensor4* w2own = nullptr,
+                             const ocf_tensor4* gocc = nullptr) {
   const int tx = (W + BTW - 1) / BTW, ty = (H + BTH - 1) / BTH;
   const int ncb = (C + BNU * Unit<T>::U - 1) / (BNU * Unit<T>::U);
   const int split = (B * tx * ty <= 128) ? ncb : 1;  // under half a tile per CU: one workgroup per (tile, channel block); measured
@@ -435,10 +480,10 @@ static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, con
   const int gvec = g->sc == 1 && g->sw == nk && g->sh == (long)W * nk && ((uintptr_t)g->data % 8 == 0) && (g->sb * es) % 8 == 0 &&
                    ((nk % per == 0) || (W % per == 0 && (!G2 || d % per == 0) && BTW % per == 0));
   switch (d) {
-    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
-    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
-    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
-    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), B, C, H, W, tx, ty, gvec); break;
+    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, gvec); break;
+    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, gvec); break;
+    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, gvec); break;
+    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, gvec); break;
   }
 }
 
@@ -500,15 +545,17 @@ static int corr_fwd_t(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_te
 
 template <typename T>
 static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* g, const ocf_tensor4* g1,
-                      const ocf_tensor4* g2, int B, int C, int H, int W, int d, hipStream_t st) {
+                      const ocf_tensor4* g2, int B, int C, int H, int W, int d, hipStream_t st, const ocf_tensor4* occ = nullptr,
+                      const ocf_tensor4* gocc = nullptr) {
   constexpr int U = Unit<T>::U;
+  if (gocc && hipMemsetAsync(gocc->data, 0, sizeof(float) * (size_t)B * H * W, st) != hipSuccess) return OCF_ELAUNCH;
   bool vec = vec_ok<T>(f1) && vec_ok<T>(w2);
   if (g1) vec = vec && vec_ok<T>(g1);
   if (g2) vec = vec && vec_ok<T>(g2);
   // tiled path: 16-byte units everywhere, whole units only, grad_out with unit channel stride
   if (vec && C % U == 0 && g->sc == 1) {
-    if (g1) launch_bwd_tiled<T, false, 16>(w2, g, g1, B, C, H, W, d, st);
-    if (g2) launch_bwd_tiled<T, true, 16>(f1, g, g2, B, C, H, W, d, st);
+    if (g1) launch_bwd_tiled<T, false, 16>(w2, g, g1, B, C, H, W, d, st, occ);
+    if (g2) launch_bwd_tiled<T, true, 16>(f1, g, g2, B, C, H, W, d, st, occ, w2, gocc);
     return launch_status();
   }
   // same kernel at 8-byte granularity: pixels that are a multiple of 8 bytes (C = 196 bf16 at the top pyramid level)
@@ -516,10 +563,11 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
   if (g1) v8 = min_vec(v8, vec_width<T>(g1));
   if (g2) v8 = min_vec(v8, vec_width<T>(g2));
   if (v8 >= 8 && (C * (long)sizeof(T)) % 8 == 0 && g->sc == 1) {
-    if (g1) launch_bwd_tiled<T, false, 8>(w2, g, g1, B, C, H, W, d, st);
-    if (g2) launch_bwd_tiled<T, true, 8>(f1, g, g2, B, C, H, W, d, st);
+    if (g1) launch_bwd_tiled<T, false, 8>(w2, g, g1, B, C, H, W, d, st, occ);
+    if (g2) launch_bwd_tiled<T, true, 8>(f1, g, g2, B, C, H, W, d, st, occ, w2, gocc);
     return launch_status();
   }
+  if (occ) return OCF_EUNSUPPORTED;  // the gather fallback has no occlusion path: the caller composes it from plain launches
   const int nunits = (C + U - 1) / U;
   const long total = (long)B * H * W * nunits;
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
@@ -559,5 +607,22 @@ extern "C" int ocf_corr_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OCF_F32) return ocf::corr_bwd_t<float>(f1, w2, gout, g1, g2, B, C, H, W, d, st);
   if (dtype == OCF_BF16) return ocf::corr_bwd_t<ocf::bf16>(f1, w2, gout, g1, g2, B, C, H, W, d, st);
+  return OCF_EINVAL;
+}
+
+/* occlusion-aware backward: see include/ocflow_hip.h */
+extern "C" int ocf_corr_occ_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* occ, const ocf_tensor4* gout,
+                                const ocf_tensor4* g1, const ocf_tensor4* g2, const ocf_tensor4* gocc, int B, int C, int H, int W, int d,
+                                int dtype, void* stream) {
+  ocf::clear_stale_error();
+  if (!f1 || !w2 || !occ || !gout || !f1->data || !w2->data || !occ->data || !gout->data) return OCF_EINVAL;
+  if ((g1 && !g1->data) || (g2 && !g2->data) || (gocc && !gocc->data) || (!g1 && !g2)) return OCF_EINVAL;
+  if (gocc && !g2) return OCF_EINVAL;  // the occlusion gradient is a by-product of the g2 pass
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
+  if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
+  if (gocc && !(gocc->sw == 1 && gocc->sh == W && gocc->sb == (long)H * W)) return OCF_EUNSUPPORTED;  // dense fp32 [B,1,H,W]
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OCF_F32) return ocf::corr_bwd_t<float>(f1, w2, gout, g1, g2, B, C, H, W, d, st, occ, gocc);
+  if (dtype == OCF_BF16) return ocf::corr_bwd_t<ocf::bf16>(f1, w2, gout, g1, g2, B, C, H, W, d, st, occ, gocc);
   return OCF_EINVAL;
 }

@@ -182,20 +182,39 @@ class _CorrWarpFn(Function):
             w2 = w2_saved
         else:
             w2 = _warp_fwd_raw(f2, flow, fs, ac) if flow is not None else f2
-        w2o = w2 * occ.to(w2.dtype) if occ is not None else w2
         need_w2 = need2 or needf or needo
         g1 = _empty_like_layout(f1, f1.shape) if need1 else None
-        gw = _empty_like_layout(w2o, w2o.shape) if need_w2 else None
-        if need1 or need_w2:
+        gw = gocc = None
+        fused_occ = False
+        if occ is not None and (need1 or need_w2):
+            # occlusion folded into the tiled kernels: w2*occ is formed while staging, gw comes back already multiplied by occ
+            # and the occlusion gradient is a by-product of the same pass (6 elementwise launches per level otherwise)
+            gw = _empty_like_layout(w2, w2.shape) if need_w2 else None
+            gocc = torch.empty((B, 1, H, W), device=f1.device, dtype=torch.float32) if (needo and need_w2) else None
+            occ32 = _f32(occ)
             with torch.cuda.device(f1.device):
-                _lib.check(_lib.load().ocf_corr_bwd(_t4(f1), _t4(w2o), _t4(gout), _t4(g1), _t4(gw), B, C_, H, W, d,
-                                                    _dtype_code(f1), _stream(f1)), "ocf_corr_bwd")
-        g2 = gflow = gocc = None
-        if need_w2:
-            if occ is not None:
+                st = _lib.load().ocf_corr_occ_bwd(_t4(f1), _t4(w2), _t4(occ32), _t4(gout), _t4(g1), _t4(gw), _t4(gocc), B, C_, H, W, d,
+                                                  _dtype_code(f1), _stream(f1))
+            if st == _lib.OCF_EUNSUPPORTED:
+                gw = gocc = None  # layout the tiled kernels do not take: compose it from the plain launches below
+            else:
+                _lib.check(st, "ocf_corr_occ_bwd")
+                fused_occ = True
+                if gocc is not None and occ.dtype != torch.float32:
+                    gocc = gocc.to(occ.dtype)
+        if not fused_occ:
+            w2o = w2 * occ.to(w2.dtype) if occ is not None else w2
+            gw = _empty_like_layout(w2o, w2o.shape) if need_w2 else None
+            if need1 or need_w2:
+                with torch.cuda.device(f1.device):
+                    _lib.check(_lib.load().ocf_corr_bwd(_t4(f1), _t4(w2o), _t4(gout), _t4(g1), _t4(gw), B, C_, H, W, d,
+                                                        _dtype_code(f1), _stream(f1)), "ocf_corr_bwd")
+            if need_w2 and occ is not None:
                 if needo:
                     gocc = (gw.float() * w2.float()).sum(dim=1, keepdim=True)
                 gw = gw * occ.to(gw.dtype)
+        g2 = gflow = None
+        if need_w2:
             if flow is not None:
                 if need2 or needf:
                     g2, gflow = _warp_bwd_raw(f2, flow, gw, fs, ac, need2, needf)

@@ -449,3 +449,32 @@ def test_bias_epilogue_inside_graph_capture(ops):
         torch.cuda.synchronize()
         assert torch.equal(gx, ref_gx)
         np.testing.assert_allclose(gb.cpu().numpy(), ref_gb.cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 21, 45), (1, 96, 12, 40), (1, 196, 7, 16), (2, 64, 9, 33)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [True, False])
+def test_corr_occlusion_backward(ops, shape, dtype, cl):
+    """out = corr(f1, f2 * occ) (flow_occ_net.py:167-168): gradients w.r.t. f1, f2 AND the occlusion map.  channels_last goes
+    through ocf_corr_occ_bwd (mask applied while staging, d/docc as a by-product of the g2 pass, split channel blocks at the
+    small shapes, 8-byte granularity at C=196); NCHW composes the same thing from ocf_corr_bwd + elementwise ops.  Reference:
+    fp32 autograd of the oracle on the same (rounded) inputs; bf16 gradients are written in bf16 => 2e-2 of the scale."""
+    gen = torch.Generator().manual_seed(shape[1] + 3)
+    f1 = torch.randn(shape, generator=gen).to(dtype)
+    f2 = torch.randn(shape, generator=gen).to(dtype)
+    occ = torch.rand((shape[0], 1, shape[2], shape[3]), generator=gen)
+    cot = torch.randn((shape[0], 81, shape[2], shape[3]), generator=gen).to(dtype)
+    a, b, o = f1.float().requires_grad_(), f2.float().requires_grad_(), occ.clone().requires_grad_()
+    ref = O.compute_cost_volume(a, b * o, 4)
+    g1r, g2r, gor = torch.autograd.grad(ref, (a, b, o), cot.float())
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    x = f1.to(DEV).contiguous(memory_format=fmt).requires_grad_()
+    y = f2.to(DEV).contiguous(memory_format=fmt).requires_grad_()
+    oc = occ.to(DEV).requires_grad_()
+    out = ops.corr_warp(x, y, None, oc, 4)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    close(out, ref, tol)
+    g1, g2, go = torch.autograd.grad(out, (x, y, oc), cot.to(DEV).contiguous(memory_format=fmt))
+    for got, want in ((g1, g1r), (g2, g2r), (go, gor)):
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=tol * 5, atol=tol * scale)
