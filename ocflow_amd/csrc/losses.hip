@@ -10,7 +10,8 @@
 namespace ocf {
 
 constexpr int LB = 256;
-constexpr int MAXC = 8;  // channels of the loss-side images (3 in the reference)
+// loops over the channel count: fully unrolled in the CT = 3 instantiations, left alone for a runtime count
+#define OCF_UNROLL_CT _Pragma("unroll 3")
 
 template <int NS>
 __device__ __forceinline__ void block_reduce_atomic(double (&v)[NS], double* sums) {
@@ -55,9 +56,11 @@ __device__ __forceinline__ PhotoPix photo_setup(const T4& img2, const T4& flow, 
   return p;
 }
 
+template <int CT>
 __global__ __launch_bounds__(LB) void photo_fwd_kernel(T4 img1, T4 img2, T4 flow, T4 occ, double* sums, int B, int C, int H,
                                                        int W, WarpGeom wg, long npix) {
-  double acc[2] = {0.0, 0.0};
+  // per-thread partial sums in fp32 (a thread visits at most a few dozen pixels), widened to fp64 for the block / grid reduction
+  float part[2] = {0.f, 0.f};
   const float* i1 = (const float*)img1.p;
   const float* i2 = (const float*)img2.p;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
@@ -69,23 +72,28 @@ __global__ __launch_bounds__(LB) void photo_fwd_kernel(T4 img1, T4 img2, T4 flow
     float e = 0.f;
     if (flow.p) {
       const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
-      for (int c = 0; c < C; c++) {
+      OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) {
+        // all four neighbour loads issued before the first use (select, not branch: a branch per tap serialises the loads)
+        float nb[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) nb[n] = p.off[n] >= 0 ? i2[p.off[n] + (long)c * img2.sc] : 0.f;
         float v = 0.f;
 #pragma unroll
-        for (int n = 0; n < 4; n++)
-          if (p.off[n] >= 0) v = __builtin_fmaf(p.w[n], i2[p.off[n] + (long)c * img2.sc], v);
+        for (int n = 0; n < 4; n++) v = __builtin_fmaf(p.w[n], nb[n], v);
         e += charb(v - i1[o1 + (long)c * img1.sc]);
       }
     } else {
       const long o2 = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
-      for (int c = 0; c < C; c++) e += charb(i2[o2 + (long)c * img2.sc] - i1[o1 + (long)c * img1.sc]);
+      OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) e += charb(i2[o2 + (long)c * img2.sc] - i1[o1 + (long)c * img1.sc]);
     }
-    acc[0] += (double)(e * vis);
-    acc[1] += (double)vis;
+    part[0] = __builtin_fmaf(e, vis, part[0]);
+    part[1] += vis;
   }
+  double acc[2] = {(double)part[0], (double)part[1]};
   block_reduce_atomic<2>(acc, sums);
 }
 
+template <int CT>
 __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow, T4 occ, const float* scale, T4 gflow,
                                                        T4 gpred, int B, int C, int H, int W, WarpGeom wg, long npix) {
   const float* i1 = (const float*)img1.p;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
     if (flow.p) {
       const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
       float gx = 0.f, gy = 0.f;
-      for (int c = 0; c < C; c++) {
+      OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) {
         float nb[4];
         float v = 0.f;
 #pragma unroll
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
       const long o2 = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
       float* gp = (float*)gpred.p;
       const long og = (long)b * gpred.sb + (long)y * gpred.sh + (long)x * gpred.sw;
-      for (int c = 0; c < C; c++) {
+      OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) {
         const float dlt = i2[o2 + (long)c * img2.sc] - i1[o1 + (long)c * img1.sc];
         gp[og + (long)c * gpred.sc] = k * dlt / charb(dlt);
       }
@@ -134,18 +142,23 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
 
 // ------------------------------------------------------------------------------------- smoothness
 // exp(-mean_c (alpha * (I[p+s] - I[p]))^2) for a step of `s` pixels along x (dirx) or y.
+// CT: compile-time channel count (3 = RGB, the only case the reference has: all 2*CT loads are issued together), 0 = runtime C
+template <int CT>
 __device__ __forceinline__ float edge_w(const float* im, long o, long step, long sc, int C, float alpha) {
+  const int n = CT ? CT : C;
   float m = 0.f;
-  for (int c = 0; c < C; c++) {
+#pragma unroll
+  for (int c = 0; c < n; c++) {
     const float d = alpha * (im[o + step + (long)c * sc] - im[o + (long)c * sc]);
     m = __builtin_fmaf(d, d, m);
   }
-  return expf(-m / (float)C);
+  return expf(-m / (float)n);
 }
 
+template <int CT>
 __global__ __launch_bounds__(LB) void smooth_fwd_kernel(T4 img, T4 flow, double* sums, int B, int C, int H, int W, float alpha,
                                                         long npix) {
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  float part[4] = {0.f, 0.f, 0.f, 0.f};  // fp32 per thread, fp64 across threads (see photo_fwd_kernel)
   const float* im = (const float*)img.p;
   const float* fl = (const float*)flow.p;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
@@ -155,72 +168,97 @@ __global__ __launch_bounds__(LB) void smooth_fwd_kernel(T4 img, T4 flow, double*
     const long oi = (long)b * img.sb + (long)y * img.sh + (long)x * img.sw;
     const long of = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
     if (x + 1 < W) {
-      const float w = edge_w(im, oi, img.sw, img.sc, C, alpha);
+      const float w = edge_w<CT>(im, oi, img.sw, img.sc, C, alpha);
       float s = 0.f;
       for (int f = 0; f < 2; f++) s += charb(fl[of + flow.sw + f * flow.sc] - fl[of + f * flow.sc]);
-      acc[0] += (double)(w * s);
+      part[0] = __builtin_fmaf(w, s, part[0]);
     }
     if (y + 1 < H) {
-      const float w = edge_w(im, oi, img.sh, img.sc, C, alpha);
+      const float w = edge_w<CT>(im, oi, img.sh, img.sc, C, alpha);
       float s = 0.f;
       for (int f = 0; f < 2; f++) s += charb(fl[of + flow.sh + f * flow.sc] - fl[of + f * flow.sc]);
-      acc[1] += (double)(w * s);
+      part[1] = __builtin_fmaf(w, s, part[1]);
     }
     if (x + 2 < W) {
-      const float w = edge_w(im, oi, 2 * img.sw, img.sc, C, alpha);
+      const float w = edge_w<CT>(im, oi, 2 * img.sw, img.sc, C, alpha);
       float s = 0.f;
       for (int f = 0; f < 2; f++) {
         const long o = of + f * flow.sc;
         s += charb((fl[o + 2 * flow.sw] - fl[o + flow.sw]) - (fl[o + flow.sw] - fl[o]));
       }
-      acc[2] += (double)(w * s);
+      part[2] = __builtin_fmaf(w, s, part[2]);
     }
     if (y + 2 < H) {
-      const float w = edge_w(im, oi, 2 * img.sh, img.sc, C, alpha);
+      const float w = edge_w<CT>(im, oi, 2 * img.sh, img.sc, C, alpha);
       float s = 0.f;
       for (int f = 0; f < 2; f++) {
         const long o = of + f * flow.sc;
         s += charb((fl[o + 2 * flow.sh] - fl[o + flow.sh]) - (fl[o + flow.sh] - fl[o]));
       }
-      acc[3] += (double)(w * s);
+      part[3] = __builtin_fmaf(w, s, part[3]);
     }
   }
+  double acc[4] = {(double)part[0], (double)part[1], (double)part[2], (double)part[3]};
   block_reduce_atomic<4>(acc, sums);
 }
 
 // phi(p) = w1(p) * d/charb(d), d = F[p+1]-F[p]           (defined for 0 <= p < n-1)
 // psi(p) = w2(p) * dd/charb(dd), dd = F[p+2]-2F[p+1]+F[p]  (defined for 0 <= p < n-2)
 // dL/dF[p] = c1*(phi(p-1) - phi(p)) + c2*(psi(p-2) - 2 psi(p-1) + psi(p))
-__device__ __forceinline__ float smooth_axis_grad(const float* im, const float* fl, long oi, long of, long istep, long isc,
-                                                  long fstep, int C, float alpha, int p, int n, float c1, float c2) {
-  float g = 0.f;
+// both flow channels at once: the edge weights depend on the image only
+template <int CT>
+__device__ __forceinline__ void smooth_axis_grad(const float* im, const float* fl, long oi, long of, long fsc, long istep, long isc,
+                                                 long fstep, int C, float alpha, int p, int n, float c1, float c2, float* g) {
   if (c1 != 0.f) {
     if (p >= 1) {
-      const float d = fl[of] - fl[of - fstep];
-      g += c1 * edge_w(im, oi - istep, istep, isc, C, alpha) * d / charb(d);
+      const float w = c1 * edge_w<CT>(im, oi - istep, istep, isc, C, alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const float d = fl[of + f * fsc] - fl[of + f * fsc - fstep];
+        g[f] += w * d / charb(d);
+      }
     }
     if (p + 1 < n) {
-      const float d = fl[of + fstep] - fl[of];
-      g -= c1 * edge_w(im, oi, istep, isc, C, alpha) * d / charb(d);
+      const float w = c1 * edge_w<CT>(im, oi, istep, isc, C, alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const float d = fl[of + f * fsc + fstep] - fl[of + f * fsc];
+        g[f] -= w * d / charb(d);
+      }
     }
   }
   if (c2 != 0.f) {
     if (p >= 2) {
-      const float d = (fl[of] - fl[of - fstep]) - (fl[of - fstep] - fl[of - 2 * fstep]);
-      g += c2 * edge_w(im, oi - 2 * istep, 2 * istep, isc, C, alpha) * d / charb(d);
+      const float w = c2 * edge_w<CT>(im, oi - 2 * istep, 2 * istep, isc, C, alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const long o = of + f * fsc;
+        const float d = (fl[o] - fl[o - fstep]) - (fl[o - fstep] - fl[o - 2 * fstep]);
+        g[f] += w * d / charb(d);
+      }
     }
     if (p >= 1 && p + 1 < n) {
-      const float d = (fl[of + fstep] - fl[of]) - (fl[of] - fl[of - fstep]);
-      g -= 2.f * c2 * edge_w(im, oi - istep, 2 * istep, isc, C, alpha) * d / charb(d);
+      const float w = 2.f * c2 * edge_w<CT>(im, oi - istep, 2 * istep, isc, C, alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const long o = of + f * fsc;
+        const float d = (fl[o + fstep] - fl[o]) - (fl[o] - fl[o - fstep]);
+        g[f] -= w * d / charb(d);
+      }
     }
     if (p + 2 < n) {
-      const float d = (fl[of + 2 * fstep] - fl[of + fstep]) - (fl[of + fstep] - fl[of]);
-      g += c2 * edge_w(im, oi, 2 * istep, isc, C, alpha) * d / charb(d);
+      const float w = c2 * edge_w<CT>(im, oi, 2 * istep, isc, C, alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const long o = of + f * fsc;
+        const float d = (fl[o + 2 * fstep] - fl[o + fstep]) - (fl[o + fstep] - fl[o]);
+        g[f] += w * d / charb(d);
+      }
     }
   }
-  return g;
 }
 
+template <int CT>
 __global__ __launch_bounds__(LB) void smooth_bwd_kernel(T4 img, T4 flow, const float* coef, T4 gflow, int B, int C, int H, int W,
                                                         float alpha, long npix) {
   const float* im = (const float*)img.p;
@@ -234,35 +272,59 @@ __global__ __launch_bounds__(LB) void smooth_bwd_kernel(T4 img, T4 flow, const f
     const long oi = (long)b * img.sb + (long)y * img.sh + (long)x * img.sw;
     const long of = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
     const long og = (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
-    for (int f = 0; f < 2; f++) {
-      float g = smooth_axis_grad(im, fl, oi, of + f * flow.sc, img.sw, img.sc, flow.sw, C, alpha, x, W, cx1, cx2);
-      g += smooth_axis_grad(im, fl, oi, of + f * flow.sc, img.sh, img.sc, flow.sh, C, alpha, y, H, cy1, cy2);
-      gf[og + f * gflow.sc] = g;
-    }
+    float g[2] = {0.f, 0.f};
+    smooth_axis_grad<CT>(im, fl, oi, of, flow.sc, img.sw, img.sc, flow.sw, C, alpha, x, W, cx1, cx2, g);
+    smooth_axis_grad<CT>(im, fl, oi, of, flow.sc, img.sh, img.sc, flow.sh, C, alpha, y, H, cy1, cy2, g);
+    gf[og] = g[0];
+    gf[og + gflow.sc] = g[1];
   }
 }
 
 // -------------------------------------------------------------------------------------- range map
-__global__ __launch_bounds__(LB) void range_splat_kernel(T4 flow, float* range, int B, int H, int W, long npix) {
+// One workgroup = a 32x8 tile of SOURCE pixels.  Their four bilinear targets are accumulated in an LDS window (tile + RSR pixels
+// on every side) with ds_add_f32 and the window is flushed with one global atomic per touched target: a smooth flow sends the
+// 1024 contributions of a tile to ~300-500 distinct targets, so the global float-atomic count -- the bound of this kernel --
+// drops 2-3x (199 -> ~90 us at 8 x 436 x 1024).  Targets outside the window (|flow| > RSR) go straight to global memory.
+constexpr int RSW = 32, RSH = 8, RSR = 8, RWW = RSW + 2 * RSR + 1, RWH = RSH + 2 * RSR + 1;
+__global__ __launch_bounds__(LB) void range_splat_kernel(T4 flow, float* range, int B, int H, int W, int tiles_x, int tiles_y) {
+  __shared__ float win[RWH * RWW];
   const float* fl = (const float*)flow.p;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
-    const int x = idx % W;
-    long r = idx / W;
-    const int y = r % H, b = r / H;
+  const int tile = blockIdx.x;
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi, trem = tile - b * tpi;
+  const int ty0 = (trem / tiles_x) * RSH, tx0 = (trem % tiles_x) * RSW;
+  for (int i = threadIdx.x; i < RWH * RWW; i += LB) win[i] = 0.f;
+  __syncthreads();
+  const int x = tx0 + (threadIdx.x & (RSW - 1)), y = ty0 + (threadIdx.x >> 5);
+  float* dst = range + (long)b * H * W;
+  if (x < W && y < H) {
     const long fo = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
     const float cx = (float)x + fl[fo], cy = (float)y + fl[fo + flow.sc];
-    if (!(cx == cx) || !(cy == cy)) continue;
-    float fx = floorf(cx), fy = floorf(cy);
-    const float rx = cx - fx, ry = cy - fy;
-    fx = fminf(fmaxf(fx, -2.f), (float)W + 1.f);
-    fy = fminf(fmaxf(fy, -2.f), (float)H + 1.f);
-    const int x0 = (int)fx, y0 = (int)fy;
-    float* dst = range + (long)b * H * W;
+    if (cx == cx && cy == cy) {
+      float fx = floorf(cx), fy = floorf(cy);
+      const float rx = cx - fx, ry = cy - fy;
+      fx = fminf(fmaxf(fx, -2.f), (float)W + 1.f);
+      fy = fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+      const int x0 = (int)fx, y0 = (int)fy;
 #pragma unroll
-    for (int n = 0; n < 4; n++) {
-      const int di = n & 1, dj = n >> 1;
-      const int tx = x0 + di, ty = y0 + dj;
-      if (tx >= 0 && tx < W && ty >= 0 && ty < H) atomicAdd(dst + (long)ty * W + tx, (di ? rx : 1.f - rx) * (dj ? ry : 1.f - ry));
+      for (int n = 0; n < 4; n++) {
+        const int di = n & 1, dj = n >> 1;
+        const int tx = x0 + di, ty = y0 + dj;
+        if (tx >= 0 && tx < W && ty >= 0 && ty < H) {
+          const float w = (di ? rx : 1.f - rx) * (dj ? ry : 1.f - ry);
+          const int wx = tx - (tx0 - RSR), wy = ty - (ty0 - RSR);
+          if (wx >= 0 && wx < RWW && wy >= 0 && wy < RWH) atomicAdd(&win[wy * RWW + wx], w);
+          else atomicAdd(dst + (long)ty * W + tx, w);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RWH * RWW; i += LB) {
+    const float v = win[i];
+    if (v != 0.f) {
+      const int wy = i / RWW, wx = i - wy * RWW;
+      atomicAdd(dst + (long)(ty0 - RSR + wy) * W + (tx0 - RSR + wx), v);  // in range by construction: only in-image targets were added
     }
   }
 }
@@ -340,6 +402,12 @@ static inline int rgrid(long n) {
   long blocks = (n + LB - 1) / LB;
   return (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
 }
+// kernels that end in block_reduce_atomic: every block issues its fp64 atomics to the SAME few addresses, which the L2
+// serialises -- 4096 blocks cost more in the tail than the streaming pass itself (photo fwd 88 us vs 46 us for its backward)
+static inline int rgrid_reduce(long n) {
+  long blocks = (n + LB - 1) / LB;
+  return (int)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks));
+}
 
 }  // namespace ocf
 
@@ -354,8 +422,12 @@ extern "C" int ocf_photo_loss_fwd(const ocf_tensor4* img1, const ocf_tensor4* im
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, 2 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(photo_fwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, mk(img1), mk(img2), mk(flow), mk(occ), sums, B, C, H,
-                     W, WarpGeom(H, W, 1), npix);
+  if (C == 3)
+    hipLaunchKernelGGL(photo_fwd_kernel<3>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img1), mk(img2), mk(flow), mk(occ), sums, B, C,
+                       H, W, WarpGeom(H, W, 1), npix);
+  else
+    hipLaunchKernelGGL(photo_fwd_kernel<0>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img1), mk(img2), mk(flow), mk(occ), sums, B, C,
+                       H, W, WarpGeom(H, W, 1), npix);
   return launch_status();
 }
 
@@ -369,8 +441,12 @@ extern "C" int ocf_photo_loss_bwd(const ocf_tensor4* img1, const ocf_tensor4* im
   if (flow && gpred) return OCF_EUNSUPPORTED; /* grad w.r.t. the un-warped image through the fused warp */
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(photo_bwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
-                     mk(occ), scale, mk(gflow), mk(gpred), B, C, H, W, WarpGeom(H, W, 1), npix);
+  if (C == 3)
+    hipLaunchKernelGGL(photo_bwd_kernel<3>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
+                       mk(occ), scale, mk(gflow), mk(gpred), B, C, H, W, WarpGeom(H, W, 1), npix);
+  else
+    hipLaunchKernelGGL(photo_bwd_kernel<0>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
+                       mk(occ), scale, mk(gflow), mk(gpred), B, C, H, W, WarpGeom(H, W, 1), npix);
   return launch_status();
 }
 
@@ -382,7 +458,10 @@ extern "C" int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* fl
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, 4 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
+  if (C == 3)
+    hipLaunchKernelGGL(smooth_fwd_kernel<3>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
+  else
+    hipLaunchKernelGGL(smooth_fwd_kernel<0>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
   return launch_status();
 }
 
@@ -392,8 +471,12 @@ extern "C" int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* fl
   if (!img || !flow || !coef || !gflow || !img->data || !flow->data || !gflow->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(smooth_bwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
-                     B, C, H, W, alpha, npix);
+  if (C == 3)
+    hipLaunchKernelGGL(smooth_bwd_kernel<3>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
+                       B, C, H, W, alpha, npix);
+  else
+    hipLaunchKernelGGL(smooth_bwd_kernel<0>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
+                       B, C, H, W, alpha, npix);
   return launch_status();
 }
 
@@ -404,7 +487,9 @@ extern "C" int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, 
   hipStream_t st = (hipStream_t)stream;
   const long npix = (long)B * H * W;
   if (hipMemsetAsync(range, 0, npix * sizeof(float), st) != hipSuccess) return OCF_ELAUNCH;
-  hipLaunchKernelGGL(range_splat_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, mk(flow), range, B, H, W, npix);
+  const int tiles_x = (W + RSW - 1) / RSW, tiles_y = (H + RSH - 1) / RSH;
+  if ((long)B * tiles_x * tiles_y > 0x7fffffffL) return OCF_EUNSUPPORTED;
+  hipLaunchKernelGGL(range_splat_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(LB), 0, st, mk(flow), range, B, H, W, tiles_x, tiles_y);
   if (occ) hipLaunchKernelGGL(occ_from_range_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, (const float*)range, occ, npix);
   return launch_status();
 }

@@ -58,15 +58,67 @@ int main(int argc, char** argv) {
     float b = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
     float c = time_us([&] { ocf_corr_fwd(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, 1.25f, 0, dt, st); }, st);
     float d = time_us([&] { ocf_warp_fwd(&t2, &tf, &tg1, B, C, H, W, 1.25f, 0, dt, st); }, st);
+    ocf_tensor4 tgo = mkt(gflow, B, 1, H, W, false);  // d/docc written into the gflow scratch buffer
     float e = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
+    float e2 = time_us([&] { ocf_corr_occ_bwd(&t1, &t2, &tc, &to, &tg1, &tg2, &tgo, B, C, H, W, 4, dt, st); }, st, 50);
     float f = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, st); }, st, 50);
     double px = (double)np, bytes_plain = px * (2.0 * C * es + 81.0 * es);
-    printf("%3dx%3dx%4d | corr %7.1f us %6.0f GB/s | +occ %7.1f us %6.0f | fused %7.1f us %6.0f | warp %6.1f us %6.0f | corr_bwd %7.1f us %6.0f | warp_bwd %7.1f us\n",
+    printf("%3dx%3dx%4d | corr %7.1f us %6.0f GB/s | +occ %7.1f us %6.0f | fused %7.1f us %6.0f | warp %6.1f us %6.0f | corr_bwd %7.1f us %6.0f | +occ %7.1f us | warp_bwd %7.1f us %6.0f\n",
            C, H, W, a, bytes_plain / a / 1e3, b, (bytes_plain + px * 4) / b / 1e3, c, (bytes_plain + px * 12) / c / 1e3, d, px * (2.0 * C * es + 8) / d / 1e3,
-           e, px * (4.0 * C * es + 81.0 * es) / e / 1e3, f);
+           e, px * (4.0 * C * es + 81.0 * es) / e / 1e3, e2, f, px * (2.0 * C * es + 4.0 * C + 16) / f / 1e3);
     tb += bytes_plain + px * 4; tt += b;
     for (void* p : {f1, f2, out, g1, g2, flow, occ, gimg, gflow}) CK(hipFree(p));
   }
   printf("corr+occ all levels: %.1f MB in %.1f us = %.0f GB/s (%.1f%% of 8 TB/s)\n", tb / 1e6, tt, tb / tt / 1e3, tb / tt / 1e3 / 80.0);
+
+  // ---- loss kernels at the full image size (B x 3 x 436 x 1024 fp32 images, flow [B,2,..], occlusion [B,1,..]); GB/s = algorithmic
+  // bytes per pixel of DESIGN.md section 4 / time
+  {
+    const int C = 3, H = 436, W = 1024;
+    const size_t np = (size_t)B * H * W;
+    float *i1, *i2, *fl, *oc, *gfl, *rng, *coef; double* sums;
+    CK(hipMalloc(&i1, np * C * 4)); CK(hipMalloc(&i2, np * C * 4)); CK(hipMalloc(&fl, np * 8)); CK(hipMalloc(&oc, np * 4)); CK(hipMalloc(&gfl, np * 8));
+    CK(hipMalloc(&rng, np * 4)); CK(hipMalloc(&coef, 16)); CK(hipMalloc(&sums, 64 * sizeof(double)));
+    std::vector<float> h(np * C);
+    for (size_t i = 0; i < np * C; i++) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+    CK(hipMemcpy(i1, h.data(), np * C * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(i2, h.data() , np * C * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < np * 2; i++) h[i] = (float)((i * 40503u) % 4001) / 1000.f - 2.f;
+    CK(hipMemcpy(fl, h.data(), np * 8, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < np; i++) h[i] = (float)((i * 9973u) % 1000) / 1000.f;
+    CK(hipMemcpy(oc, h.data(), np * 4, hipMemcpyHostToDevice));
+    const float hc[4] = {1e-6f, 1e-6f, 1e-6f, 1e-6f};
+    CK(hipMemcpy(coef, hc, 16, hipMemcpyHostToDevice));
+    ocf_tensor4 t1 = mkt(i1, B, C, H, W, false), t2 = mkt(i2, B, C, H, W, false), tf = mkt(fl, B, 2, H, W, false), to = mkt(oc, B, 1, H, W, false),
+                tg = mkt(gfl, B, 2, H, W, false);
+    const double px = (double)np;
+    float a = time_us([&] { ocf_photo_loss_fwd(&t1, &t2, &tf, &to, sums, B, C, H, W, st); }, st, 50);
+    float b = time_us([&] { ocf_photo_loss_bwd(&t1, &t2, &tf, &to, coef, &tg, nullptr, B, C, H, W, st); }, st, 50);
+    float c = time_us([&] { ocf_smooth_loss_fwd(&t1, &tf, sums, B, C, H, W, 100.f, st); }, st, 50);
+    float d = time_us([&] { ocf_smooth_loss_bwd(&t1, &tf, coef, &tg, B, C, H, W, 100.f, st); }, st, 50);
+    float e = time_us([&] { ocf_range_map(&tf, rng, oc, B, H, W, st); }, st, 50);
+    float f = time_us([&] { ocf_ssim_fwd(&t1, &t2, sums, B, C, H, W, 11, st); }, st, 20);
+    float ms16 = time_us([&] { CK(hipMemsetAsync(sums, 0, 16, st)); }, st, 200);
+    float ms14m = time_us([&] { CK(hipMemsetAsync(rng, 0, np * 4, st)); }, st, 50);
+    printf("hipMemsetAsync back-to-back on the stream: 16 B %5.1f us, %zu MB %5.1f us\n", ms16, np * 4 >> 20, ms14m);
+    printf("losses %dx3x%dx%d fp32 | photo fwd %6.1f us %5.0f GB/s  bwd %6.1f us %5.0f | smooth fwd %6.1f us %5.0f  bwd %6.1f us %5.0f | range map %6.1f us %5.0f | ssim(11) %7.1f us\n",
+           B, H, W, a, px * 36 / a / 1e3, b, px * 44 / b / 1e3, c, px * 20 / c / 1e3, d, px * 28 / d / 1e3, e, px * 16 / e / 1e3, f);
+    for (void* p : {(void*)i1, (void*)i2, (void*)fl, (void*)oc, (void*)gfl, (void*)rng, (void*)coef, (void*)sums}) CK(hipFree(p));
+  }
+  // ---- convolution epilogue at the level-2 decoder shapes (bf16 channels_last): in-place bias + LeakyReLU and its backward
+  if (bf && cl) {
+    const int H = 109, W = 256;
+    for (int C : {128, 96, 64, 32}) {
+      const size_t n = (size_t)B * C * H * W;
+      void *x, *gy, *gx; float *bias, *gb;
+      CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&gy, n * 2)); CK(hipMalloc(&gx, n * 2)); CK(hipMalloc(&bias, C * 4)); CK(hipMalloc(&gb, C * 4));
+      CK(hipMemset(x, 0x3c, n * 2)); CK(hipMemset(gy, 0x3c, n * 2)); CK(hipMemset(bias, 0, C * 4));
+      ocf_tensor4 tx = mkt(x, B, C, H, W, true), tgy = mkt(gy, B, C, H, W, true), tgx = mkt(gx, B, C, H, W, true);
+      float a = time_us([&] { ocf_bias_act_fwd(&tx, bias, B, C, H, W, 0.1f, OCF_BF16, st); }, st, 100);
+      float b = time_us([&] { ocf_bias_act_bwd(&tx, &tgy, &tgx, gb, B, C, H, W, 0.1f, 0, OCF_BF16, st); }, st, 100);
+      printf("epilogue %dx%dx%dx%d bf16 | bias+lrelu fwd %6.1f us %5.0f GB/s | bwd (+bias grad) %6.1f us %5.0f GB/s\n", B, C, H, W, a, n * 4.0 / a / 1e3, b,
+             n * 6.0 / b / 1e3);
+      for (void* p : {x, gy, gx, (void*)bias, (void*)gb}) CK(hipFree(p));
+    }
+  }
   return 0;
 }
