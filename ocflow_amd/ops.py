@@ -247,6 +247,9 @@ def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flo
         if occ.shape[0] != B or occ.shape[2:] != features1.shape[2:]:
             raise ValueError("occ must be [B,1,H,W] matching the features")
     f1, f2 = _features(features1, features2)
+    if f1.numel() == 0:  # empty batch / empty map: what the reference's pad-and-shift loop returns, without a launch
+        n = 2 * d + 1
+        return (f1.sum() + f2.sum()) * 0 + f1.new_zeros((B, n * n, H, W))
     return _CorrWarpFn.apply(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners)
 
 
@@ -286,6 +289,8 @@ def warp(img, flow, align_corners=False, flow_scale=1.0):
         raise ValueError("flow must be [B,2,H,W] matching img")
     _require_hip(img, flow)
     (x,) = _features(img)
+    if x.numel() == 0:  # empty batch: grid_sample of nothing
+        return x * 1
     return _WarpFn.apply(x, _f32(flow), flow_scale, align_corners)
 
 

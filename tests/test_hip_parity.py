@@ -478,3 +478,15 @@ def test_corr_occlusion_backward(ops, shape, dtype, cl):
     for got, want in ((g1, g1r), (g2, g2r), (go, gor)):
         scale = float(want.abs().max())
         np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=tol * 5, atol=tol * scale)
+
+
+def test_empty_batch(ops):
+    """an empty batch goes through like in the reference (torch ops on empty tensors): empty outputs, no launch, no error"""
+    f = torch.zeros((0, 32, 12, 20), device=DEV, requires_grad=True)
+    fl = torch.zeros((0, 2, 12, 20), device=DEV)
+    out = ops.compute_cost_volume(f, f, 4)
+    assert out.shape == (0, 81, 12, 20)
+    out.sum().backward()
+    assert f.grad.shape == f.shape
+    assert ops.warp(f, fl).shape == f.shape
+    assert ops.corr_warp(f, f, fl, None, 4).shape == (0, 81, 12, 20)
