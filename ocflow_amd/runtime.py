@@ -258,7 +258,7 @@ class TrainStepper:
     def _forward_backward(self, batch, batch_idx: int = 0) -> torch.Tensor:
         # gradients are dropped, not zero-filled: backward then writes them instead of accumulating (one fill and one add
         # per parameter saved); inside a graph capture they are re-allocated from the graph's pool, so replays reuse them
-        self.raw.zero_grad(set_to_none=not getattr(self, "_static_grads", False))
+        self.raw.zero_grad(set_to_none=True)
         ctx = torch.autocast(self.env.device.type, dtype=self.amp_dtype) if self.amp_dtype is not None else nullcontext()
         with ctx:
             loss = self.module(batch, batch_idx)
@@ -345,7 +345,6 @@ class TrainStepper:
                 self._eager_step(self._static_batch, i)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._static_grads = os.environ.get("OCFLOW_GRAPH_STATIC_GRADS", "0") == "1"
         graph = torch.cuda.CUDAGraph()
         if not self._manual:
             with torch.cuda.graph(graph, pool=self._graph_pool):
