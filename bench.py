@@ -198,8 +198,17 @@ def main():
     batch = stepper.prepare(synthetic_batch(B, args.height, args.width, env.device, seed=42, index_offset=env.rank * B))
 
     t_w = time.perf_counter()
+    def avg_step_seconds(n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            stepper.step(batch)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
     if use_graph:
         stepper.step(batch)  # lazy initialisation (kernel JIT / db loads) must not happen inside a capture
+        t_eager = avg_step_seconds(4)
         failure = None
         try:
             stepper.enable_graph(batch)
@@ -218,6 +227,15 @@ def main():
             batch = stepper.prepare(synthetic_batch(B, args.height, args.width, env.device, seed=42, index_offset=env.rank * B))
         else:
             batch = stepper._static_batch
+            # sanity gate: replay must not be slower than the eager loop it replaces (it is ~20 % faster on one GPU).  Multi-GPU
+            # replay cannot be rehearsed on the one-GPU development box (two ranks sharing a GPU replay pathologically slowly),
+            # so the decision is taken here, on the machine being measured, by all ranks together.
+            t_graph = avg_step_seconds(8)
+            if all_reduce_max(env, t_graph / t_eager) > 1.5:
+                print(f"[bench] rank {env.rank}: hipGraph replay {1e3 * t_graph:.1f} ms/step vs eager {1e3 * t_eager:.1f} ms/step; "
+                      "using the eager loop (same stepper, gradients through the flat buffer)", file=sys.stderr, flush=True)
+                use_graph = False
+                stepper._graph = stepper._graph_opt = None
     for i in range(args.preroll):
         stepper.step(batch)
         if env.is_main and i in (0, args.preroll - 1):  # the first step loads/JITs kernels on a fresh box: show progress
