@@ -9,6 +9,7 @@ the reference's own (commented-out) Lightning DDP, test_unsupervised.py:123,134.
 from __future__ import annotations
 
 import os
+import time
 from contextlib import nullcontext
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -207,6 +208,9 @@ class TrainStepper:
         if master_weights and self.amp_dtype == torch.bfloat16 and not (self.dp_mode == "ddp" and env.world_size > 1):
             self._setup_master_weights()
         self._manual = self.dp_mode == "flat" or bool(self._masters)  # gradients go through the flat buffer
+        # flat mode all-reduces whenever a process group exists (a single rank under OCFLOW_FORCE_DIST included: that is how
+        # the RCCL path -- stream ordering of the all-reduce between the two graph replays -- is exercised on a one-GPU box)
+        self._reduce = self.dp_mode == "flat" and dist.is_available() and dist.is_initialized()
         self._graph = None
         self._graph_opt = None
         self._graph_pool = None
@@ -307,7 +311,7 @@ class TrainStepper:
             params = self._grad_params()
             flat, views = self._flat_views(params)
             self._gather(views, [p.grad for p in params])
-            if self.dp_mode == "flat" and self.env.world_size > 1:
+            if self._reduce:
                 dist.all_reduce(flat)
             self._attach(params, views)
         self._optimizer_step()
@@ -345,16 +349,25 @@ class TrainStepper:
                 self._eager_step(self._static_batch, i)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # With a process group alive, ProcessGroupNCCL's watchdog thread polls the events of recently issued collectives; under
+        # the default "global" capture mode such a query from ANOTHER thread while this thread captures is an error that
+        # terminates the process ("operation not permitted when stream is capturing", seen with the single-rank RCCL rehearsal).
+        # "thread_local" restricts the check to the capturing thread (kernels other threads -- autograd's -- launch on the
+        # capturing stream are captured in every mode); the pause lets the watchdog retire the warm-up collectives first.
+        mode = "global"
+        if dist.is_available() and dist.is_initialized():
+            mode = "thread_local"
+            time.sleep(1.0)
         graph = torch.cuda.CUDAGraph()
         if not self._manual:
-            with torch.cuda.graph(graph, pool=self._graph_pool):
+            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
                 self._static_loss = self._eager_step(self._static_batch, 0)
             self._graph = graph
             return self
-        split = self.dp_mode == "flat" and self.env.world_size > 1  # an all-reduce sits between backward and the optimizer
+        split = self._reduce  # an all-reduce sits between backward and the optimizer
         params = self._grad_params()  # after the warm-up steps: exactly the parameters that reach the loss
         self._flat, views = self._flat_views(params)
-        with torch.cuda.graph(graph, pool=self._graph_pool):
+        with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
             self._static_loss = self._forward_backward(self._static_batch, 0)
             got = self._grad_params()
             if len(got) != len(params) or any(a is not b for a, b in zip(got, params)):
@@ -365,10 +378,10 @@ class TrainStepper:
                 self._optimizer_step()
         self._graph = graph
         if split:
-            dist.all_reduce(self._flat)  # keeps the ranks' collective sequence aligned (the capture itself ran no kernels)
+            # (no collective in here: a rank whose capture raised must not leave the others waiting inside one)
             self._attach(params, views)
             opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(opt_graph, pool=self._graph_pool):
+            with torch.cuda.graph(opt_graph, pool=self._graph_pool, capture_error_mode=mode):
                 self._optimizer_step()
             self._graph_opt = opt_graph
         return self

@@ -293,3 +293,40 @@ def test_master_weights_follow_autocast():
     assert p.dtype == torch.bfloat16 and torch.equal(p.detach(), w1b.to(torch.bfloat16))
     st.restore_fp32_weights()
     assert p.dtype == torch.float32 and torch.equal(p.detach(), w1b)
+
+
+def _rccl_single_rank_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OCFLOW_FORCE_DIST="1")
+    import ocflow_amd  # noqa: F401
+    import torch
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    from ocflow_amd.runtime import TrainStepper, init_distributed, shutdown_distributed, synthetic_batch
+    env = init_distributed()
+    assert env.backend == "nccl"
+    torch.manual_seed(7)
+    st = TrainStepper(FlowOccModel({"learning_rate": 1e-4, "model": "flowoccnet"}), env, amp_dtype=torch.bfloat16, channels_last=True,
+                      fused_optimizer=True, dp_mode="flat", master_weights=True)
+    batch = st.prepare(synthetic_batch(2, 128, 192, env.device, seed=3))
+    losses = [float(st.step(batch, 0))]
+    st.enable_graph(batch)  # collectives were issued a moment ago: the capture must survive ProcessGroupNCCL's watchdog
+    assert st._graph_opt is not None
+    losses += [float(st.step(st._static_batch, i)) for i in range(1, 9)]
+    torch.save({"losses": losses}, os.path.join(out_dir, "rccl.pt"))
+    shutdown_distributed()
+
+
+@pytest.mark.timeout(600)
+def test_split_graphs_over_the_real_rccl_process_group(tmp_path):
+    """the multi-GPU replay structure (forward+backward graph, RCCL all-reduce of the flat gradient buffer, optimizer graph) on the
+    real `nccl` backend with a single rank: stream ordering of the collective against the replays, and graph capture while
+    ProcessGroupNCCL's watchdog thread is alive (it aborts the process under the default capture mode)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.start_processes(_rccl_single_rank_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    losses = torch.load(tmp_path / "rccl.pt")["losses"]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
