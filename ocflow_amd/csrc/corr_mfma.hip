@@ -393,13 +393,17 @@ static int num_cus() {
 }
 
 // tile height: 8 rows for the single-block (C <= 32) variant -- half the tiles, 2/3 of the halo rows per pixel, one workgroup
-// per CU (116 KB LDS); 4 rows for the multi-block variant (64 accumulator registers per lane instead of 128)
-constexpr int TH_SINGLE = 8, TH_MULTI = 4;
+// per CU (116 KB LDS); 4 rows for the multi-block variant (64 accumulator registers per lane instead of 128), 2 rows when a
+// level has fewer 4-row tiles than CUs: those launches are a sequential channel-block loop on a fraction of the chip, and twice
+// the workgroups with half the MFMA / epilogue work each measured 14.0 -> 10.6, 10.8 -> 8.5, 10.0 -> 8.3 us at the three top
+// levels (B = 8), while the 448-tile level got slower (15.9 -> 20.5 us: more halo rows per pixel) and keeps 4 rows.
+// One-row tiles do the same again below a quarter of that (10.6 -> 8.6 and 8.5 -> 6.6 us at the two top levels; 8.2 -> 9.7 at
+// the third, which stays at 2 rows).
+constexpr int TH_SINGLE = 8, TH_MULTI = 4, TH_MULTI_SMALL = 2, TH_MULTI_TINY = 1;
 
-template <int VEC, int MODE, int D, bool MULTI>
+template <int VEC, int MODE, int D, bool MULTI, int TH>
 static int launch_mfma_th(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
                           float fs, int ac, int out_mode, hipStream_t st) {
-  constexpr int TH = MULTI ? TH_MULTI : TH_SINGLE;
   const int tx = (W + mf::TW - 1) / mf::TW, ty = (H + TH - 1) / TH;
   const WarpGeom wg(H, W, ac);
   // persistent grid: a multiple of 8 (XCD-affine schedule), as many workgroups as are co-resident (queried once per variant)
@@ -424,8 +428,11 @@ static int launch_mfma_th(const T4& f1, const T4& f2, const T4& flow, const T4& 
 template <int VEC, int MODE, int D>
 static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
                        float fs, int ac, int out_mode, hipStream_t st) {
-  return C > 32 ? launch_mfma_th<VEC, MODE, D, true>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st)
-                : launch_mfma_th<VEC, MODE, D, false>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+  if (C <= 32) return launch_mfma_th<VEC, MODE, D, false, TH_SINGLE>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+  const long tiles4 = (long)B * ((W + mf::TW - 1) / mf::TW) * ((H + TH_MULTI - 1) / TH_MULTI);
+  if (tiles4 * 4 < num_cus()) return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_TINY>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+  if (tiles4 < num_cus()) return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_SMALL>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+  return launch_mfma_th<VEC, MODE, D, true, TH_MULTI>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
 }
 
 template <int VEC, int MODE>
