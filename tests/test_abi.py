@@ -56,6 +56,18 @@ def test_argument_validation_without_device():
     assert lib.ocf_warp_fwd(None, None, None, 1, 1, 1, 1, 1.0, 0, 0, None) == -1
     assert lib.ocf_range_map(None, None, None, 1, 1, 1, None) == -1
     assert lib.ocf_photo_loss_fwd(None, None, None, None, None, 1, 3, 1, 1, None) == -1
+    # the widened entry points (conv epilogue, occlusion-aware correlation backward, capture id)
+    assert lib.ocf_bias_act_fwd(None, None, 1, 1, 1, 1, 0.1, 0, None) == -1
+    assert lib.ocf_bias_act_fwd(C.byref(good), C.c_void_p(16), 1, 1, 1, 1, 0.1, 7, None) == -1  # bad dtype
+    assert lib.ocf_bias_act_bwd(None, None, None, None, 1, 1, 1, 1, 0.1, 0, 0, None) == -1
+    # a pass-through backward (no input-gradient tensor) only exists for the plain bias epilogue (slope 1)
+    assert lib.ocf_bias_act_bwd(None, C.byref(good), None, C.c_void_p(16), 1, 1, 1, 1, 0.1, 0, 0, None) == -1
+    assert lib.ocf_corr_occ_bwd(None, None, None, None, None, None, None, 1, 1, 1, 1, 4, 0, None) == -1
+    assert lib.ocf_corr_occ_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, C.byref(good),
+                                1, 1, 1, 1, 4, 0, None) == -1  # d/docc is a by-product of the g2 pass
+    assert lib.ocf_corr_occ_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), C.byref(good), C.byref(good), None,
+                                1, 1, 1, 1, 9, 0, None) == -2
+    assert lib.ocf_stream_capture_id(None, None) == -1
 
 
 def test_build_is_reproducible_entry_point():
