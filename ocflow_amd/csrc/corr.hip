@@ -347,12 +347,29 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
     const int gy0 = G2 ? ty0 - D : ty0, gx0 = G2 ? tx0 - D : tx0;
     constexpr int ROWE = GCOLS * NK, VE = 8 / ES;  // elements per row / per 8-byte vector
     if (gvec && gx0 >= 0 && gx0 + GCOLS <= W && ROWE % VE == 0) {
-      for (int v = tid; v < GROWS * (ROWE / VE); v += 256) {
-        const int r = v / (ROWE / VE), q = v - r * (ROWE / VE);
-        const int gy = gy0 + r;
-        u32x2 val = {0u, 0u};
-        if (gy >= 0 && gy < H) val = *(const u32x2*)(g.p + ((long)b * g.sb + (long)gy * g.sh + (long)gx0 * g.sw) * ES + (long)q * 8);
-        *(u32x2*)((char*)s_g + (long)r * ROWE * ES + q * 8) = val;
+      // SB vectors per thread are loaded before the first LDS store: with one load per loop iteration every iteration waited
+      // out a full memory latency (23 of them per thread in the g2 pass -- the whole kernel was this loop)
+      constexpr int NV = GROWS * (ROWE / VE), SB = (NV + 255) / 256 < 24 ? (NV + 255) / 256 : 24;
+      for (int v0 = tid; v0 < NV; v0 += 256 * SB) {
+        u32x2 val[SB];
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+          const int v = v0 + j * 256;
+          val[j] = u32x2{0u, 0u};
+          if (v < NV) {
+            const int r = v / (ROWE / VE), q = v - r * (ROWE / VE);
+            const int gy = gy0 + r;
+            if (gy >= 0 && gy < H) val[j] = *(const u32x2*)(g.p + ((long)b * g.sb + (long)gy * g.sh + (long)gx0 * g.sw) * ES + (long)q * 8);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+          const int v = v0 + j * 256;
+          if (v < NV) {
+            const int r = v / (ROWE / VE), q = v - r * (ROWE / VE);
+            *(u32x2*)((char*)s_g + (long)r * ROWE * ES + q * 8) = val[j];
+          }
+        }
       }
     } else {
       for (int e = tid; e < GROWS * ROWE; e += 256) {
@@ -373,13 +390,19 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
   for (int cb = cb_lo; cb < cb_hi; cb++) {
     const int cbase = cb * BNU * U;
     if (cb > cb_lo) __syncthreads();
-    // ---- stage the halo tile of the other operand for this channel block
-    for (int it = tid; it < HH * HW * BNU; it += 256) {
+    // ---- stage the halo tile of the other operand for this channel block (all of a thread's loads in flight together)
+    constexpr int NIT = (HH * HW * BNU + 255) / 256;
+    u32x4 sv[NIT];
+    float so[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; j++) {
+      const int it = tid + j * 256;
       const int uu = it & (BNU - 1), pos = it >> 2;
       const int xx = pos % HW, r = pos / HW;
       const int gy = ty0 - D + r, gx = tx0 - D + xx, c0 = cbase + uu * U;
       u32x4 v = zero4;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C) {
+      so[j] = 1.f;
+      if (it < HH * HW * BNU && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C) {
         const char* src = other.p + ((long)b * other.sb + (long)gy * other.sh + (long)gx * other.sw + c0) * ES;
         if (VEC == 16) {
           v = *(const u32x4*)src;
@@ -389,16 +412,26 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
           if (c0 + U / 2 < C) hi = *(const u32x2*)(src + 8);
           v = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
+        if (!G2 && occ.p) so[j] = ((const float*)occ.p)[(long)b * occ.sb + (long)gy * occ.sh + (long)gx * occ.sw];
+      }
+      sv[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; j++) {
+      const int it = tid + j * 256;
+      if (it < HH * HW * BNU) {
+        u32x4 v = sv[j];
         if (!G2 && occ.p) {
-          const float o = ((const float*)occ.p)[(long)b * occ.sb + (long)gy * occ.sh + (long)gx * occ.sw];
           float f[U];
           unit_to_f<T>(v, f);
 #pragma unroll
-          for (int j = 0; j < U; j++) f[j] = (float)(T)(f[j] * o);  // rounded like the materialised product w2 * occ
+          for (int k = 0; k < U; k++) f[k] = (float)(T)(f[k] * so[j]);  // rounded like the materialised product w2 * occ
           v = f_to_unit<T>(f);
         }
+        const int uu = it & (BNU - 1), pos = it >> 2;
+        const int xx = pos % HW, r = pos / HW;
+        s_op[(r * HW + xx) * BNU + uu] = v;
       }
-      s_op[(r * HW + xx) * BNU + uu] = v;
     }
     __syncthreads();
     float acc[U];
