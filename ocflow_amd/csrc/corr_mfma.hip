@@ -24,6 +24,7 @@
 //                disjoint banks), then whole contiguous pixel runs -> HBM with 16-byte stores (channels_last, dense).
 // reference semantics: models/networks/correlation_layer.py:7-40 (+ warp cost_volume_flow_net.py:121-151)
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 #include "ocf_common.h"
 #include "corr_internal.h"
 
@@ -420,8 +421,16 @@ static int launch_mfma_th(const T4& f1, const T4& f2, const T4& flow, const T4& 
   int g = ((ntiles + 7) / 8) * 8;
   const int cap = occ_blocks * num_cus();
   if (g > cap) g = cap;
-  hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, MULTI, TH>), dim3((unsigned)g), block, lds, st, f1, f2, flow, occ, out, B, C, H, W, fs,
-                     wg, tx, ty, out_mode);
+  ProfileSlot& ps = profile_slot();
+  if (ps.start && ps.stop) {  // one-shot: the events receive this dispatch's begin / end timestamps
+    hipEvent_t e0 = ps.start, e1 = ps.stop;
+    ps.start = nullptr; ps.stop = nullptr;
+    hipExtLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, MULTI, TH>), dim3((unsigned)g), block, lds, st, e0, e1, 0, f1, f2, flow, occ, out, B, C,
+                          H, W, fs, wg, tx, ty, out_mode);
+  } else {
+    hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, MULTI, TH>), dim3((unsigned)g), block, lds, st, f1, f2, flow, occ, out, B, C, H, W, fs,
+                       wg, tx, ty, out_mode);
+  }
   return launch_status();
 }
 
