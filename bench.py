@@ -13,10 +13,15 @@ channels_last, inputs resident in HBM before the timed region.  Per-GPU shard = 
 per-rank share of configs[4], "batch 64 across 8 GPUs"); weak scaling: per-GPU work is fixed as N grows.
 
 One JSON line on rank 0 with, besides the driver contract keys:
-  roofline     -- the fused correlation kernel (`corr_fwd_tiled`): algorithmic bytes of all its launches in the timed
-                  region / their HIP-event durations (events recorded on the launch stream), vs the 8 TB/s HBM3E peak.
+  roofline     -- the fused correlation kernel (`corr_fwd_mfma`, ocf_corr_fwd): algorithmic bytes of its launches / their
+                  durations from HIP events stamped by the dispatch itself on the launch stream (hipExtLaunchKernelGGL), vs
+                  the 8 TB/s HBM3E peak; `traffic` = PMC bytes per launch from the committed rocprofv3 counter passes.  With
+                  graph replay (default) the launches of the timed region cannot carry events, so the SAME step is run eagerly
+                  right after the timed loop for this leg.
   cpu_baseline -- the oracle (CPU restatement of the reference's op structure, "port") running the SAME training step
                   at batch 1, fp32, on this box's host cores (N=1 only, bounded to ~20 s).
+Launch modes: one GPU = the whole step in one hipGraph; several GPUs = forward+backward graph, one RCCL all-reduce of a flat
+gradient buffer, optimizer graph (falls back, all ranks together, to eager DDP / the eager flat loop).
 """
 import argparse
 import json
