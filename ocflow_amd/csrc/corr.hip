@@ -320,12 +320,21 @@ constexpr int BTW = 16, BTH = 4, BNU = 4;
 //                         one fp32 atomic per pixel and channel block).  `w2own` = the unmasked w2 (read at the own pixel).
 template <typename T, bool G2, int D, int VEC>
 __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t, T4 occ, T4 w2own, T4 gocc, int B, int C, int H, int W,
-                                                      int tiles_x, int tiles_y, int gvec) {
+                                                      int tiles_x, int tiles_y) {
   constexpr int U = Unit<T>::U, ES = (int)sizeof(T);
   constexpr int N = 2 * D + 1, NK = N * N;
   constexpr int HH = BTH + 2 * D, HW = BTW + 2 * D;
   constexpr int GROWS = G2 ? HH : BTH, GCOLS = G2 ? HW : BTW;   // region of grad_out staged
-  constexpr int GPITCH = NK;                                      // LDS row image == global row image (dense channels_last grad_out)
+  // g1: LDS row image == global row image (all NK taps of the tile's own pixels).  g2: a halo pixel in halo row py is only ever
+  // read with the dy rows r in [py - (BTH-1), py] -- at most BTH*N CONTIGUOUS taps -- so only that window is staged (36 of 81
+  // at d = 4): 2.25x less staging traffic and LDS (46.6 -> 20.7 KB bf16), i.e. four workgroups per CU instead of two.
+  constexpr int WN = BTH * N;
+  constexpr int GPITCH = G2 ? WN : ((NK * ES + 7) / 8) * (8 / ES);  // g1: NK taps, pitch rounded up to 8 bytes (84 elements bf16)
+  auto kstart = [](int py) __attribute__((always_inline)) {  // first tap of the window kept for halo row py
+    const int rhi = py < 2 * D ? py : 2 * D;
+    const int ks = NK - (rhi + 1) * N;
+    return ks > NK - WN ? NK - WN : ks;
+  };
   __shared__ u32x4 s_op[BNU * HH * HW];                           // [row][x][unit]
   __shared__ __attribute__((aligned(16))) T s_g[GROWS * GCOLS * GPITCH + 8];
 
@@ -341,44 +350,73 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
   const float invC = 1.f / (float)C;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  // ---- stage the grad_out slice once (all channel passes reuse it): rows of GCOLS pixels x NK contiguous elements.
-  // Interior tiles of a dense, 8-byte aligned grad_out copy whole rows with 8-byte vectors; edge tiles go element by element.
+  // ---- stage the grad_out slice once (all channel passes reuse it).  Interior tiles of a channel-contiguous grad_out copy
+  // per-pixel tap windows with 8-byte vectors; edge tiles (and other layouts) go element by element.
   {
     const int gy0 = G2 ? ty0 - D : ty0, gx0 = G2 ? tx0 - D : tx0;
-    constexpr int ROWE = GCOLS * NK, VE = 8 / ES;  // elements per row / per 8-byte vector
-    if (gvec && gx0 >= 0 && gx0 + GCOLS <= W && ROWE % VE == 0) {
-      // SB vectors per thread are loaded before the first LDS store: with one load per loop iteration every iteration waited
-      // out a full memory latency (23 of them per thread in the g2 pass -- the whole kernel was this loop)
-      constexpr int NV = GROWS * (ROWE / VE), SB = (NV + 255) / 256 < 24 ? (NV + 255) / 256 : 24;
-      for (int v0 = tid; v0 < NV; v0 += 256 * SB) {
-        u32x2 val[SB];
+    if (G2 && g.sc == 1 && gx0 >= 0 && gx0 + GCOLS <= W && (WN * ES) % 8 == 0) {
+      // per halo pixel one window of WN taps = CH eight-byte chunks at a 2-byte aligned address (unaligned global loads), any
+      // pixel pitch; all of a thread's chunks are in flight before the first LDS store
+      constexpr int CH = WN * ES / 8, NV = GROWS * GCOLS * CH, SB = (NV + 255) / 256;
+      u32x2 val[SB];
 #pragma unroll
-        for (int j = 0; j < SB; j++) {
-          const int v = v0 + j * 256;
-          val[j] = u32x2{0u, 0u};
-          if (v < NV) {
-            const int r = v / (ROWE / VE), q = v - r * (ROWE / VE);
-            const int gy = gy0 + r;
-            if (gy >= 0 && gy < H) val[j] = *(const u32x2*)(g.p + ((long)b * g.sb + (long)gy * g.sh + (long)gx0 * g.sw) * ES + (long)q * 8);
-          }
+      for (int j = 0; j < SB; j++) {
+        const int v = tid + j * 256;
+        val[j] = u32x2{0u, 0u};
+        if (v < NV) {
+          const int pi = v / CH, c = v - pi * CH;
+          const int r = pi / GCOLS, xx = pi - r * GCOLS;
+          const int gy = gy0 + r;
+          if (gy >= 0 && gy < H)
+            val[j] = *(const u32x2*)(g.p + ((long)b * g.sb + (long)gy * g.sh + (long)(gx0 + xx) * g.sw + kstart(r)) * ES + c * 8);
         }
+      }
 #pragma unroll
-        for (int j = 0; j < SB; j++) {
-          const int v = v0 + j * 256;
-          if (v < NV) {
-            const int r = v / (ROWE / VE), q = v - r * (ROWE / VE);
-            *(u32x2*)((char*)s_g + (long)r * ROWE * ES + q * 8) = val[j];
+      for (int j = 0; j < SB; j++) {
+        const int v = tid + j * 256;
+        if (v < NV) *(u32x2*)((char*)s_g + (long)v * 8) = val[j];   // [pixel][chunk] == [pixel][WN taps]
+      }
+    } else if (!G2 && g.sc == 1 && gx0 >= 0 && gx0 + GCOLS <= W) {
+      // g1: the NK taps of each tile pixel as CH eight-byte chunks from a 2-byte aligned address (any pixel pitch: the
+      // gradient may be a channel slice of the decoder-input gradient); the last chunk holds the tail of the pixel and is read
+      // element-wise so that nothing past the pixel (and the tensor) is touched
+      constexpr int CH = GPITCH * ES / 8, NV = GROWS * GCOLS * CH, SB = (NV + 255) / 256, TAIL = NK - (CH - 1) * (8 / ES);
+      u32x2 val[SB];
+#pragma unroll
+      for (int j = 0; j < SB; j++) {
+        const int v = tid + j * 256;
+        val[j] = u32x2{0u, 0u};
+        if (v < NV) {
+          const int pi = v / CH, c = v - pi * CH;
+          const int r = pi / GCOLS, xx = pi - r * GCOLS;
+          const int gy = gy0 + r;
+          if (gy >= 0 && gy < H) {
+            const char* src = g.p + ((long)b * g.sb + (long)gy * g.sh + (long)(gx0 + xx) * g.sw) * ES + c * 8;
+            if (c < CH - 1) {
+              val[j] = *(const u32x2*)src;
+            } else {
+              T tail[8 / ES] = {};
+#pragma unroll
+              for (int t = 0; t < TAIL; t++) tail[t] = ((const T*)src)[t];
+              val[j] = __builtin_bit_cast(u32x2, tail);
+            }
           }
         }
       }
+#pragma unroll
+      for (int j = 0; j < SB; j++) {
+        const int v = tid + j * 256;
+        if (v < NV) *(u32x2*)((char*)s_g + (long)v * 8) = val[j];   // [pixel][chunk]
+      }
     } else {
-      for (int e = tid; e < GROWS * ROWE; e += 256) {
-        const int r = e / ROWE, q = e - r * ROWE;
-        const int xx = q / NK, k = q - xx * NK;
+      for (int e = tid; e < GROWS * GCOLS * GPITCH; e += 256) {
+        const int pi = e / GPITCH, j = e - pi * GPITCH;
+        const int r = pi / GCOLS, xx = pi - r * GCOLS;
+        const int k = G2 ? kstart(r) + j : j;
         const int gy = gy0 + r, gx = gx0 + xx;
         T v = (T)0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ((const T*)g.p)[(long)b * g.sb + (long)gy * g.sh + (long)gx * g.sw + k];
-        s_g[(r * GCOLS + xx) * GPITCH + k] = v;
+        if (k < NK && gy >= 0 && gy < H && gx >= 0 && gx < W) v = ((const T*)g.p)[(long)b * g.sb + (long)gy * g.sh + (long)gx * g.sw + (long)k * g.sc];
+        s_g[e] = v;
       }
     }
   }
@@ -441,7 +479,7 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
     for (int r = 0; r < N; r++) {
       const u32x4* orow = &s_op[((ly + r) * HW + lx) * BNU + u];
       // g1: own pixel, taps r*N .. r*N+N-1;  g2: source pixel (ly+r, lx+s) of the halo, mirrored tap NK-1-(r*N+s)
-      const T* grow = G2 ? &s_g[((ly + r) * GCOLS + lx) * GPITCH + (NK - 1 - r * N)] : &s_g[(ly * GCOLS + lx) * GPITCH + r * N];
+      const T* grow = G2 ? &s_g[((ly + r) * GCOLS + lx) * GPITCH + (NK - 1 - r * N) - kstart(ly + r)] : &s_g[(ly * GCOLS + lx) * GPITCH + r * N];
 #pragma unroll
       for (int sft = 0; sft < N; sft++) {
         const float gk = (float)(G2 ? grow[sft * GPITCH - sft] : grow[sft]);
@@ -506,17 +544,11 @@ static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, con
   const int split = (B * tx * ty <= 128) ? ncb : 1;  // under half a tile per CU: one workgroup per (tile, channel block); measured
                                                      // 81 -> 28 us and 60 -> 34 us (g1+g2) at the two top levels, slower from 224 tiles up
   const dim3 grid((unsigned)(B * tx * ty), (unsigned)split), block(256);
-  const int nk = (2 * d + 1) * (2 * d + 1);
-  const long es = sizeof(T);
-  // 8-byte vector staging of grad_out rows: dense channels_last, row starts 8-byte aligned ((gy*W + gx0)*nk*es % 8 == 0)
-  const long per = 8 / es;  // pixels offsets must be multiples of `per` when nk is odd
-  const int gvec = g->sc == 1 && g->sw == nk && g->sh == (long)W * nk && ((uintptr_t)g->data % 8 == 0) && (g->sb * es) % 8 == 0 &&
-                   ((nk % per == 0) || (W % per == 0 && (!G2 || d % per == 0) && BTW % per == 0));
   switch (d) {
-    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, gvec); break;
-    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, gvec); break;
-    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, gvec); break;
-    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, gvec); break;
+    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty); break;
+    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty); break;
+    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty); break;
+    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty); break;
   }
 }
 

@@ -172,10 +172,11 @@ class _CorrWarpFn(Function):
         need1, need2, needf, needo = ctx.needs_input_grad[:4]
         if gout.dtype != f1.dtype:
             gout = gout.to(f1.dtype)
-        # autograd hands the cost-volume gradient over as a channel slice of the decoder-input gradient (cat backward):
-        # 81 contiguous values per pixel but at the concat buffer's pixel pitch.  The tiled backward kernels stage whole
-        # rows with 8-byte vectors only from a dense channels_last tensor -- one 36 MB copy is far cheaper than 2-byte staging.
-        if _is_cl(f1) and not (gout.stride(1) == 1 and gout.stride(3) == gout.size(1) and gout.stride(2) == gout.size(1) * gout.size(3)):
+        # autograd hands the cost-volume gradient over as a channel slice of the decoder-input gradient (cat backward): 81
+        # contiguous values per pixel at the concat buffer's pixel pitch.  The tiled backward kernels stage per-pixel tap
+        # windows with unaligned 8-byte loads, so that view is consumed as is; only a gradient whose taps are not contiguous
+        # per pixel (NCHW) is brought to channels_last first.
+        if _is_cl(f1) and gout.stride(1) != 1:
             gout = gout.contiguous(memory_format=torch.channels_last)
         # second operand of the plain correlation (kept by the two-launch forward; recomputed after a fused forward)
         if w2_saved is not None:

@@ -490,3 +490,29 @@ def test_empty_batch(ops):
     assert f.grad.shape == f.shape
     assert ops.warp(f, fl).shape == f.shape
     assert ops.corr_warp(f, f, fl, None, 4).shape == (0, 81, 12, 20)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_occ", [False, True])
+def test_corr_backward_from_concat_slice(ops, dtype, with_occ):
+    """in the decoders the cost volume is concatenated with other features, so its gradient arrives as a channel slice of the
+    concat gradient (81 contiguous taps per pixel at a 117-element pixel pitch, 2-byte aligned): the tiled backward kernels
+    consume that view directly (per-pixel tap windows, unaligned 8-byte loads) -- no dense copy"""
+    gen = torch.Generator().manual_seed(17)
+    B, C, H, W = 2, 32, 21, 45
+    f1 = torch.randn((B, C, H, W), generator=gen).to(dtype)
+    f2 = torch.randn((B, C, H, W), generator=gen).to(dtype)
+    occ = torch.rand((B, 1, H, W), generator=gen) if with_occ else None
+    extra = torch.randn((B, 36, H, W), generator=gen).to(dtype)
+    cot = torch.randn((B, 81 + 36, H, W), generator=gen).to(dtype)
+    a, b = f1.float().requires_grad_(), f2.float().requires_grad_()
+    ref = torch.cat([O.compute_cost_volume(a, b * occ if with_occ else b, 4), extra.float()], 1)
+    g1r, g2r = torch.autograd.grad(ref, (a, b), cot.float())
+    x = f1.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = f2.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    out = torch.cat([ops.corr_warp(x, y, None, occ.to(DEV) if with_occ else None, 4), extra.to(DEV).contiguous(memory_format=torch.channels_last)], 1)
+    g1, g2 = torch.autograd.grad(out, (x, y), cot.to(DEV).contiguous(memory_format=torch.channels_last))
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    for got, want in ((g1, g1r), (g2, g2r)):
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=tol * 5, atol=tol * scale)
