@@ -48,9 +48,12 @@ __global__ void __launch_bounds__(256) bias_act_fwd_cl(T* __restrict__ x, const 
 // partial sums are reduced over r through LDS and leave the block as one atomicAdd per channel (consecutive threads ->
 // consecutive channels, i.e. whole-cache-line atomics), so the grid is kept at <= 512 blocks.
 // PASS: negative_slope == 1 (plain bias epilogue): gx == gy, nothing to read from y or write to gx, only the reduction runs.
+// gy_pitch: elements between consecutive pixels of gy (== C for a dense tensor; larger when gy is a channel slice of the gradient
+// of a concatenation -- the dense blocks of the decoders -- whose pixels start at any 2-byte aligned address: its units are then
+// read with unaligned 16-byte loads instead of being copied to a dense tensor first).
 template <typename T, int U, bool PASS>
 __global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx,
-                                                       float* __restrict__ gbias, long R, int G, float slope) {
+                                                       float* __restrict__ gbias, long R, int G, float slope, long gy_pitch) {
   constexpr int UNR = (U == 1) ? 8 : 4;
   __shared__ float red[256][U + 1];
   const int rpb = 256 / G;               // rows per pass
@@ -67,7 +70,8 @@ __global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, 
         const long row = row0 + k * step;
         if (row < R) {
           if (!PASS) ld_u<T, U>(y, row * G + cg, fy[k]);
-          ld_u<T, U>(gy, row * G + cg, fg[k]);
+          if (U == 1) fg[k][0] = (float)gy[row * gy_pitch + cg];
+          else unit_to_f<T>(*(const u32x4*)(gy + row * gy_pitch + (long)cg * U), fg[k]);
         }
       }
 #pragma unroll
@@ -179,13 +183,34 @@ static int bias_act_fwd_t(const T4& x, const float* bias, int B, int C, int H, i
   return launch_status();
 }
 
+// pixel pitch of a channel-contiguous tensor whose pixels are laid out in dense (b, y, x) order, 0 if it is not one
+static long uniform_pixel_pitch(const T4& t, int B, int C, int H, int W) {
+  if (!(t.sc == 1 || C == 1)) return 0;
+  // strides of size-1 dimensions carry no information: take the pitch from the innermost dimension that has extent
+  const long p = W > 1 ? t.sw : (H > 1 ? t.sh : (B > 1 ? t.sb : (long)C));
+  if (p < C) return 0;
+  if (W > 1 && H > 1 && t.sh != (long)W * p) return 0;
+  if ((W > 1 || H > 1) && B > 1 && t.sb != (long)H * W * p) return 0;
+  return p;
+}
+
 template <typename T, bool PASS>
 static int bias_act_bwd_t(const T4& y, const T4& gy, const T4& gx, float* gbias, int B, int C, int H, int W, float slope, bool accumulate,
                           hipStream_t st) {
   constexpr int U = Unit<T>::U;
-  const int lay = dense_layout<T>(gy, B, C, H, W);
+  // the layout is decided by the tensors this launch owns (y / gx; gy alone in the pass-through form); gy may additionally be a
+  // channel slice with a larger pixel pitch when the others are channels_last
+  int lay = PASS ? dense_layout<T>(gy, B, C, H, W) : dense_layout<T>(y, B, C, H, W);
+  long gy_pitch = C;
+  if (!PASS && dense_layout<T>(gx, B, C, H, W) != lay) return OCF_EUNSUPPORTED;
+  if (lay == LAYOUT_CL || lay == LAYOUT_CL1 || (PASS && lay == LAYOUT_NONE)) {
+    gy_pitch = uniform_pixel_pitch(gy, B, C, H, W);
+    if (gy_pitch == 0) return OCF_EUNSUPPORTED;
+    if (PASS && lay == LAYOUT_NONE) lay = (C % U == 0 && C / U <= 256) ? LAYOUT_CL : (C <= 256 && C > 1 ? LAYOUT_CL1 : LAYOUT_NONE);
+  } else if (lay == LAYOUT_NCHW) {
+    if (dense_layout<T>(gy, B, C, H, W) != LAYOUT_NCHW) return OCF_EUNSUPPORTED;
+  }
   if (lay == LAYOUT_NONE) return OCF_EUNSUPPORTED;
-  if (!PASS && (dense_layout<T>(y, B, C, H, W) != lay || dense_layout<T>(gx, B, C, H, W) != lay)) return OCF_EUNSUPPORTED;
   if (!accumulate && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return OCF_ELAUNCH;
   if (lay == LAYOUT_CL || lay == LAYOUT_CL1) {
     const int G = lay == LAYOUT_CL ? C / U : C;
@@ -196,9 +221,9 @@ static int bias_act_bwd_t(const T4& y, const T4& gy, const T4& gx, float* gbias,
     long want = (R + (long)rpb * 8 - 1) / ((long)rpb * 8);
     const int grid = (int)(want < 1 ? 1 : (want < 512 ? want : 512));
     if (lay == LAYOUT_CL)
-      hipLaunchKernelGGL((bias_act_bwd_cl<T, U, PASS>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
+      hipLaunchKernelGGL((bias_act_bwd_cl<T, U, PASS>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope, gy_pitch);
     else
-      hipLaunchKernelGGL((bias_act_bwd_cl<T, 1, PASS>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope);
+      hipLaunchKernelGGL((bias_act_bwd_cl<T, 1, PASS>), dim3(grid), dim3(256), 0, st, (const T*)y.p, (const T*)gy.p, (T*)gx.p, gbias, R, G, slope, gy_pitch);
   } else {
     const long HW = (long)H * W;
     int chunks = (int)((HW + 2047) / 2048);  // 8 elements per thread: these are 1- and 2-channel maps, parallelism comes from chunks

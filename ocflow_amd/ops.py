@@ -581,14 +581,23 @@ class _BiasActFn(Function):
     def backward(ctx, gy):
         B, C_, H, W = gy.shape
         passthrough = ctx.slope == 1.0
+
+        def pixel_major(t):
+            """channel-contiguous with pixels in dense (b, y, x) order at ANY pixel pitch: dense channels_last, or a channel
+            slice of the gradient of a concatenation (the decoders' dense blocks) -- the kernel reads either without a copy"""
+            sb, sc, sh, sw = t.stride()
+            pitch = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C_))  # size-1 dimensions have arbitrary strides
+            return ((sc == 1 or C_ == 1) and pitch >= C_ and (sh == W * pitch or H == 1 or W == 1)
+                    and (sb == H * W * pitch or B == 1 or (H == 1 and W == 1)))
+
         if passthrough:
             y, gg = None, gy
-            if not (gg.is_contiguous() or gg.is_contiguous(memory_format=torch.channels_last)):
+            if not (gg.is_contiguous() or pixel_major(gg)):
                 gg = gg.contiguous(memory_format=ctx.fmt)  # reduction operand only; the gradient returned stays `gy`
         else:
             (y,) = ctx.saved_tensors
             gg = gy if gy.dtype == y.dtype else gy.to(y.dtype)
-            if gg.stride() != y.stride():  # e.g. the channel slice of a concatenation's gradient
+            if gg.stride() != y.stride() and not (_is_cl(y) and pixel_major(gg)):
                 gg = gg.contiguous(memory_format=torch.channels_last if _is_cl(y) else torch.contiguous_format)
                 if gg.stride() != y.stride():
                     gg = torch.empty_like(y).copy_(gg)
@@ -599,7 +608,8 @@ class _BiasActFn(Function):
                 gb = _take_zeros(C_, gy.device)
             with torch.cuda.device(gy.device):
                 _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y), _t4(gg), _t4(gx), C.c_void_p(gb.data_ptr()), B, C_, H, W, ctx.slope, 1,
-                                                        _dtype_code(gg), _stream(gg)), "ocf_bias_act_bwd")
+                                                        _dtype_code(gg), _stream(gg)),
+                           "ocf_bias_act_bwd")
         if gb is not None and ctx.bias_dtype != torch.float32:
             gb = gb.to(ctx.bias_dtype)
         return (gy if passthrough else gx), (gb if ctx.needs_input_grad[1] else None), None

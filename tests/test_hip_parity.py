@@ -516,3 +516,28 @@ def test_corr_backward_from_concat_slice(ops, dtype, with_occ):
     for got, want in ((g1, g1r), (g2, g2r)):
         scale = float(want.abs().max())
         np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=tol * 5, atol=tol * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C_,slope", [(32, 0.1), (96, 0.1), (12, 0.1), (2, 1.0), (32, 1.0)])
+def test_bias_epilogue_backward_from_concat_slice(ops, dtype, C_, slope):
+    """the decoders concatenate every conv output with its input (dense blocks), so the epilogue's incoming gradient is a channel
+    slice of the concat gradient: channel-contiguous pixels at a larger, 2-byte aligned pitch.  The backward kernel reads that
+    view with unaligned 16-byte loads (no dense copy) -- same input gradient bit for bit, same bias gradient"""
+    gen = torch.Generator().manual_seed(C_ * 3 + int(slope * 10))
+    B, H, W, E = 2, 19, 23, 37
+    x0 = torch.randn((B, C_, H, W), generator=gen).to(dtype)
+    b0 = torch.randn(C_, generator=gen)
+    extra = torch.randn((B, E, H, W), generator=gen).to(dtype)
+    cot = torch.randn((B, E + C_, H, W), generator=gen).to(dtype)
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fn in (lambda t, bb: O.bias_leaky_relu(t, bb, slope), lambda t, bb: ops.bias_leaky_relu(t * 1, bb, slope)):
+        x, b = cl(x0).requires_grad_(), b0.to(DEV).requires_grad_()
+        out = torch.cat([cl(extra), fn(x, b)], 1)  # the slice starts at channel 37: odd element offset
+        res.append(torch.autograd.grad(out, (x, b), cl(cot)))
+    (gxr, gbr), (gx, gb) = res
+    assert torch.equal(gx, gxr)
+    n = B * H * W
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    np.testing.assert_allclose(gb.cpu().numpy(), gbr.float().cpu().numpy(), rtol=tol, atol=tol * np.sqrt(n))
