@@ -170,6 +170,11 @@ def pmc_traffic_per_launch():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result of rank 0: libraries that print to fd 1 (RCCL's version banner at
+    # communicator creation, MIOpen notes) are sent to stderr for the whole run and the real stdout is restored for that line
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     from ocflow_amd import ops
     from ocflow_amd.runtime import (KernelTimer, all_reduce_max, barrier, init_distributed, shutdown_distributed,
                                     synthetic_batch)
@@ -322,7 +327,10 @@ def main():
                        "weights": "fp32 masters + bf16 compute copies" if stepper._masters else "fp32 (autocast casts per use)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     shutdown_distributed()
 
 
