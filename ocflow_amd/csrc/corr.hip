@@ -320,7 +320,7 @@ constexpr int BTW = 16, BTH = 4, BNU = 4;
 //                         one fp32 atomic per pixel and channel block).  `w2own` = the unmasked w2 (read at the own pixel).
 template <typename T, bool G2, int D, int VEC>
 __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t, T4 occ, T4 w2own, T4 gocc, int B, int C, int H, int W,
-                                                      int tiles_x, int tiles_y) {
+                                                      int tiles_x, int tiles_y, int ablate) {
   constexpr int U = Unit<T>::U, ES = (int)sizeof(T);
   constexpr int N = 2 * D + 1, NK = N * N;
   constexpr int HH = BTH + 2 * D, HW = BTW + 2 * D;
@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
   // per-pixel tap windows with 8-byte vectors; edge tiles (and other layouts) go element by element.
   {
     const int gy0 = G2 ? ty0 - D : ty0, gx0 = G2 ? tx0 - D : tx0;
-    if (G2 && g.sc == 1 && gx0 >= 0 && gx0 + GCOLS <= W && (WN * ES) % 8 == 0) {
+    if (ablate & 1) {  // kernel-tuning aid (tools/kbench, OCF_ABLATE_BWD): no grad_out staging
+    } else if (G2 && g.sc == 1 && (WN * ES) % 8 == 0) {
       // per halo pixel one window of WN taps = CH eight-byte chunks at a 2-byte aligned address (unaligned global loads), any
       // pixel pitch; all of a thread's chunks are in flight before the first LDS store
       constexpr int CH = WN * ES / 8, NV = GROWS * GCOLS * CH, SB = (NV + 255) / 256;
@@ -362,21 +363,24 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
 #pragma unroll
       for (int j = 0; j < SB; j++) {
         const int v = tid + j * 256;
-        val[j] = u32x2{0u, 0u};
-        if (v < NV) {
-          const int pi = v / CH, c = v - pi * CH;
-          const int r = pi / GCOLS, xx = pi - r * GCOLS;
-          const int gy = gy0 + r;
-          if (gy >= 0 && gy < H)
-            val[j] = *(const u32x2*)(g.p + ((long)b * g.sb + (long)gy * g.sh + (long)(gx0 + xx) * g.sw + kstart(r)) * ES + c * 8);
-        }
+        // branch-free: a load inside a divergent branch is followed by s_waitcnt vmcnt(0) at the join, which serialised all of
+        // a thread's loads behind each other's latency (ISA check); invalid lanes read the tile's first valid window and discard it
+        const int vv = v < NV ? v : 0;
+        const int pi = vv / CH, c = vv - pi * CH;
+        const int r = pi / GCOLS, xx = pi - r * GCOLS;
+        const int gy = gy0 + r;
+        const int gx = gx0 + xx;
+        const bool ok = v < NV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+        const u32x2 ld = *(const u32x2*)(g.p + ((long)b * g.sb + (long)gyc * g.sh + (long)gxc * g.sw + kstart(r)) * ES + c * 8);
+        val[j] = ok ? ld : u32x2{0u, 0u};
       }
 #pragma unroll
       for (int j = 0; j < SB; j++) {
         const int v = tid + j * 256;
         if (v < NV) *(u32x2*)((char*)s_g + (long)v * 8) = val[j];   // [pixel][chunk] == [pixel][WN taps]
       }
-    } else if (!G2 && g.sc == 1 && gx0 >= 0 && gx0 + GCOLS <= W) {
+    } else if (!G2 && g.sc == 1) {
       // g1: the NK taps of each tile pixel as CH eight-byte chunks from a 2-byte aligned address (any pixel pitch: the
       // gradient may be a channel slice of the decoder-input gradient); the last chunk holds the tail of the pixel and is read
       // element-wise so that nothing past the pixel (and the tensor) is touched
@@ -385,23 +389,24 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
 #pragma unroll
       for (int j = 0; j < SB; j++) {
         const int v = tid + j * 256;
-        val[j] = u32x2{0u, 0u};
-        if (v < NV) {
-          const int pi = v / CH, c = v - pi * CH;
-          const int r = pi / GCOLS, xx = pi - r * GCOLS;
-          const int gy = gy0 + r;
-          if (gy >= 0 && gy < H) {
-            const char* src = g.p + ((long)b * g.sb + (long)gy * g.sh + (long)(gx0 + xx) * g.sw) * ES + c * 8;
-            if (c < CH - 1) {
-              val[j] = *(const u32x2*)src;
-            } else {
-              T tail[8 / ES] = {};
-#pragma unroll
-              for (int t = 0; t < TAIL; t++) tail[t] = ((const T*)src)[t];
-              val[j] = __builtin_bit_cast(u32x2, tail);
-            }
-          }
+        // branch-free (see the g2 path): the last chunk of a pixel re-reads its final full 8 bytes and shifts the tail into place
+        const int vv = v < NV ? v : 0;
+        const int pi = vv / CH, c = vv - pi * CH;
+        const int r = pi / GCOLS, xx = pi - r * GCOLS;
+        const int gy = gy0 + r;
+        const int gx = gx0 + xx;
+        const bool ok = v < NV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+        const bool last = c == CH - 1;
+        // the last chunk starts (8/ES - TAIL) elements early so that it ends exactly at the pixel's last tap
+        const long eoff = ((long)b * g.sb + (long)gyc * g.sh + (long)gxc * g.sw) + (last ? NK - 8 / ES : c * (8 / ES));
+        u32x2 ld = *(const u32x2*)(g.p + eoff * ES);
+        if (last) {  // keep the TAIL newest elements, in the low positions
+          constexpr int SH = (8 / ES - TAIL) * ES * 8;  // bits to drop
+          const unsigned long long w = __builtin_bit_cast(unsigned long long, ld) >> SH;
+          ld = __builtin_bit_cast(u32x2, w);
         }
+        val[j] = ok ? ld : u32x2{0u, 0u};
       }
 #pragma unroll
       for (int j = 0; j < SB; j++) {
@@ -438,21 +443,23 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
       const int uu = it & (BNU - 1), pos = it >> 2;
       const int xx = pos % HW, r = pos / HW;
       const int gy = ty0 - D + r, gx = tx0 - D + xx, c0 = cbase + uu * U;
-      u32x4 v = zero4;
-      so[j] = 1.f;
-      if (it < HH * HW * BNU && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C) {
-        const char* src = other.p + ((long)b * other.sb + (long)gy * other.sh + (long)gx * other.sw + c0) * ES;
-        if (VEC == 16) {
-          v = *(const u32x4*)src;
-        } else {
-          const u32x2 lo = *(const u32x2*)src;
-          u32x2 hi = {0u, 0u};
-          if (c0 + U / 2 < C) hi = *(const u32x2*)(src + 8);
-          v = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        }
-        if (!G2 && occ.p) so[j] = ((const float*)occ.p)[(long)b * occ.sb + (long)gy * occ.sh + (long)gx * occ.sw];
+      // branch-free loads (clamped address, result discarded when out of range): see the grad_out staging above
+      const bool ok = !(ablate & 2) && it < HH * HW * BNU && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C;
+      const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+      const int c0c = c0 < C ? c0 : 0;
+      const char* src = other.p + ((long)b * other.sb + (long)gyc * other.sh + (long)gxc * other.sw + c0c) * ES;
+      u32x4 v;
+      if (VEC == 16) {
+        v = *(const u32x4*)src;
+      } else {
+        const u32x2 lo = *(const u32x2*)src;
+        const bool full = c0c + U / 2 < C;
+        const u32x2 hi = *(const u32x2*)(src + (full ? 8 : 0));
+        v = u32x4{lo[0], lo[1], full ? hi[0] : 0u, full ? hi[1] : 0u};
       }
-      sv[j] = v;
+      so[j] = 1.f;
+      if (!G2 && occ.p) so[j] = ((const float*)occ.p)[(long)b * occ.sb + (long)gyc * occ.sh + (long)gxc * occ.sw];
+      sv[j] = ok ? v : zero4;
     }
 #pragma unroll
     for (int j = 0; j < NIT; j++) {
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
 #pragma unroll
     for (int j = 0; j < U; j++) acc[j] = 0.f;
 #pragma unroll 1
-    for (int r = 0; r < N; r++) {
+    for (int r = 0; r < ((ablate & 4) ? 0 : N); r++) {
       const u32x4* orow = &s_op[((ly + r) * HW + lx) * BNU + u];
       // g1: own pixel, taps r*N .. r*N+N-1;  g2: source pixel (ly+r, lx+s) of the halo, mirrored tap NK-1-(r*N+s)
       const T* grow = G2 ? &s_g[((ly + r) * GCOLS + lx) * GPITCH + (NK - 1 - r * N) - kstart(ly + r)] : &s_g[(ly * GCOLS + lx) * GPITCH + r * N];
@@ -544,11 +551,12 @@ static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, con
   const int split = (B * tx * ty <= 128) ? ncb : 1;  // under half a tile per CU: one workgroup per (tile, channel block); measured
                                                      // 81 -> 28 us and 60 -> 34 us (g1+g2) at the two top levels, slower from 224 tiles up
   const dim3 grid((unsigned)(B * tx * ty), (unsigned)split), block(256);
+  static const int ablate = getenv("OCF_ABLATE_BWD") ? atoi(getenv("OCF_ABLATE_BWD")) : 0;  // 0 in production
   switch (d) {
-    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty); break;
-    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty); break;
-    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty); break;
-    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty); break;
+    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
+    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
+    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
+    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
   }
 }
 

@@ -67,12 +67,12 @@ __global__ void __launch_bounds__(256) bias_act_bwd_cl(const T* __restrict__ y, 
       float fy[UNR][U], fg[UNR][U];
 #pragma unroll
       for (int k = 0; k < UNR; k++) {
-        const long row = row0 + k * step;
-        if (row < R) {
-          if (!PASS) ld_u<T, U>(y, row * G + cg, fy[k]);
-          if (U == 1) fg[k][0] = (float)gy[row * gy_pitch + cg];
-          else unit_to_f<T>(*(const u32x4*)(gy + row * gy_pitch + (long)cg * U), fg[k]);
-        }
+        // branch-free loads (rows past the end re-read the last row and are ignored below): a load inside a divergent branch is
+        // followed by s_waitcnt vmcnt(0) at the join, which serialises the UNR loads behind each other
+        const long row = row0 + k * step < R ? row0 + k * step : R - 1;
+        if (!PASS) ld_u<T, U>(y, row * G + cg, fy[k]);
+        if (U == 1) fg[k][0] = (float)gy[row * gy_pitch + cg];
+        else unit_to_f<T>(*(const u32x4*)(gy + row * gy_pitch + (long)cg * U), fg[k]);
       }
 #pragma unroll
       for (int k = 0; k < UNR; k++) {
