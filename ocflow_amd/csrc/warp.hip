@@ -189,16 +189,37 @@ __global__ __launch_bounds__(256) void warp_bwd_cl_kernel(T4 img, T4 flow, T4 go
     gy = g * ((1.f - s.wx1) * (v[2] - v[0]) + s.wx1 * (v[3] - v[1]));
   }
   if (gflow.p) {
-    // G = largest power of two <= 64 dividing C: lanes [k*G, (k+1)*G) of a wave belong to one pixel
-    for (int o = G >> 1; o > 0; o >>= 1) {
-      gx += __shfl_xor(gx, o, 64);
-      gy += __shfl_xor(gy, o, 64);
-    }
-    if (live && (threadIdx.x & (G - 1)) == 0) {
-      float* gf = (float*)gflow.p;
-      const long o = (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
-      atomicAdd(gf + o, gx * wg.ax * fs);
-      atomicAdd(gf + o + gflow.sc, gy * wg.ay * fs);
+    float* gf = (float*)gflow.p;
+    const long o = (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
+    if (C >= 64) {
+      // a wave (64 consecutive (pixel, channel) lanes) covers at most two pixels: one segmented wave sum per pixel and one
+      // atomic pair per (wave, pixel).  With the power-of-two groups below, C = 196 (G = 4) issued 49 atomic pairs per pixel
+      // to the same two addresses: 34 us for the 7x16 top level, most of it same-address serialisation.
+      const long p0 = __shfl(pix, 0, 64);
+      const bool first = live && pix == p0, second = live && pix != p0;
+      const float ax = wave_sum(first ? gx : 0.f), ay = wave_sum(first ? gy : 0.f);
+      const float bx = wave_sum(second ? gx : 0.f), by = wave_sum(second ? gy : 0.f);
+      const int lane = threadIdx.x & 63;
+      // the first lane of each segment issues that segment's atomics (lane 0, and the first lane whose pixel differs)
+      const unsigned long long m2 = __ballot(second);
+      if (lane == 0 && live) {
+        atomicAdd(gf + o, ax * wg.ax * fs);
+        atomicAdd(gf + o + gflow.sc, ay * wg.ay * fs);
+      }
+      if (m2 != 0ull && lane == __ffsll((long long)m2) - 1) {
+        atomicAdd(gf + o, bx * wg.ax * fs);
+        atomicAdd(gf + o + gflow.sc, by * wg.ay * fs);
+      }
+    } else {
+      // G = largest power of two <= 64 dividing C: lanes [k*G, (k+1)*G) of a wave belong to one pixel
+      for (int oo = G >> 1; oo > 0; oo >>= 1) {
+        gx += __shfl_xor(gx, oo, 64);
+        gy += __shfl_xor(gy, oo, 64);
+      }
+      if (live && (threadIdx.x & (G - 1)) == 0) {
+        atomicAdd(gf + o, gx * wg.ax * fs);
+        atomicAdd(gf + o + gflow.sc, gy * wg.ay * fs);
+      }
     }
   }
 }
