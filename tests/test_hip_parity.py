@@ -541,3 +541,30 @@ def test_bias_epilogue_backward_from_concat_slice(ops, dtype, C_, slope):
     n = B * H * W
     tol = 1e-5 if dtype == torch.float32 else 1e-2
     np.testing.assert_allclose(gb.cpu().numpy(), gbr.float().cpu().numpy(), rtol=tol, atol=tol * np.sqrt(n))
+
+
+@pytest.mark.parametrize("shape,d", [((1, 8, 5, 7), 1), ((2, 24, 9, 33), 2), ((1, 40, 8, 31), 3), ((2, 32, 4, 70), 4), ((1, 64, 1, 50), 4),
+                                      ((1, 16, 50, 1), 4), ((1, 100, 13, 17), 4), ((3, 32, 17, 16), 4)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_occ", [False, True])
+def test_corr_backward_odd_shapes(ops, shape, d, dtype, with_occ):
+    """the tiled backward's staging (per-pixel tap windows, clamped branch-free loads, edge tiles, 1-pixel-wide / 1-pixel-high maps,
+    d < 4, channel counts that are not a multiple of the tile's 32 / of the 16-byte unit) against fp32 autograd of the oracle"""
+    gen = torch.Generator().manual_seed(sum(shape) * 7 + d)
+    n = (2 * d + 1) ** 2
+    f1 = torch.randn(shape, generator=gen).to(dtype)
+    f2 = torch.randn(shape, generator=gen).to(dtype)
+    occ = torch.rand((shape[0], 1, shape[2], shape[3]), generator=gen) if with_occ else None
+    cot = torch.randn((shape[0], n, shape[2], shape[3]), generator=gen).to(dtype)
+    a, b = f1.float().requires_grad_(), f2.float().requires_grad_()
+    ref = O.compute_cost_volume(a, b * occ if with_occ else b, d)
+    g1r, g2r = torch.autograd.grad(ref, (a, b), cot.float())
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    x, y = cl(f1).requires_grad_(), cl(f2).requires_grad_()
+    out = ops.corr_warp(x, y, None, occ.to(DEV) if with_occ else None, d)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    close(out, ref, tol)
+    g1, g2 = torch.autograd.grad(out, (x, y), cl(cot))
+    for got, want in ((g1, g1r), (g2, g2r)):
+        scale = float(want.abs().max()) + 1e-12
+        np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=tol * 5, atol=tol * scale)
