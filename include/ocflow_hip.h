@@ -151,6 +151,12 @@ int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int H, int W, 
 int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W, int window_size,
                  void* stream);
 
+/* ---- PSNR metric (sibling of SSIM in the reference's inpainting_metrics) ------------------------------------------------------
+ * sums[b] = sum over (C,H,W) of (img1 - img2)^2 of sample b (fp64, zeroed by the launcher); img1 / img2 fp32, any strides.
+ * replaces: psnr()  inpainting_metrics/psnr/psnr.py:4-11  (numpy mean((a-b)^2) per image after a device-to-host copy,
+ *           call site inpainting_metrics/__init__.py:76-78) */
+int ocf_sqdiff(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W, void* stream);
+
 /* ---- convolution epilogue of the estimator nets (second "next" row: the callers either side of the correlation) ----------
  * forward, IN PLACE on x (the bias-free convolution output):   t = T(x + T(bias[c]));  y = t > 0 ? t : T(t * negative_slope)
  *   negative_slope == 1: plain bias add (prediction layers, transposed convolutions).

@@ -47,6 +47,7 @@ SIGNATURES = {
     "ocf_range_map": [_T4P, _vp, _vp, _i, _i, _i, _vp],
     "ocf_moments": [_T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_ssim_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
+    "ocf_sqdiff": [_T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
     "ocf_bias_act_fwd": [_T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
 }

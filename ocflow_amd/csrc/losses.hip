@@ -398,6 +398,31 @@ __global__ __launch_bounds__(LB) void ssim_fwd_kernel(T4 a, T4 b, double* sums, 
   block_reduce_atomic<1>(acc, sums + bi);
 }
 
+// ------------------------------------------------------------------------------------------ PSNR
+// sums[b] = sum over (C,H,W) of (a - b)^2 for sample b (fp64); blocks_per_b blocks per sample, memory order of whichever
+// layout is dense
+__global__ __launch_bounds__(LB) void sqdiff_kernel(T4 a, T4 bt, double* sums, int C, int H, int W, int blocks_per_b) {
+  const int b = blockIdx.x / blocks_per_b, blk = blockIdx.x % blocks_per_b;
+  const long n = (long)C * H * W;
+  const float* pa = (const float*)a.p;
+  const float* pb = (const float*)bt.p;
+  float part = 0.f;
+  double acc[1] = {0.0};
+  int cnt = 0;
+  for (long idx = (long)blk * LB + threadIdx.x; idx < n; idx += (long)blocks_per_b * LB) {
+    int c, y, x;
+    long r = idx;
+    if (a.sc == 1) { c = r % C; r /= C; x = r % W; y = r / W; }
+    else           { x = r % W; r /= W; y = r % H; c = r / H; }
+    const float d = pa[(long)b * a.sb + (long)c * a.sc + (long)y * a.sh + (long)x * a.sw] -
+                    pb[(long)b * bt.sb + (long)c * bt.sc + (long)y * bt.sh + (long)x * bt.sw];
+    part = __builtin_fmaf(d, d, part);
+    if (++cnt == 64) { acc[0] += (double)part; part = 0.f; cnt = 0; }
+  }
+  acc[0] += (double)part;
+  block_reduce_atomic<1>(acc, sums + b);
+}
+
 static inline int rgrid(long n) {
   long blocks = (n + LB - 1) / LB;
   return (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
@@ -581,4 +606,19 @@ extern "C" int ocf_device_info(char* name, int name_len, int* compute_units) {
   }
   if (compute_units) *compute_units = prop.multiProcessorCount;
   return OCF_OK;
+}
+
+extern "C" int ocf_sqdiff(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W, void* stream) {
+  ocf::clear_stale_error();
+  if (!img1 || !img2 || !sums || !img1->data || !img2->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, (size_t)B * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
+  const long n = (long)C * H * W;
+  long bpb = (n + (long)LB * 8 - 1) / ((long)LB * 8);
+  if (bpb < 1) bpb = 1;
+  if (bpb > 512) bpb = 512;
+  if ((long)B * bpb > 0x7fffffffL) return OCF_EUNSUPPORTED;
+  hipLaunchKernelGGL(sqdiff_kernel, dim3((unsigned)(B * bpb)), dim3(LB), 0, st, mk(img1), mk(img2), sums, C, H, W, (int)bpb);
+  return launch_status();
 }

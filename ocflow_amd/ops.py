@@ -536,6 +536,26 @@ def ssim(img1, img2, window_size=11, size_average=True):
     return per_sample.mean() if size_average else per_sample
 
 
+def psnr(img1, img2, pixel_max=255.0, per_sample=True):
+    """Drop-in for inpainting_metrics/psnr/psnr.py:4-11 applied image by image as calculate_psnr does
+    (inpainting_metrics/__init__.py:76-78: `psnr((img+1)*127.5, (complete+1)*127.5)` on numpy copies of each image): here one
+    kernel over the batch, on the device.  `img1`, `img2`: [B,C,H,W] already in the 0..pixel_max scale.  Returns the per-image
+    values [B] (100 where the images are identical, like the reference), or their mean when per_sample is False."""
+    _check4(img1, "img1")
+    _check4(img2, "img2")
+    if img1.shape != img2.shape:
+        raise ValueError("psnr: image shapes differ")
+    _require_hip(img1, img2)
+    a, b = _f32(img1.detach()), _f32(img2.detach())
+    B, C_, H, W = a.shape
+    sums = torch.empty(B, device=a.device, dtype=torch.float64)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().ocf_sqdiff(_t4(a), _t4(b), C.c_void_p(sums.data_ptr()), B, C_, H, W, _stream(a)), "ocf_sqdiff")
+    mse = sums / (C_ * H * W)
+    val = torch.where(mse == 0, torch.full_like(mse, 100.0), 20.0 * torch.log10(float(pixel_max) / torch.sqrt(mse.clamp_min(1e-300))))
+    return val if per_sample else val.mean()
+
+
 # ---------------------------------------------------------------------------------- convolution epilogue
 _ZERO_POOL = {}  # device index -> [fp32 buffer of zeros, next free element, graph-capture id it was filled in (0 = eager)]
 _ZERO_POOL_ELEMS = 1 << 16

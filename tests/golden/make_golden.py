@@ -343,7 +343,24 @@ def gold_ssim():
     save("ssim", **arrs)
 
 
+# ------------------------------------------------------------- 10. PSNR metric (sibling of SSIM)
+def gold_psnr():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_psnr", os.path.join(REF, "inpainting_metrics", "psnr", "psnr.py"))
+    ref_psnr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_psnr)
+    a = torch.rand((3, 3, 16, 20), generator=g(93)) * 2 - 1
+    b = (a + 0.1 * torch.randn(a.shape, generator=g(94))).clamp(-1, 1)
+    b[2] = a[2]  # identical pair: the reference returns 100
+    # exactly what calculate_psnr feeds the function (inpainting_metrics/__init__.py:76-78): per image, 0..255 scale, numpy
+    vals = [ref_psnr.psnr((x.numpy() + 1) * 127.5, (y.numpy() + 1) * 127.5) for x, y in zip(a, b)]
+    save("psnr", a=a, b=b, psnr=np.asarray(vals, dtype=np.float64))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "psnr":
+        gold_psnr()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ssim":
         gold_ssim()
         sys.exit(0)
@@ -357,4 +374,5 @@ if __name__ == "__main__":
     gold_range()
     gold_epe()
     gold_ssim()
+    gold_psnr()
     gold_nets()

@@ -568,3 +568,21 @@ def test_corr_backward_odd_shapes(ops, shape, d, dtype, with_occ):
     for got, want in ((g1, g1r), (g2, g2r)):
         scale = float(want.abs().max()) + 1e-12
         np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=tol * 5, atol=tol * scale)
+
+
+def test_psnr_golden(ops, golden):
+    """ops.psnr (one reduction kernel over the batch) against the reference's per-image numpy psnr, incl. the identical-pair case
+    (100) and a strided view of a [B,6,H,W] batch at a Sintel-sized frame against the oracle"""
+    g = golden("psnr")
+    a, b = (dev(g["a"]) + 1) * 127.5, (dev(g["b"]) + 1) * 127.5
+    np.testing.assert_allclose(ops.psnr(a, b).cpu().numpy(), g["psnr"], rtol=1e-5, atol=1e-4)
+    assert abs(float(ops.psnr(a, b, per_sample=False)) - float(g["psnr"].mean())) < 1e-3
+    gen = torch.Generator().manual_seed(8)
+    imgs = torch.rand((2, 6, 109, 256), generator=gen) * 255
+    got = ops.psnr(imgs.to(DEV)[:, :3], imgs.to(DEV)[:, 3:]).cpu().numpy()
+    want = [O.psnr(imgs[i, :3], imgs[i, 3:]) for i in range(2)]
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    cl = imgs.to(DEV).contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(ops.psnr(cl[:, :3], cl[:, 3:]).cpu().numpy(), want, rtol=1e-5)
+    with pytest.raises(ValueError):
+        ops.psnr(a, b[:, :2])
