@@ -76,6 +76,24 @@ int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4
                  const ocf_tensor4* out, int B, int C, int H, int W, int d, float flow_scale, int align_corners,
                  int dtype, void* stream);
 
+/* Diagnostics: which kernel ocf_corr_fwd launches for a request (same arguments, nothing is launched).  The parity tests assert
+ * that every instantiation the benchmark times is the one they value-check. */
+enum ocf_corr_variant {
+  OCF_CORR_ROWS_K1 = 1,         /* bf16 row kernel, one 32-channel block   (dense channels_last, d = 4, C <= 32)  */
+  OCF_CORR_ROWS_K2 = 2,         /* bf16 row kernel, two blocks resident    (dense channels_last, d = 4, C <= 64)  */
+  OCF_CORR_BAND_TH8 = 11,       /* bf16 band-GEMM kernel, C <= 32, 32x8 tiles, persistent multi-tile walk         */
+  OCF_CORR_BAND_MULTI_TH4 = 12, /* bf16 band-GEMM kernel, C > 32, 4-row tiles                                      */
+  OCF_CORR_BAND_MULTI_TH2 = 13, /*   ... 2-row tiles (fewer 4-row tiles than CUs)                                  */
+  OCF_CORR_BAND_MULTI_TH1 = 14, /*   ... 1-row tiles (fewer than a quarter of that)                                */
+  OCF_CORR_VECTOR_F32 = 20      /* fp32 vector-ALU kernel                                                          */
+};
+int ocf_corr_fwd_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
+                         const ocf_tensor4* out, int B, int C, int H, int W, int d, int dtype);
+/* Kernel selection policy of ocf_corr_fwd for bf16 (process-wide; results are the same under every policy, only the kernel
+ * differs -- for A/B measurements and for testing the kernels the automatic choice would not pick). */
+enum ocf_corr_policy { OCF_CORR_POLICY_AUTO = 0, OCF_CORR_POLICY_BAND_ONLY = 1 };
+int ocf_corr_fwd_select(int policy);
+
 /* gradient of the plain cost volume w.r.t. both operands (w2 materialised by the caller):
  *   g1[b,c,y,x] = 1/C sum_k gout[b,k,y,x]       * w2[b,c,y+dy,x+dx]
  *   g2[b,c,y,x] = 1/C sum_k gout[b,k,y-dy,x-dx] * f1[b,c,y-dy,x-dx]
@@ -108,6 +126,14 @@ int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tens
                  const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners, int dtype,
                  void* stream);
 
+/* Deterministic variant: the same contributions accumulated through 64-bit fixed-point integer atomics
+ * (2^-36 resolution, |sum| < 1.3e8) in a caller-provided workspace of ocf_warp_bwd_det_workspace_bytes() bytes (zeroed by the
+ * launcher), then converted to fp32: results are bit-identical from run to run.  gimg need NOT be zeroed; any strides. */
+int ocf_warp_bwd_det_workspace_bytes(int B, int C, int H, int W, int64_t* bytes);
+int ocf_warp_bwd_det(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
+                     const ocf_tensor4* gflow, void* workspace, int B, int C, int H, int W, float flow_scale, int align_corners,
+                     int dtype, void* stream);
+
 /* ---- K4  Charbonnier photometric error, optionally fused with the AC-True image warp ------
  * e = sqrt((P - img1)^2 + 1e-6),  P = img2 (flow==NULL) or warp_ac1(img2, flow)
  * sums[0] = sum e*(1-occ)   sums[1] = sum (1-occ)   (occ==NULL: occ := 0, sums[1] = B*H*W)
@@ -138,6 +164,10 @@ int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const f
  * range is zeroed by the launcher.
  * replaces: flow_to_warp + compute_range_map  models/model.py:223-305 (dup flow_model.py:81-163), model.py:391 */
 int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, int B, int H, int W, void* stream);
+
+/* deterministic variant (fixed-point integer atomics, see ocf_warp_bwd_det); workspace: ocf_range_map_det_workspace_bytes() */
+int ocf_range_map_det_workspace_bytes(int B, int H, int W, int64_t* bytes);
+int ocf_range_map_det(const ocf_tensor4* flow, float* range, float* occ, void* workspace, int B, int H, int W, void* stream);
 
 /* ---- K3  moments for normalize_features ---------------------------------------------------
  * sums[2*b+0] = sum over (C,H,W) of f[b],  sums[2*b+1] = sum of squares  (fp64, B pairs)

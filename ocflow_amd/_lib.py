@@ -36,10 +36,16 @@ SIGNATURES = {
     "ocf_profile_next_launch": [_vp, _vp],
     "ocf_stream_capture_id": [_vp, C.POINTER(C.c_ulonglong)],
     "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ocf_corr_fwd_variant": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i],
+    "ocf_corr_fwd_select": [_i],
     "ocf_corr_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_corr_occ_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_warp_fwd": [_T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ocf_warp_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ocf_warp_bwd_det_workspace_bytes": [_i, _i, _i, _i, C.POINTER(C.c_int64)],
+    "ocf_warp_bwd_det": [_T4P, _T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ocf_range_map_det_workspace_bytes": [_i, _i, _i, C.POINTER(C.c_int64)],
+    "ocf_range_map_det": [_T4P, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ocf_photo_loss_fwd": [_T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
     "ocf_photo_loss_bwd": [_T4P, _T4P, _T4P, _T4P, _vp, _T4P, _T4P, _i, _i, _i, _i, _vp],
     "ocf_smooth_loss_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _f, _vp],

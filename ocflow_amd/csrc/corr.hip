@@ -59,8 +59,12 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2,
   u32x4* s_f2 = smem;
   u32x4* s_f1 = smem + G::F2_SLOTS;
 
-  const int ablate = out_mode >> 8;  // tuning aid: bit0 no compute, bit1 no global loads, bit2 no output
+#ifdef OCF_TUNING_BUILD  // ablation switches exist only in the library tools/kbench builds for itself (-DOCF_TUNING_BUILD)
+  const int ablate = out_mode >> 8;  // bit0 no compute, bit1 no global loads, bit2 no output
   out_mode &= 0xff;
+#else
+  constexpr int ablate = 0;
+#endif
   const int tid = threadIdx.x;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tpi = tiles_x * tiles_y;
@@ -321,6 +325,9 @@ constexpr int BTW = 16, BTH = 4, BNU = 4;
 template <typename T, bool G2, int D, int VEC>
 __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t, T4 occ, T4 w2own, T4 gocc, int B, int C, int H, int W,
                                                       int tiles_x, int tiles_y, int ablate) {
+#ifndef OCF_TUNING_BUILD
+  ablate = 0;  // the ablation switches only exist in the tuning build of tools/kbench
+#endif
   constexpr int U = Unit<T>::U, ES = (int)sizeof(T);
   constexpr int N = 2 * D + 1, NK = N * N;
   constexpr int HH = BTH + 2 * D, HW = BTW + 2 * D;
@@ -551,7 +558,11 @@ static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, con
   const int split = (B * tx * ty <= 128) ? ncb : 1;  // under half a tile per CU: one workgroup per (tile, channel block); measured
                                                      // 81 -> 28 us and 60 -> 34 us (g1+g2) at the two top levels, slower from 224 tiles up
   const dim3 grid((unsigned)(B * tx * ty), (unsigned)split), block(256);
-  static const int ablate = getenv("OCF_ABLATE_BWD") ? atoi(getenv("OCF_ABLATE_BWD")) : 0;  // 0 in production
+#ifdef OCF_TUNING_BUILD
+  static const int ablate = getenv("OCF_ABLATE_BWD") ? atoi(getenv("OCF_ABLATE_BWD")) : 0;
+#else
+  constexpr int ablate = 0;
+#endif
   switch (d) {
     case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
     case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
@@ -604,7 +615,9 @@ static int corr_fwd_t(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_te
                    out->sb % PX == 0;
     out_mode = v ? OUT_DIRECT_VEC : OUT_DIRECT;
   }
-  if (const char* ab = getenv("OCF_ABLATE")) out_mode |= atoi(ab) << 8;  // kernel-tuning aid (tools/kbench), 0 in production
+#ifdef OCF_TUNING_BUILD
+  if (const char* ab = getenv("OCF_ABLATE")) out_mode |= atoi(ab) << 8;
+#endif
   const T4 a = mk(f1), bq = mk(f2), fl = mk(flow), oc = mk(occ), o = mk(out);
 #define OCF_DISPATCH(V)                                                                                              \
   (flow ? launch_fwd_d<T, V, 2>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)                               \
@@ -671,6 +684,22 @@ extern "C" int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const 
   ocf::ScopedProfile prof(st);
   if (dtype == OCF_F32) return ocf::corr_fwd_t<float>(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, st);
   return OCF_EINVAL;
+}
+
+extern "C" int ocf_corr_fwd_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
+                                    const ocf_tensor4* out, int B, int C, int H, int W, int d, int dtype) {
+  if (!f1 || !f2 || !out || !f1->data || !f2->data || !out->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
+  if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
+  if (dtype == OCF_F32) return OCF_CORR_VECTOR_F32;
+  if (dtype != OCF_BF16) return OCF_EINVAL;
+  return ocf::corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d);
+}
+
+extern "C" int ocf_corr_fwd_select(int policy) {
+  if (policy != OCF_CORR_POLICY_AUTO && policy != OCF_CORR_POLICY_BAND_ONLY) return OCF_EINVAL;
+  ocf::corr_fwd_set_policy(policy);
+  return OCF_OK;
 }
 
 extern "C" int ocf_corr_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* gout, const ocf_tensor4* g1,

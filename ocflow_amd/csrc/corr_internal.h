@@ -7,4 +7,13 @@ namespace ocf {
 // bf16 forward on the matrix cores (corr_mfma.hip)
 int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                        const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st);
+// which kernel a bf16 forward request gets (enum ocf_corr_variant), without launching anything
+int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
+                          const ocf_tensor4* out, int B, int C, int H, int W, int d);
+void corr_fwd_set_policy(int policy);
+// the row kernel (corr_rows.hip): dense channels_last bf16, d = 4, C <= 64, no in-kernel warp
+bool corr_rows_eligible(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* out, int C, int H,
+                        int W, int d);
+int corr_fwd_bf16_rows(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* occ, const ocf_tensor4* out, int B, int C, int H,
+                       int W, hipStream_t st);
 }  // namespace ocf

@@ -85,8 +85,12 @@ __global__ __launch_bounds__(64 * (2 * D + 1), (MULTI || TH > 4) ? 3 : 5) void c
   unsigned short* s_out = (unsigned short*)(smem + GG::F2_SLOTS + GG::F1_SLOTS);
   float* s_occ = (float*)(smem + GG::F2_SLOTS + GG::F1_SLOTS + (GG::OUT_ELEMS * ES + 15) / 16);
 
-  const int ablate = out_mode >> 8;  // tuning aid (tools/kbench): bit0 no MFMA, bit1 no global loads, bit2 no output
+#ifdef OCF_TUNING_BUILD  // ablation switches exist only in the library tools/kbench builds for itself (-DOCF_TUNING_BUILD)
+  const int ablate = out_mode >> 8;  // bit0 no MFMA, bit1 no global loads, bit2 no output
   out_mode &= 0xff;
+#else
+  constexpr int ablate = 0;
+#endif
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int ln = lane & 15, lg = lane >> 4;
@@ -434,14 +438,24 @@ static int launch_mfma_th(const T4& f1, const T4& f2, const T4& flow, const T4& 
   return launch_status();
 }
 
+// which band-GEMM instantiation a shape gets (also reported by ocf_corr_fwd_variant)
+static int band_variant(int B, int C, int H, int W) {
+  if (C <= 32) return OCF_CORR_BAND_TH8;
+  const long tiles4 = (long)B * ((W + mf::TW - 1) / mf::TW) * ((H + TH_MULTI - 1) / TH_MULTI);
+  if (tiles4 * 4 < num_cus()) return OCF_CORR_BAND_MULTI_TH1;
+  if (tiles4 < num_cus()) return OCF_CORR_BAND_MULTI_TH2;
+  return OCF_CORR_BAND_MULTI_TH4;
+}
+
 template <int VEC, int MODE, int D>
 static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
                        float fs, int ac, int out_mode, hipStream_t st) {
-  if (C <= 32) return launch_mfma_th<VEC, MODE, D, false, TH_SINGLE>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
-  const long tiles4 = (long)B * ((W + mf::TW - 1) / mf::TW) * ((H + TH_MULTI - 1) / TH_MULTI);
-  if (tiles4 * 4 < num_cus()) return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_TINY>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
-  if (tiles4 < num_cus()) return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_SMALL>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
-  return launch_mfma_th<VEC, MODE, D, true, TH_MULTI>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+  switch (band_variant(B, C, H, W)) {
+    case OCF_CORR_BAND_TH8: return launch_mfma_th<VEC, MODE, D, false, TH_SINGLE>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+    case OCF_CORR_BAND_MULTI_TH1: return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_TINY>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+    case OCF_CORR_BAND_MULTI_TH2: return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_SMALL>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+    default: return launch_mfma_th<VEC, MODE, D, true, TH_MULTI>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+  }
 }
 
 template <int VEC, int MODE>
@@ -456,8 +470,19 @@ static int launch_mfma_d(const T4& f1, const T4& f2, const T4& flow, const T4& o
   }
 }
 
+static int g_corr_policy = 0;  // ocf_corr_fwd_select: 0 = automatic, 1 = band-GEMM kernels only
+void corr_fwd_set_policy(int p) { g_corr_policy = p; }
+
+int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
+                          const ocf_tensor4* out, int B, int C, int H, int W, int d) {
+  if (g_corr_policy == 0 && corr_rows_eligible(f1, f2, flow, out, C, H, W, d)) return C <= 32 ? OCF_CORR_ROWS_K1 : OCF_CORR_ROWS_K2;
+  return band_variant(B, C, H, W);
+}
+
 int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                        const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st) {
+  if (corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d) <= OCF_CORR_ROWS_K2)
+    return corr_fwd_bf16_rows(f1, f2, occ, out, B, C, H, W, st);
   auto span = [&](const ocf_tensor4* t, long c) { return (labs(t->sh) * H + labs(t->sw) * W + labs(t->sc) * c) * 2L; };
   if (span(f1, C) >= (1L << 31) || span(f2, C) >= (1L << 31)) return OCF_EUNSUPPORTED;
   int vec = min_vec(vec_width<bf16>(f1), vec_width<bf16>(f2));
@@ -468,7 +493,9 @@ int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_t
   const bool dense = out->sc == 1 && out->sw == nk && ((uintptr_t)out->data % 16 == 0) && (out->sh * 2) % 16 == 0 &&
                      (out->sb * 2) % 16 == 0 && ((long)mf::TW * nk * 2) % 16 == 0;
   int out_mode = dense ? MOUT_CL_VEC : MOUT_GENERIC;
-  if (const char* ab = getenv("OCF_ABLATE")) out_mode |= atoi(ab) << 8;  // kernel-tuning aid (tools/kbench), 0 in production
+#ifdef OCF_TUNING_BUILD
+  if (const char* ab = getenv("OCF_ABLATE")) out_mode |= atoi(ab) << 8;
+#endif
   const T4 a = mk(f1), bq = mk(f2), fl = mk(flow), oc = mk(occ), o = mk(out);
 #define OCF_DISPATCH(V)                                                                            \
   (flow ? launch_mfma_d<V, 2>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)               \

@@ -1,10 +1,12 @@
 // K2: backward bilinear warp with zero padding, both align_corners variants.
 // reference: cost_volume_flow_net.py:121-151 (AC-False), models/model.py:191-221 (AC-True).
 //
-// One thread per output pixel; the thread walks the pixel's channels in 16-byte units (channels_last:
-// one global_load_dwordx4 per neighbour and unit) or per channel plane (NCHW: lanes = consecutive x,
-// coalesced).  Backward: grad_img is a scatter (float atomics into an fp32 buffer, 4 neighbours),
-// grad_flow is accumulated in registers over the channels and written once -- no atomics.
+// channels_last (the throughput layout): forward = one lane per (pixel, 16-byte channel unit) -- warp_fwd_cl_kernel; backward = one
+// lane per (pixel, channel) -- warp_bwd_cl_kernel: grad_img is a scatter (float atomics whose wave instructions cover whole
+// contiguous channel runs of a neighbour pixel), grad_flow a wave-shuffle reduction over the pixel's channel lanes followed by
+// one float atomic pair per lane group (so grad_flow IS accumulated with atomics there and is zeroed by the launcher).
+// NCHW / strided views: one thread per output pixel walking the channels (warp_fwd_kernel / warp_bwd_kernel; grad_flow in
+// registers, written once).  Run-to-run bit-identical variant: det.hip.
 #include "ocf_common.h"
 
 namespace ocf {

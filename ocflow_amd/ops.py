@@ -24,13 +24,29 @@ from . import _lib
 __all__ = [
     "compute_cost_volume", "corr_warp", "warp", "normalize_features", "robust_l1", "photometric_error",
     "warp_photometric_error", "gradient", "first_order_smoothness_loss", "second_order_smoothness_loss",
-    "smoothness_losses", "compute_range_map", "occlusion_from_flow", "ssim",
+    "smoothness_losses", "compute_range_map", "occlusion_from_flow", "ssim", "psnr", "set_deterministic",
 ]
 
 MAX_DISPLACEMENT = 4
 _FUSED_WARP = os.environ.get("OCFLOW_FUSED_WARP", "0") == "1"
 
 _KERNEL_TIMER = None
+_DETERMINISTIC = os.environ.get("OCFLOW_DETERMINISTIC", "0") == "1"
+
+
+def set_deterministic(flag: bool = True):
+    """Run-to-run bit-identical results for the two scatter kernels (warp backward, range map): they accumulate through 64-bit
+    fixed-point integer atomics instead of float atomics (ocf_warp_bwd_det / ocf_range_map_det).  Slower; off by default
+    (OCFLOW_DETERMINISTIC=1 turns it on at import).  Every other kernel is deterministic by construction except the fp64 / fp32
+    block-partial atomics of the reductions, whose arrival-order effect is below fp32 resolution of the loss."""
+    global _DETERMINISTIC
+    _DETERMINISTIC = bool(flag)
+
+
+def _workspace(nbytes_fn, *args, device):
+    n = C.c_int64(0)
+    _lib.check(nbytes_fn(*args, C.byref(n)), "workspace size query")
+    return torch.empty(n.value, device=device, dtype=torch.uint8)
 
 
 def set_kernel_timer(timer):
@@ -118,10 +134,21 @@ def _warp_fwd_raw(img, flow, flow_scale, align_corners):
 
 def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flow):
     B, C_, H, W = img.shape
-    gimg = _zeros_like_layout(img, img.shape, torch.float32) if need_img else None
-    gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32) if need_flow else None
     if gout.dtype != img.dtype:
         gout = gout.to(img.dtype)
+    if _DETERMINISTIC:
+        L = _lib.load()
+        gimg = _empty_like_layout(img, img.shape, torch.float32) if need_img else None
+        gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32) if need_flow else None
+        ws = _workspace(L.ocf_warp_bwd_det_workspace_bytes, B, C_, H, W, device=img.device)
+        with torch.cuda.device(img.device):
+            _lib.check(L.ocf_warp_bwd_det(_t4(img), _t4(flow), _t4(gout), _t4(gimg), _t4(gflow), C.c_void_p(ws.data_ptr()), B, C_, H, W,
+                                          float(flow_scale), int(bool(align_corners)), _dtype_code(img), _stream(img)), "ocf_warp_bwd_det")
+        if gimg is not None and gimg.dtype != img.dtype:
+            gimg = gimg.to(img.dtype)
+        return gimg, gflow
+    gimg = _zeros_like_layout(img, img.shape, torch.float32) if need_img else None
+    gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32) if need_flow else None
     with torch.cuda.device(img.device):
         _lib.check(_lib.load().ocf_warp_bwd(_t4(img), _t4(flow), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W,
                                             float(flow_scale), int(bool(align_corners)), _dtype_code(img), _stream(img)),
@@ -225,10 +252,14 @@ class _CorrWarpFn(Function):
 
 
 def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flow_scale=1.0, align_corners=False):
-    """Cost volume of features1 against  warp(features2, flow*flow_scale) [* occ]  in ONE kernel: the search window
-    is gathered through the warp straight into LDS, the warped tensor never exists in HBM.
+    """Cost volume of features1 against  warp(features2, flow*flow_scale) [* occ].
 
-    Fuses the per-level chain  warp -> [* occ] -> correlation  of flow_net.py:110-112 and
+    With a flow this is TWO launches by default -- ocf_warp_fwd materialises the warped operand (backward and the occlusion
+    estimators need it as a tensor anyway), then ocf_corr_fwd with the mask applied to the band outputs; measured faster than the
+    single launch at every pyramid level.  OCFLOW_FUSED_WARP=1 selects the single launch that gathers the
+    search window through the warp straight into LDS (the warped tensor then never exists in HBM; same values).
+
+    Replaces the per-level chain  warp -> [* occ] -> correlation  of flow_net.py:110-112 and
     cost_volume_flow_occ_net.py:204-206 (with flow=None, occ given: flow_occ_net.py:167-168)."""
     _check4(features1, "features1")
     _check4(features2, "features2")
@@ -495,9 +526,15 @@ def _range_map(flow, want_occ):
     B, _, H, W = f.shape
     rng = torch.empty((B, 1, H, W), device=f.device, dtype=torch.float32)
     occ = torch.empty_like(rng) if want_occ else None
+    occ_p = C.c_void_p(occ.data_ptr()) if want_occ else None
     with torch.cuda.device(f.device):
-        _lib.check(_lib.load().ocf_range_map(_t4(f), C.c_void_p(rng.data_ptr()), C.c_void_p(occ.data_ptr()) if want_occ else None,
-                                             B, H, W, _stream(f)), "ocf_range_map")
+        if _DETERMINISTIC:
+            L = _lib.load()
+            ws = _workspace(L.ocf_range_map_det_workspace_bytes, B, H, W, device=f.device)
+            _lib.check(L.ocf_range_map_det(_t4(f), C.c_void_p(rng.data_ptr()), occ_p, C.c_void_p(ws.data_ptr()), B, H, W, _stream(f)),
+                       "ocf_range_map_det")
+        else:
+            _lib.check(_lib.load().ocf_range_map(_t4(f), C.c_void_p(rng.data_ptr()), occ_p, B, H, W, _stream(f)), "ocf_range_map")
     return rng, occ
 
 

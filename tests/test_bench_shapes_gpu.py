@@ -1,0 +1,248 @@
+"""GPU parity ON THE TIMED PATH: the exact shapes `bench.py` runs (8 pairs per GPU at 436x1024 => the five FPN pyramid levels
+B=8 x (C, h, w) below, and 8 x 3 x 436 x 1024 for the loss kernels), HIP kernels through the C ABI against the CPU oracle on the
+same seeded inputs.  Each correlation test also asserts WHICH kernel instantiation ran (ocf_corr_fwd_variant), under the automatic
+policy and with the band-GEMM kernels forced, so that every variant the benchmark can time is value-checked at its own shape:
+row kernel K1 / K2, band TH=8 with the persistent multi-tile walk (896 tiles > 512 workgroups), band MULTI TH=4 / TH=2 / TH=1.
+
+bf16 bar: inputs are bf16-rounded once, the oracle runs in fp32 on those values; the HIP result differs from it by the output's own
+bf16 rounding (<= 2^-8 relative) plus fp32 summation order => rtol 8e-3 (two bf16 ulps), atol 1e-3 of the value scale."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ocflow_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B = 8
+# (C, h, w) of FeaturePyramidNet at 436x1024, level 6 .. 2 and the warp displacement scale of the level (20 / 2^level)
+LEVELS = {6: (196, 7, 16), 5: (128, 14, 32), 4: (96, 28, 64), 3: (64, 55, 128), 2: (32, 109, 256)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ocflow_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ocflow_amd import _lib
+    return _lib
+
+
+def _t4(lib, t):
+    return C.byref(lib.Tensor4(t.data_ptr(), *t.stride()))
+
+
+def cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def assert_close(got, want, rtol, atol_rel, what="", outliers=0.0):
+    """|got - want| <= atol_rel * max|want| + rtol * |want| everywhere, except for at most `outliers` (a fraction) of the elements:
+    the flow gradient of a bilinear warp is DISCONTINUOUS where a sample coordinate crosses an integer, and the oracle (normalised
+    grid -> grid_sample) and the kernel (closed form) round that coordinate differently in the last bit."""
+    got = got.detach().float().cpu().numpy()
+    want = want.detach().float().cpu().numpy()
+    scale = float(np.abs(want).max()) + 1e-30
+    if outliers > 0.0:
+        bad = np.abs(got - want) > atol_rel * scale + rtol * np.abs(want)
+        assert bad.mean() <= outliers, f"{what}: {int(bad.sum())} of {bad.size} elements out of tolerance (allowed fraction {outliers})"
+        return
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol_rel * scale, err_msg=what)
+
+
+def level_inputs(level, seed=0):
+    Cc, h, w = LEVELS[level]
+    gen = torch.Generator().manual_seed(1000 * level + seed)
+    f1 = torch.randn((B, Cc, h, w), generator=gen).bfloat16()
+    f2 = torch.randn((B, Cc, h, w), generator=gen).bfloat16()
+    # a smooth-ish flow of a few pixels at this level plus out-of-range spikes at the borders
+    flow = torch.randn((B, 2, h, w), generator=gen) * 1.5
+    occ = torch.rand((B, 1, h, w), generator=gen)
+    return f1, f2, flow, occ
+
+
+# variant the automatic policy / the forced band policy must pick at B = 8 on a 256-CU MI355X
+EXPECTED = {
+    2: ("OCF_CORR_ROWS_K1", "OCF_CORR_BAND_TH8"),
+    3: ("OCF_CORR_ROWS_K2", "OCF_CORR_BAND_MULTI_TH4"),
+    4: ("OCF_CORR_BAND_MULTI_TH2", "OCF_CORR_BAND_MULTI_TH2"),
+    5: ("OCF_CORR_BAND_MULTI_TH1", "OCF_CORR_BAND_MULTI_TH1"),
+    6: ("OCF_CORR_BAND_MULTI_TH1", "OCF_CORR_BAND_MULTI_TH1"),
+}
+VARIANT_CODE = {"OCF_CORR_ROWS_K1": 1, "OCF_CORR_ROWS_K2": 2, "OCF_CORR_BAND_TH8": 11, "OCF_CORR_BAND_MULTI_TH4": 12,
+                "OCF_CORR_BAND_MULTI_TH2": 13, "OCF_CORR_BAND_MULTI_TH1": 14}
+
+
+@pytest.mark.parametrize("level", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("policy", ["auto", "band"])
+@pytest.mark.parametrize("with_occ", [True, False])
+def test_corr_forward_at_bench_shapes(ops, lib, level, policy, with_occ):
+    """flow_occ_net.py:155-168 at the benchmark's shapes: warp(f2, flow * 20/2^level) -> * occ -> cost volume"""
+    f1, f2, flow, occ = level_inputs(level)
+    Cc, h, w = LEVELS[level]
+    if policy == "band" and EXPECTED[level][0] == EXPECTED[level][1]:
+        pytest.skip("the automatic policy already picks the band kernel at this level")
+    fs = 20.0 / 2 ** level
+    L = lib.load()
+    a, b2, fl, oc = cl(f1), cl(f2), flow.to(DEV), occ.to(DEV) if with_occ else None
+    try:
+        assert L.ocf_corr_fwd_select(1 if policy == "band" else 0) == 0
+        w2 = ops.warp(b2, fl, False, flow_scale=fs) if level != 6 else b2  # level 6 is not warped (flow_occ_net.py:151)
+        out = ops.corr_warp(a, w2, None, oc, 4)
+        got_variant = L.ocf_corr_fwd_variant(_t4(lib, a), _t4(lib, w2), None, _t4(lib, oc) if with_occ else None, _t4(lib, out), B, Cc, h, w,
+                                             4, lib.OCF_BF16)
+    finally:
+        L.ocf_corr_fwd_select(0)
+    assert got_variant == VARIANT_CODE[EXPECTED[level][1 if policy == "band" else 0]], got_variant
+    assert out.dtype == torch.bfloat16 and out.shape == (B, 81, h, w) and out.stride(1) == 1
+    if level != 6:
+        assert_close(w2, O.warp(f2.float(), flow * fs, False), 8e-3, 4e-3, "warp forward")
+    # the correlation against the oracle on exactly the operand the kernel consumed (the bf16 warped tensor)
+    w2c = w2.float().cpu()
+    ref = O.compute_cost_volume(f1.float(), w2c * occ if with_occ else w2c, 4)
+    assert_close(out, ref, 8e-3, 1e-3, f"corr level {level} {policy}")
+
+
+@pytest.mark.parametrize("level", [2, 3])
+def test_row_kernel_equals_band_kernel_bitwise(ops, lib, level):
+    """same products, same fp32 accumulation order inside the MFMA, same scaling order: the two kernels agree bit for bit"""
+    f1, f2, _, occ = level_inputs(level, seed=3)
+    L = lib.load()
+    a, b2, oc = cl(f1), cl(f2), occ.to(DEV)
+    try:
+        L.ocf_corr_fwd_select(1)
+        band = ops.corr_warp(a, b2, None, oc, 4)
+        band_plain = ops.corr_warp(a, b2, None, None, 4)
+    finally:
+        L.ocf_corr_fwd_select(0)
+    assert torch.equal(ops.corr_warp(a, b2, None, oc, 4), band)
+    assert torch.equal(ops.corr_warp(a, b2, None, None, 4), band_plain)
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 5, 40), (2, 24, 9, 33), (1, 64, 7, 70), (3, 40, 13, 31), (1, 8, 1, 8), (2, 32, 4, 64), (1, 56, 3, 100)])
+@pytest.mark.parametrize("with_occ", [True, False])
+def test_row_kernel_edge_tiles(ops, lib, shape, with_occ):
+    """partial tiles in x and y, widths that are not a multiple of 8 (scalar row tail), channel counts below a full 32-channel
+    block, one-row / one-tile maps -- the row kernel (asserted) against the oracle"""
+    Bb, Cc, h, w = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    f1 = torch.randn(shape, generator=gen).bfloat16()
+    f2 = torch.randn(shape, generator=gen).bfloat16()
+    occ = torch.rand((Bb, 1, h, w), generator=gen) if with_occ else None
+    a, b2 = cl(f1), cl(f2)
+    oc = occ.to(DEV) if with_occ else None
+    out = ops.corr_warp(a, b2, None, oc, 4)
+    if (w * 81 * 2) % 16 == 0:  # rows of the dense output start on 16-byte boundaries: the row kernel's precondition
+        v = lib.load().ocf_corr_fwd_variant(_t4(lib, a), _t4(lib, b2), None, _t4(lib, oc) if with_occ else None, _t4(lib, out), Bb, Cc, h, w, 4,
+                                            lib.OCF_BF16)
+        assert v in (1, 2), v
+    ref = O.compute_cost_volume(f1.float(), f2.float() * occ if with_occ else f2.float(), 4)
+    assert_close(out, ref, 8e-3, 1e-3)
+
+
+@pytest.mark.parametrize("level", [2, 3, 4, 5, 6])
+def test_corr_occ_backward_at_bench_shapes(ops, level):
+    """ocf_corr_occ_bwd (tiled backward, mask folded in, d/docc by-product; channel-block split at the two smallest levels, 8-byte
+    granularity at C = 196) vs fp32 autograd of the oracle; gradients leave the kernel in bf16"""
+    f1, f2, _, occ = level_inputs(level, seed=1)
+    Cc, h, w = LEVELS[level]
+    gen = torch.Generator().manual_seed(77 + level)
+    cot = torch.randn((B, 81, h, w), generator=gen).bfloat16()
+    a, b2, o = f1.float().requires_grad_(), f2.float().requires_grad_(), occ.clone().requires_grad_()
+    g1r, g2r, gor = torch.autograd.grad(O.compute_cost_volume(a, b2 * o, 4), (a, b2, o), cot.float())
+    x, y, oc = cl(f1).requires_grad_(), cl(f2).requires_grad_(), occ.to(DEV).requires_grad_()
+    g1, g2, go = torch.autograd.grad(ops.corr_warp(x, y, None, oc, 4), (x, y, oc), cl(cot))
+    assert_close(g1, g1r, 2e-2, 4e-3, "grad f1")
+    assert_close(g2, g2r, 2e-2, 4e-3, "grad f2")
+    assert_close(go, gor, 2e-2, 4e-3, "grad occ")
+
+
+@pytest.mark.parametrize("level", [2, 3, 4, 5])
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_warp_backward_at_bench_shapes(ops, level, deterministic):
+    """ocf_warp_fwd / ocf_warp_bwd (AC-False feature warp) at the bench shapes vs autograd of the oracle's grid_sample warp"""
+    f1, f2, flow, _ = level_inputs(level, seed=2)
+    Cc, h, w = LEVELS[level]
+    fs = 20.0 / 2 ** level
+    gen = torch.Generator().manual_seed(5 + level)
+    cot = torch.randn((B, Cc, h, w), generator=gen).bfloat16()
+    img, fl = f2.float().requires_grad_(), flow.clone().requires_grad_()
+    gir, gfr = torch.autograd.grad(O.warp(img, fl * fs, False), (img, fl), cot.float())
+    x, f = cl(f2).requires_grad_(), flow.to(DEV).requires_grad_()
+    ops.set_deterministic(deterministic)
+    try:
+        out = ops.warp(x, f, False, flow_scale=fs)
+        gi, gf = torch.autograd.grad(out, (x, f), cl(cot))
+        if deterministic:
+            gi2, gf2 = torch.autograd.grad(ops.warp(x, f, False, flow_scale=fs), (x, f), cl(cot))
+            assert torch.equal(gi, gi2) and torch.equal(gf, gf2)
+    finally:
+        ops.set_deterministic(False)
+    assert_close(gi, gir, 2e-2, 4e-3, "grad img")
+    # the flow gradient is a sum over C channels of products with bf16 features: relative to its own scale
+    assert_close(gf, gfr, 2e-2, 4e-3, "grad flow", outliers=1e-4)
+
+
+def _loss_inputs():
+    gen = torch.Generator().manual_seed(11)
+    H, W = 436, 1024
+    base = torch.rand((B, 3, H // 4 + 2, W // 4 + 2), generator=gen) * 2 - 1
+    img1 = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
+    img2 = (img1 + 0.1 * torch.randn((B, 3, H, W), generator=gen)).clamp(-1, 1)
+    flow = torch.nn.functional.interpolate(torch.randn((B, 2, H // 16, W // 16), generator=gen) * 4, size=(H, W), mode="bilinear",
+                                           align_corners=False)
+    occ = (torch.rand((B, 1, H, W), generator=gen) < 0.3).float()
+    return img1, img2, flow, occ
+
+
+def test_loss_kernels_full_size_vs_oracle(ops):
+    """photometric (fused AC-True warp + mask), first/second-order smoothness and SSIM at 8 x 3 x 436 x 1024: values and flow
+    gradients vs the oracle (multi-block fp64-atomic reductions, 1024-block grids) -- fp32 bar"""
+    img1, img2, flow, occ = _loss_inputs()
+    fl = flow.clone().requires_grad_()
+    ref_p = O.photometric_error(O.warp(img2, fl, True), img1, occ)
+    (gp_ref,) = torch.autograd.grad(ref_p, fl)
+    fl2 = flow.clone().requires_grad_()
+    s1_ref, s2_ref = O.first_order_smoothness_loss(img1, fl2), O.second_order_smoothness_loss(img1, fl2)
+    (gs_ref,) = torch.autograd.grad(0.7 * s1_ref + 0.3 * s2_ref, fl2)
+
+    d1, d2, dfl, docc = img1.to(DEV), img2.to(DEV), flow.to(DEV).requires_grad_(), occ.to(DEV)
+    p = ops.warp_photometric_error(d1, d2, dfl, docc)
+    assert abs(float(p) - float(ref_p)) <= 2e-5 * abs(float(ref_p))
+    (gp,) = torch.autograd.grad(p, dfl)
+    assert_close(gp, gp_ref, 1e-4, 1e-5, "photometric grad_flow")
+    p_nomask = ops.warp_photometric_error(d1, d2, dfl.detach(), None)
+    ref_nomask = O.photometric_error(O.warp(img2, flow, True), img1, None)
+    assert abs(float(p_nomask) - float(ref_nomask)) <= 2e-5 * abs(float(ref_nomask))
+    dfl2 = flow.to(DEV).requires_grad_()
+    s1, s2 = ops.smoothness_losses(d1, dfl2)
+    assert abs(float(s1) - float(s1_ref)) <= 2e-5 * abs(float(s1_ref))
+    assert abs(float(s2) - float(s2_ref)) <= 2e-5 * abs(float(s2_ref))
+    (gs,) = torch.autograd.grad(0.7 * s1 + 0.3 * s2, dfl2)
+    assert_close(gs, gs_ref, 1e-4, 1e-5, "smoothness grad_flow")
+    for ws in (11, 4):
+        assert abs(float(ops.ssim(d1, d2, ws)) - float(O.ssim(img1, img2, ws))) <= 2e-5
+
+
+def test_range_map_full_batch_vs_oracle(ops):
+    """the LDS-window splat at the benchmark's 8 x 436 x 1024 (3488 workgroups), incl. flows that leave the window and the image"""
+    gen = torch.Generator().manual_seed(21)
+    flow = torch.nn.functional.interpolate(torch.randn((B, 2, 28, 64), generator=gen) * 6, size=(436, 1024), mode="bilinear")
+    flow[:, :, :3, :] *= 20.0  # far out of the window / out of the image
+    for det in (False, True):
+        ops.set_deterministic(det)
+        try:
+            rm = ops.compute_range_map(flow.to(DEV))
+            oc = ops.occlusion_from_flow(flow.to(DEV))
+            if det:
+                assert torch.equal(rm, ops.compute_range_map(flow.to(DEV)))
+        finally:
+            ops.set_deterministic(False)
+        ref = O.compute_range_map(flow)
+        assert_close(rm, ref, 1e-4, 1e-6, "range map")
+        assert_close(oc, O.occlusion_from_range(ref), 1e-4, 1e-5, "occlusion")

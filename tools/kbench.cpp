@@ -54,8 +54,22 @@ int main(int argc, char** argv) {
     CK(hipMemset(out, 0, no * es));
     ocf_tensor4 t1 = mkt(f1, B, C, H, W, cl), t2 = mkt(f2, B, C, H, W, cl), to = mkt(out, B, 81, H, W, cl), tg1 = mkt(g1, B, C, H, W, cl), tg2 = mkt(g2, B, C, H, W, cl);
     ocf_tensor4 tf = mkt(flow, B, 2, H, W, false), tc = mkt(occ, B, 1, H, W, false), tgi = mkt(gimg, B, C, H, W, cl), tgf = mkt(gflow, B, 2, H, W, false);
+    // A/B of the kernel selection policies (same results, different kernels) + a bitwise cross-check of the two outputs
+    const int var_auto = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt);
+    ocf_corr_fwd_select(OCF_CORR_POLICY_BAND_ONLY);
+    const int var_band = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt);
+    float a_band = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, nullptr, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
+    float b_band = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
+    std::vector<unsigned char> ref(no * es), got(no * es);
+    CK(hipStreamSynchronize(st)); CK(hipMemcpy(ref.data(), out, no * es, hipMemcpyDeviceToHost));
+    ocf_corr_fwd_select(OCF_CORR_POLICY_AUTO);
     float a = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, nullptr, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
     float b = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
+    CK(hipStreamSynchronize(st)); CK(hipMemcpy(got.data(), out, no * es, hipMemcpyDeviceToHost));
+    size_t ndiff = 0;
+    for (size_t i = 0; i < no * es; i++) ndiff += ref[i] != got[i];
+    printf("  variant auto %d (corr %.1f us, +occ %.1f us) | band-only %d (corr %.1f us, +occ %.1f us) | bytes differing between the two +occ outputs: %zu\n",
+           var_auto, a, b, var_band, a_band, b_band, ndiff);
     float c = time_us([&] { ocf_corr_fwd(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, 1.25f, 0, dt, st); }, st);
     float d = time_us([&] { ocf_warp_fwd(&t2, &tf, &tg1, B, C, H, W, 1.25f, 0, dt, st); }, st);
     ocf_tensor4 tgo = mkt(gflow, B, 1, H, W, false);  // d/docc written into the gflow scratch buffer
