@@ -81,6 +81,7 @@ int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4
 enum ocf_corr_variant {
   OCF_CORR_ROWS_K1 = 1,         /* bf16 row kernel, one 32-channel block   (dense channels_last, d = 4, C <= 32)  */
   OCF_CORR_ROWS_K2 = 2,         /* bf16 row kernel, two blocks resident    (dense channels_last, d = 4, C <= 64)  */
+  OCF_CORR_DIRECT = 3,          /* bf16 direct kernel: fragments straight from global memory (d = 4, 64 < C <= 128, or <= 224 for W <= 16) */
   OCF_CORR_BAND_TH8 = 11,       /* bf16 band-GEMM kernel, C <= 32, 32x8 tiles, persistent multi-tile walk         */
   OCF_CORR_BAND_MULTI_TH4 = 12, /* bf16 band-GEMM kernel, C > 32, 4-row tiles                                      */
   OCF_CORR_BAND_MULTI_TH2 = 13, /*   ... 2-row tiles (fewer 4-row tiles than CUs)                                  */
@@ -146,6 +147,16 @@ int ocf_photo_loss_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const o
 int ocf_photo_loss_bwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const ocf_tensor4* flow,
                        const ocf_tensor4* occ, const float* scale, const ocf_tensor4* gflow, const ocf_tensor4* gpred,
                        int B, int C, int H, int W, void* stream);
+
+/* ---- masked L1 of the inpainting head (BASELINE configs[3]; "next" row 8f-4, first slice) ------------------------------------
+ * sums[0] = sum_{b,c,y,x} |pred - target| * mask[b,0,y,x]   sums[1] = sum mask     (fp64, zeroed by the launcher)
+ * loss = sums[0] / (C * sums[1] + 1e-16) is formed by the caller.  pred / target [B,C,H,W], mask [B,1,H,W], all fp32, any strides.
+ * backward: gpred = scale * sign(pred - target) * mask  with scale a device fp32 scalar (dLoss/d sums[0]).
+ * replaces: `(torch.abs(img_completed-img1) * occ).sum() / (3*occ.sum() + 1e-16)`  models/inpainting_model.py:71 */
+int ocf_masked_l1_fwd(const ocf_tensor4* pred, const ocf_tensor4* target, const ocf_tensor4* mask, double* sums, int B, int C, int H,
+                      int W, void* stream);
+int ocf_masked_l1_bwd(const ocf_tensor4* pred, const ocf_tensor4* target, const ocf_tensor4* mask, const float* scale,
+                      const ocf_tensor4* gpred, int B, int C, int H, int W, void* stream);
 
 /* ---- K5  edge-aware first + second order smoothness, one pass ----------------------------
  * sums[0] = sum wx *charb(dxF)   over [B,2,H,W-1]     sums[1] = sum wy *charb(dyF)  over [B,2,H-1,W]

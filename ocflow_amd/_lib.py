@@ -48,6 +48,8 @@ SIGNATURES = {
     "ocf_range_map_det": [_T4P, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ocf_photo_loss_fwd": [_T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
     "ocf_photo_loss_bwd": [_T4P, _T4P, _T4P, _T4P, _vp, _T4P, _T4P, _i, _i, _i, _i, _vp],
+    "ocf_masked_l1_fwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
+    "ocf_masked_l1_bwd": [_T4P, _T4P, _T4P, _vp, _T4P, _i, _i, _i, _i, _vp],
     "ocf_smooth_loss_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _f, _vp],
     "ocf_smooth_loss_bwd": [_T4P, _T4P, _vp, _T4P, _i, _i, _i, _i, _f, _vp],
     "ocf_range_map": [_T4P, _vp, _vp, _i, _i, _i, _vp],

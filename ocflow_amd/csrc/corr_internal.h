@@ -11,9 +11,9 @@ int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_t
 int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                           const ocf_tensor4* out, int B, int C, int H, int W, int d);
 void corr_fwd_set_policy(int policy);
-// the row kernel (corr_rows.hip): dense channels_last bf16, d = 4, C <= 64, no in-kernel warp
-bool corr_rows_eligible(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* out, int C, int H,
-                        int W, int d);
+// the row / direct kernels (corr_rows.hip): dense channels_last bf16 output, d = 4, no in-kernel warp; 0 = not eligible
+int corr_rows_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* out, int C, int H, int W,
+                      int d);
 int corr_fwd_bf16_rows(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* occ, const ocf_tensor4* out, int B, int C, int H,
                        int W, hipStream_t st);
 }  // namespace ocf

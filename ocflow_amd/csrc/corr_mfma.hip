@@ -475,13 +475,16 @@ void corr_fwd_set_policy(int p) { g_corr_policy = p; }
 
 int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                           const ocf_tensor4* out, int B, int C, int H, int W, int d) {
-  if (g_corr_policy == 0 && corr_rows_eligible(f1, f2, flow, out, C, H, W, d)) return C <= 32 ? OCF_CORR_ROWS_K1 : OCF_CORR_ROWS_K2;
+  if (g_corr_policy == 0) {
+    const int v = corr_rows_variant(f1, f2, flow, out, C, H, W, d);
+    if (v) return v;
+  }
   return band_variant(B, C, H, W);
 }
 
 int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                        const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st) {
-  if (corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d) <= OCF_CORR_ROWS_K2)
+  if (corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d) <= OCF_CORR_DIRECT)
     return corr_fwd_bf16_rows(f1, f2, occ, out, B, C, H, W, st);
   auto span = [&](const ocf_tensor4* t, long c) { return (labs(t->sh) * H + labs(t->sw) * W + labs(t->sc) * c) * 2L; };
   if (span(f1, C) >= (1L << 31) || span(f2, C) >= (1L << 31)) return OCF_EUNSUPPORTED;

@@ -140,6 +140,50 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
   }
 }
 
+// ------------------------------------------------------------------------------------- masked L1
+// sums[0] = sum_{b,c,y,x} |pred - target| * mask[b,0,y,x],  sums[1] = sum mask   (inpainting_model.py:71: the completion loss is
+// taken over occluded pixels only); backward: gpred = scale * sign(pred - target) * mask  (torch.abs: sign(0) = 0)
+__global__ __launch_bounds__(LB) void masked_l1_fwd_kernel(T4 pred, T4 target, T4 mask, double* sums, int B, int C, int H, int W, long npix) {
+  float part[2] = {0.f, 0.f};
+  const float* pp = (const float*)pred.p;
+  const float* tp = (const float*)target.p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const float m = ((const float*)mask.p)[(long)b * mask.sb + (long)y * mask.sh + (long)x * mask.sw];
+    const long op = (long)b * pred.sb + (long)y * pred.sh + (long)x * pred.sw;
+    const long ot = (long)b * target.sb + (long)y * target.sh + (long)x * target.sw;
+    float e = 0.f;
+    for (int c = 0; c < C; c++) e += fabsf(pp[op + (long)c * pred.sc] - tp[ot + (long)c * target.sc]);
+    part[0] = __builtin_fmaf(e, m, part[0]);
+    part[1] += m;
+  }
+  double acc[2] = {(double)part[0], (double)part[1]};
+  block_reduce_atomic<2>(acc, sums);
+}
+
+__global__ __launch_bounds__(LB) void masked_l1_bwd_kernel(T4 pred, T4 target, T4 mask, const float* scale, T4 gpred, int B, int C, int H,
+                                                           int W, long npix) {
+  const float* pp = (const float*)pred.p;
+  const float* tp = (const float*)target.p;
+  float* gp = (float*)gpred.p;
+  const float sc = *scale;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+    const int x = idx % W;
+    long r = idx / W;
+    const int y = r % H, b = r / H;
+    const float k = sc * ((const float*)mask.p)[(long)b * mask.sb + (long)y * mask.sh + (long)x * mask.sw];
+    const long op = (long)b * pred.sb + (long)y * pred.sh + (long)x * pred.sw;
+    const long ot = (long)b * target.sb + (long)y * target.sh + (long)x * target.sw;
+    const long og = (long)b * gpred.sb + (long)y * gpred.sh + (long)x * gpred.sw;
+    for (int c = 0; c < C; c++) {
+      const float d = pp[op + (long)c * pred.sc] - tp[ot + (long)c * target.sc];
+      gp[og + (long)c * gpred.sc] = d > 0.f ? k : (d < 0.f ? -k : 0.f);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------- smoothness
 // exp(-mean_c (alpha * (I[p+s] - I[p]))^2) for a step of `s` pixels along x (dirx) or y.
 // CT: compile-time channel count (3 = RGB, the only case the reference has: all 2*CT loads are issued together), 0 = runtime C
@@ -496,6 +540,29 @@ extern "C" int ocf_photo_loss_bwd(const ocf_tensor4* img1, const ocf_tensor4* im
   else
     hipLaunchKernelGGL(photo_bwd_kernel<0>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
                        mk(occ), scale, mk(gflow), mk(gpred), B, C, H, W, WarpGeom(H, W, 1), npix);
+  return launch_status();
+}
+
+extern "C" int ocf_masked_l1_fwd(const ocf_tensor4* pred, const ocf_tensor4* target, const ocf_tensor4* mask, double* sums, int B, int C,
+                                 int H, int W, void* stream) {
+  ocf::clear_stale_error();
+  if (!pred || !target || !mask || !sums || !pred->data || !target->data || !mask->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, 2 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(masked_l1_fwd_kernel, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(pred), mk(target), mk(mask), sums, B, C, H, W, npix);
+  return launch_status();
+}
+
+extern "C" int ocf_masked_l1_bwd(const ocf_tensor4* pred, const ocf_tensor4* target, const ocf_tensor4* mask, const float* scale,
+                                 const ocf_tensor4* gpred, int B, int C, int H, int W, void* stream) {
+  ocf::clear_stale_error();
+  if (!pred || !target || !mask || !scale || !gpred || !pred->data || !target->data || !mask->data || !gpred->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(pred), mk(target), mk(mask), scale, mk(gpred),
+                     B, C, H, W, npix);
   return launch_status();
 }
 

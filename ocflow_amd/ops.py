@@ -24,7 +24,7 @@ from . import _lib
 __all__ = [
     "compute_cost_volume", "corr_warp", "warp", "normalize_features", "robust_l1", "photometric_error",
     "warp_photometric_error", "gradient", "first_order_smoothness_loss", "second_order_smoothness_loss",
-    "smoothness_losses", "compute_range_map", "occlusion_from_flow", "ssim", "psnr", "set_deterministic",
+    "smoothness_losses", "compute_range_map", "occlusion_from_flow", "ssim", "psnr", "set_deterministic", "masked_l1",
 ]
 
 MAX_DISPLACEMENT = 4
@@ -455,6 +455,53 @@ def warp_photometric_error(img1, img2, flow, occ=None):
     written (models/model.py:379+394 / :327-330)."""
     _check4(flow, "flow", 2)
     return _photo(img1, img2, flow, occ)
+
+
+# --------------------------------------------------------------------------------------------- masked L1
+class _MaskedL1Fn(Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        B, C_, H, W = pred.shape
+        sums = torch.empty(2, device=pred.device, dtype=torch.float64)
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.load().ocf_masked_l1_fwd(_t4(pred), _t4(target), _t4(mask), C.c_void_p(sums.data_ptr()), B, C_, H, W,
+                                                     _stream(pred)), "ocf_masked_l1_fwd")
+        ctx.save_for_backward(pred, target, mask)
+        num, den = sums[0].float(), sums[1].float()
+        ctx.mark_non_differentiable(den)
+        return num, den
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gnum, _gden):
+        pred, target, mask = ctx.saved_tensors
+        n_p, n_t, n_m = ctx.needs_input_grad
+        if n_m:
+            raise NotImplementedError("masked_l1: gradient w.r.t. the mask is not implemented (the reference's mask is data, "
+                                      "models/inpainting_model.py:63)")
+        if not (n_p or n_t):
+            return None, None, None
+        B, C_, H, W = pred.shape
+        scale = gnum.float().reshape(1).contiguous()
+        g = torch.empty((B, C_, H, W), device=pred.device, dtype=torch.float32)
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.load().ocf_masked_l1_bwd(_t4(pred), _t4(target), _t4(mask), C.c_void_p(scale.data_ptr()), _t4(g), B, C_, H, W,
+                                                     _stream(pred)), "ocf_masked_l1_bwd")
+        return (g if n_p else None), (-g if n_t else None), None
+
+
+def masked_l1(pred, target, mask):
+    """`(torch.abs(pred - target) * mask).sum() / (C * mask.sum() + 1e-16)` -- the completion loss of the inpainting head over the
+    occluded pixels only (models/inpainting_model.py:71; C = 3 there).  pred / target [B,C,H,W], mask [B,1,H,W]; one reduction pass
+    forward and one elementwise pass backward instead of sub, abs, mul, two sums and their five backward kernels."""
+    _check4(pred, "pred")
+    _check4(target, "target")
+    _check4(mask, "mask", 1)
+    if pred.shape != target.shape or mask.shape[0] != pred.shape[0] or mask.shape[2:] != pred.shape[2:]:
+        raise ValueError("masked_l1: pred / target [B,C,H,W] and mask [B,1,H,W] must agree")
+    _require_hip(pred, target, mask)
+    num, den = _MaskedL1Fn.apply(_f32(pred), _f32(target), _f32(mask))
+    return num / (den * pred.shape[1] + 1e-16)
 
 
 # -------------------------------------------------------------------------------------------- smoothness

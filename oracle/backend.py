@@ -45,6 +45,7 @@ PATCHES = {
     "occlusion_from_flow": _occ_from_flow,
     "bias_leaky_relu": O.bias_leaky_relu,
     "bias_add": O.bias_add,
+    "masked_l1": O.masked_l1,
 }
 
 
