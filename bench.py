@@ -13,13 +13,18 @@ channels_last, inputs resident in HBM before the timed region.  Per-GPU shard = 
 per-rank share of configs[4], "batch 64 across 8 GPUs"); weak scaling: per-GPU work is fixed as N grows.
 
 One JSON line on rank 0 with, besides the driver contract keys:
-  roofline     -- the fused correlation kernel (`corr_fwd_mfma`, ocf_corr_fwd): algorithmic bytes of its launches / their
-                  durations from HIP events stamped by the dispatch itself on the launch stream (hipExtLaunchKernelGGL), vs
-                  the 8 TB/s HBM3E peak; `traffic` = PMC bytes per launch from the committed rocprofv3 counter passes.  With
+  roofline     -- the cost-volume kernel (ocf_corr_fwd): algorithmic bytes of its launches / their durations from HIP events
+                  stamped by the dispatch itself on the launch stream (hipExtLaunchKernelGGL), vs the 8 TB/s HBM3E peak;
+                  `traffic` = PMC bytes per launch from the committed rocprofv3 counter passes; `copy_ceiling_GBps` = a device
+                  copy measured in this run; `kernels` = the same figures for every other hot-path kernel of the step (warp forward /
+                  backward, correlation backward and -- from the unsupervised leg -- photometric, smoothness, range map).  With
                   graph replay (default) the launches of the timed region cannot carry events, so the SAME step is run eagerly
                   right after the timed loop for this leg.
-  cpu_baseline -- the oracle (CPU restatement of the reference's op structure, "port") running the SAME training step
-                  at batch 1, fp32, on this box's host cores (N=1 only, bounded to ~20 s).
+  unsupervised -- (N = 1) the other half of the hot path: `FlowStageModel('flownet')` occlusion-aware training step (two forwards,
+                  fused warp + photometric, smoothness, range-map occlusion) on the same shapes, timed the same way.
+  cpu_baseline -- the oracle (CPU restatement of the reference's op structure, "port") on this box's host cores (N = 1 only,
+                  bounded): the SAME training step at batch 1 fp32 (best / median), `compute_cost_volume` per pyramid level in
+                  algorithmic GB/s, and one step of BASELINE configs[2] (pwc, 8 x 384 x 512) when the budget allows.
 Launch modes: one GPU = the whole step in one hipGraph; several GPUs = forward+backward graph, one RCCL all-reduce of a flat
 gradient buffer, optimizer graph (falls back, all ranks together, to eager DDP / the eager flat loop).
 """
@@ -55,7 +60,11 @@ def parse():
                         "occlusion-aware step (2 forwards + warp/photometric/smoothness/range-map loss kernels)")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--layout", default="cl", choices=["cl", "nchw"])
-    p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables it)")
+    p.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline leg (0 disables it)")
+    p.add_argument("--unsup-steps", type=int, default=10,
+                   help="timed steps of the unsupervised FlowStageModel leg (N = 1 only; 0 disables it)")
+    p.add_argument("--config", default=None, choices=[None, "cfg3"],
+                   help="cfg3: BASELINE configs[2] -- FlowStageModel('pwc') occlusion-aware step, batch 8 at 384x512")
     p.add_argument("--fused-adam", type=int, default=1,
                    help="1 (default): run the module's Adam (models/flow_occ_model.py:77-78) through torch's fused multi-tensor "
                         "kernel -- same update rule, checked in tests/test_models_gpu.py::test_fused_adam_same_update; 0: foreach")
@@ -111,35 +120,166 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("OCFLOW_CPU_CORES", "32"))))
 
 
+def cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, budget_s):
-    """Reference CPU path (oracle = port of the reference's ATen op structure) on the host cores: same model, same
-    training step, batch 1, fp32.  Bounded sample: the first step is the probe; further steps only while they fit the
-    budget.  Progress goes to stderr (a silent GPU box is taken for hung)."""
+    """Reference CPU path (oracle = port of the reference's ATen op structure) on the host cores, SURVEY 8d5: (i) the same model and
+    training step at batch 1, fp32 -- first step is the probe, further steps only while they fit the budget, best and median
+    reported; (ii) `compute_cost_volume` (pad-and-shift loop, correlation_layer.py:7-40) per pyramid level at batch 1 in
+    algorithmic GB/s (fp32 byte model h*w*(8C + 324)); (iii) one step of BASELINE configs[2] (pwc, occlusion-aware, 8 x 384 x 512)
+    if the remaining budget covers the survey's estimate for it.  Progress goes to stderr (a silent GPU box is taken for hung)."""
+    import statistics
     from oracle.backend import oracle_ops
+    from oracle import ocflow_oracle as O
     from ocflow_amd.runtime import DistEnv, TrainStepper, synthetic_batch
     cores = usable_cores()
     torch.set_num_threads(cores)
     env = DistEnv()
     times = []
+    t_start = time.perf_counter()
     with oracle_ops():
         torch.manual_seed(42)
         stepper = TrainStepper(build_module(args), env, amp_dtype=None, channels_last=False)
         batch = synthetic_batch(1, args.height, args.width, "cpu", seed=42)
-        t_start = time.perf_counter()
         while True:
             t0 = time.perf_counter()
             stepper.step(batch)
             times.append(time.perf_counter() - t0)
             print(f"[bench] cpu_baseline step {len(times)}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
             spent = time.perf_counter() - t_start
-            if len(times) >= 4 or spent + times[-1] > budget_s:
+            if len(times) >= 6 or spent + times[-1] > 0.4 * budget_s:
                 break
+        del stepper
     timed = times[1:] if len(times) > 1 else times  # first step pays allocator / oneDNN primitive warm-up
-    dt = sum(timed) / len(timed)
-    return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{len(timed)} training step(s){' after 1 warm-up' if len(times) > 1 else ' (cold)'} of "
-                      f"the same model ('{args.model}') at batch 1, {args.height}x{args.width}, fp32, oracle ops "
-                      f"(pad-and-shift correlation, grid_sample warp), {dt:.2f} s/step"}
+    med, best = statistics.median(timed), min(timed)
+    out = {"value": round(1.0 / med, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+           "best": round(1.0 / best, 4), "median": round(1.0 / med, 4),
+           "sample": f"{len(timed)} training step(s){' after 1 warm-up' if len(times) > 1 else ' (cold)'} of "
+                     f"the same model ('{args.model}') at batch 1, {args.height}x{args.width}, fp32, oracle ops "
+                     f"(pad-and-shift correlation, grid_sample warp); value = median ({med:.2f} s/step), best {best:.2f} s/step"}
+    # (ii) the correlation alone, per level (FPN shapes at this resolution)
+    levels = {}
+    gen = torch.Generator().manual_seed(1)
+    h, w = args.height, args.width
+    dims = []
+    for _ in range(6):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        dims.append((h, w))
+    for lvl, Cc, (hh, ww) in zip((6, 5, 4, 3, 2), (196, 128, 96, 64, 32), reversed(dims[1:])):
+        f1 = torch.randn((1, Cc, hh, ww), generator=gen)
+        f2 = torch.randn((1, Cc, hh, ww), generator=gen)
+        O.compute_cost_volume(f1, f2, 4)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.compute_cost_volume(f1, f2, 4)
+            ts.append(time.perf_counter() - t0)
+        nbytes = hh * ww * (8 * Cc + 324)
+        levels[f"C{Cc}x{hh}x{ww}"] = {"best_ms": round(1e3 * min(ts), 3), "GBps": round(nbytes / min(ts) / 1e9, 3)}
+    out["compute_cost_volume_levels_b1_fp32"] = levels
+    # (iii) configs[2]: the survey measured 11.8 s/step on 8 threads; run it only if that fits what is left
+    remaining = budget_s - (time.perf_counter() - t_start)
+    if remaining > 12.0 * 8 / max(cores, 1) * 1.3 + 3.0:
+        try:
+            from ocflow_amd.models.model import FlowStageModel
+            with oracle_ops():
+                torch.manual_seed(42)
+                m = FlowStageModel({"learning_rate": 1e-5, "model": "pwc", "displacement": 4, "photo_weight": 4.0, "smooth1_weight": 0.5,
+                                    "smooth2_weight": 0.0, "with_occ": False, "occ_aware": True})
+                st3 = TrainStepper(m, env, amp_dtype=None, channels_last=False)
+                b3 = synthetic_batch(8, 384, 512, "cpu", seed=42)
+                t0 = time.perf_counter()
+                st3.step(b3)
+                dt = time.perf_counter() - t0
+            print(f"[bench] cpu_baseline configs[2] step: {dt:.2f} s", file=sys.stderr, flush=True)
+            out["cfg3_pwc_b8_384x512"] = {"pairs_per_s": round(8.0 / dt, 4), "s_per_step": round(dt, 2), "steps": 1, "note": "cold single step"}
+        except Exception as e:  # noqa: BLE001
+            out["cfg3_pwc_b8_384x512"] = {"error": str(e)}
+    return out
+
+
+def copy_ceiling_gbps(device) -> float:
+    """measured device-copy rate (read + write bytes / time) of a 1 GiB fp32 tensor: the practical HBM ceiling beside the 8 TB/s
+    spec peak the roofline fraction is quoted against"""
+    n = 1 << 28
+    a = torch.empty(n, device=device, dtype=torch.float32).fill_(1.0)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2.0 * 4 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
+def kernel_rooflines(summ: dict, peak: float) -> dict:
+    """per-kernel {launches, avg_us, achieved GB/s, frac} from a KernelTimer summary"""
+    out = {}
+    for name, v in summ.items():
+        if v["ms_total"] <= 0:
+            continue
+        gbps = v["bytes_total"] / (v["ms_total"] * 1e-3) / 1e9
+        out[name] = {"launches": v["launches"], "avg_launch_us": round(1e3 * v["ms_total"] / v["launches"], 2), "achieved": round(gbps, 1),
+                     "frac": round(gbps / peak, 4), "algorithmic_bytes_per_launch": int(v["bytes_total"] / v["launches"]),
+                     "per_shape": {k: {"launches": w["launches"], "avg_us": round(1e3 * w["ms_total"] / w["launches"], 2),
+                                       "GBps": round(w["bytes"] / (1e-3 * w["ms_total"] / w["launches"]) / 1e9, 1)}
+                                   for k, w in v["by_shape"].items()}}
+    return out
+
+
+def unsupervised_leg(args, env, steps):
+    """the loss side of the hot path: FlowStageModel('flownet') occlusion-aware step (two forwards, fused warp + photometric,
+    smoothness, range map) at the same shapes, hipGraph replay, then the same step eagerly with the kernel timer"""
+    import copy
+    from ocflow_amd import ops
+    from ocflow_amd.runtime import KernelTimer, synthetic_batch
+    a2 = copy.copy(args)
+    a2.model = "flownet"
+    stepper = build_stepper(a2, env, dp_mode="ddp")
+    batch = stepper.prepare(synthetic_batch(args.batch, args.height, args.width, env.device, seed=43))
+    stepper.step(batch)
+    graphed = True
+    try:
+        stepper.enable_graph(batch)
+        batch = stepper._static_batch
+    except Exception as e:  # noqa: BLE001
+        graphed = False
+        print(f"[bench] unsupervised leg: hipGraph capture failed ({type(e).__name__}: {e}); eager", file=sys.stderr, flush=True)
+    for _ in range(6):
+        stepper.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = stepper.step(batch, i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss_val = float(loss)
+    timer = KernelTimer(enabled=True)
+    stepper._graph = None
+    ops.set_kernel_timer(timer)
+    for i in range(4):
+        stepper.step(batch, i)
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(None)
+    res = {"metric": "image-pairs/sec (unsupervised occlusion-aware training step)", "value": round(args.batch / dt, 3), "unit": "image-pairs/s",
+           "ms_per_step": round(1e3 * dt, 3), "steps": steps, "launch": "hipGraph replay" if graphed else "eager", "final_loss": round(loss_val, 5),
+           "workload": f"FlowStageModel('flownet', occ_aware) full training step, {args.batch} x {args.height}x{args.width}, {args.dtype}"}
+    if not (loss_val == loss_val and abs(loss_val) < 1e6):
+        res["invalid"] = f"loss {loss_val}"
+    return res, timer.summary()
 
 
 def pmc_traffic_per_launch():
@@ -170,6 +310,8 @@ def pmc_traffic_per_launch():
 
 def main():
     args = parse()
+    if args.config == "cfg3":  # BASELINE configs[2]: unsupervised_config.yml photometric train step, batch 8 at 384x512
+        args.model, args.batch, args.height, args.width = "pwc", 8, 384, 512
     # stdout carries exactly ONE line, the JSON result of rank 0: libraries that print to fd 1 (RCCL's version banner at
     # communicator creation, MIOpen notes) are sent to stderr for the whole run and the real stdout is restored for that line
     sys.stdout.flush()
@@ -282,8 +424,10 @@ def main():
         torch.cuda.synchronize()
     ops.set_kernel_timer(None)
     elapsed = all_reduce_max(env, elapsed)
+    weights_master = bool(stepper._masters)
 
     # ---- roofline of the dominant hot-path kernel, from the launches of the timed region itself
+    all_k = kernel_rooflines(timer.summary(), HBM_PEAK_GBPS)
     summ = timer.summary().get("corr_fwd", None)
     roofline = None
     if summ and summ["ms_total"] > 0:
@@ -292,13 +436,32 @@ def main():
                          "GBps": round(v["bytes"] / (1e-3 * v["ms_total"] / v["launches"]) / 1e9, 1)}
                      for k, v in summ["by_shape"].items()}
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "ocf::corr_fwd_mfma (ocf_corr_fwd)",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "ocf::corr_fwd_rows / corr_fwd_direct (ocf_corr_fwd)",
                     "launches": summ["launches"], "avg_launch_us": round(1e3 * summ["ms_total"] / summ["launches"], 2),
                     "algorithmic_bytes_per_launch": int(summ["bytes_total"] / summ["launches"]),
                     "tflops": round(summ["flops_total"] / (summ["ms_total"] * 1e-3) / 1e12, 2), "per_level": per_level}
 
     if roofline is not None:
         roofline.update(pmc_traffic_per_launch())
+        roofline["kernels"] = {k: v for k, v in all_k.items() if k != "corr_fwd"}
+
+    unsup = None
+    if env.is_main and env.world_size == 1 and args.unsup_steps > 0 and args.model in ("flowoccnet", "pwoc"):
+        try:
+            del stepper
+            torch.cuda.empty_cache()
+            unsup, usumm = unsupervised_leg(args, env, args.unsup_steps)
+            if roofline is not None:
+                for k, v in kernel_rooflines(usumm, HBM_PEAK_GBPS).items():
+                    roofline["kernels"].setdefault(k if k not in all_k else k + "_unsupervised", v)
+        except Exception as e:  # noqa: BLE001 - the headline numbers stay valid
+            unsup = {"error": f"{type(e).__name__}: {e}"}
+        stepper = None
+    if roofline is not None and env.is_main:
+        try:
+            roofline["copy_ceiling_GBps"] = copy_ceiling_gbps(env.device)
+        except Exception:  # noqa: BLE001
+            roofline["copy_ceiling_GBps"] = None
 
     cpu = None
     if env.is_main and env.world_size == 1 and args.cpu_seconds > 0:
@@ -324,8 +487,8 @@ def main():
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager",
                        "final_loss": round(loss_val, 5),
                        "optimizer": "adam(fused)" if args.fused_adam else "adam(foreach)",
-                       "weights": "fp32 masters + bf16 compute copies" if stepper._masters else "fp32 (autocast casts per use)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "weights": "fp32 masters + bf16 compute copies" if weights_master else "fp32 (autocast casts per use)"},
+            "roofline": roofline, "unsupervised": unsup, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.dup2(real_stdout, 1)

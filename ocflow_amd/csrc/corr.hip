@@ -550,8 +550,8 @@ __global__ __launch_bounds__(256) void corr_bwd_tiled(T4 other, T4 g, T4 gout_t,
 }
 
 template <typename T, bool G2, int VEC>
-static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, const ocf_tensor4* dst, int B, int C, int H, int W, int d,
-                             hipStream_t st, const ocf_tensor4* occ = nullptr, const ocf_tensor4* w2own = nullptr,
+static void launch_bwd_tiled(LaunchProf& lp, bool last, const ocf_tensor4* other, const ocf_tensor4* g, const ocf_tensor4* dst, int B, int C,
+                             int H, int W, int d, hipStream_t st, const ocf_tensor4* occ = nullptr, const ocf_tensor4* w2own = nullptr,
                              const ocf_tensor4* gocc = nullptr) {
   const int tx = (W + BTW - 1) / BTW, ty = (H + BTH - 1) / BTH;
   const int ncb = (C + BNU * Unit<T>::U - 1) / (BNU * Unit<T>::U);
@@ -564,10 +564,10 @@ static void launch_bwd_tiled(const ocf_tensor4* other, const ocf_tensor4* g, con
   constexpr int ablate = 0;
 #endif
   switch (d) {
-    case 1: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 1, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
-    case 2: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 2, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
-    case 3: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 3, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
-    default: hipLaunchKernelGGL((corr_bwd_tiled<T, G2, 4, VEC>), grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
+    case 1: lp.launch(last, corr_bwd_tiled<T, G2, 1, VEC>, grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
+    case 2: lp.launch(last, corr_bwd_tiled<T, G2, 2, VEC>, grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
+    case 3: lp.launch(last, corr_bwd_tiled<T, G2, 3, VEC>, grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
+    default: lp.launch(last, corr_bwd_tiled<T, G2, 4, VEC>, grid, block, 0, st, mk(other), mk(g), mk(dst), mk(occ), mk(w2own), mk(gocc), B, C, H, W, tx, ty, ablate); break;
   }
 }
 
@@ -639,9 +639,10 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
   if (g1) vec = vec && vec_ok<T>(g1);
   if (g2) vec = vec && vec_ok<T>(g2);
   // tiled path: 16-byte units everywhere, whole units only, grad_out with unit channel stride
+  LaunchProf lp;
   if (vec && C % U == 0 && g->sc == 1) {
-    if (g1) launch_bwd_tiled<T, false, 16>(w2, g, g1, B, C, H, W, d, st, occ);
-    if (g2) launch_bwd_tiled<T, true, 16>(f1, g, g2, B, C, H, W, d, st, occ, w2, gocc);
+    if (g1) launch_bwd_tiled<T, false, 16>(lp, !g2, w2, g, g1, B, C, H, W, d, st, occ);
+    if (g2) launch_bwd_tiled<T, true, 16>(lp, true, f1, g, g2, B, C, H, W, d, st, occ, w2, gocc);
     return launch_status();
   }
   // same kernel at 8-byte granularity: pixels that are a multiple of 8 bytes (C = 196 bf16 at the top pyramid level)
@@ -649,8 +650,8 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
   if (g1) v8 = min_vec(v8, vec_width<T>(g1));
   if (g2) v8 = min_vec(v8, vec_width<T>(g2));
   if (v8 >= 8 && (C * (long)sizeof(T)) % 8 == 0 && g->sc == 1) {
-    if (g1) launch_bwd_tiled<T, false, 8>(w2, g, g1, B, C, H, W, d, st, occ);
-    if (g2) launch_bwd_tiled<T, true, 8>(f1, g, g2, B, C, H, W, d, st, occ, w2, gocc);
+    if (g1) launch_bwd_tiled<T, false, 8>(lp, !g2, w2, g, g1, B, C, H, W, d, st, occ);
+    if (g2) launch_bwd_tiled<T, true, 8>(lp, true, f1, g, g2, B, C, H, W, d, st, occ, w2, gocc);
     return launch_status();
   }
   if (occ) return OCF_EUNSUPPORTED;  // the gather fallback has no occlusion path: the caller composes it from plain launches

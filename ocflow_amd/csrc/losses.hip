@@ -516,10 +516,10 @@ extern "C" int ocf_photo_loss_fwd(const ocf_tensor4* img1, const ocf_tensor4* im
   if (hipMemsetAsync(sums, 0, 2 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
   const long npix = (long)B * H * W;
   if (C == 3)
-    hipLaunchKernelGGL(photo_fwd_kernel<3>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img1), mk(img2), mk(flow), mk(occ), sums, B, C,
+    LaunchProf().launch(true, photo_fwd_kernel<3>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img1), mk(img2), mk(flow), mk(occ), sums, B, C,
                        H, W, WarpGeom(H, W, 1), npix);
   else
-    hipLaunchKernelGGL(photo_fwd_kernel<0>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img1), mk(img2), mk(flow), mk(occ), sums, B, C,
+    LaunchProf().launch(true, photo_fwd_kernel<0>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img1), mk(img2), mk(flow), mk(occ), sums, B, C,
                        H, W, WarpGeom(H, W, 1), npix);
   return launch_status();
 }
@@ -535,10 +535,10 @@ extern "C" int ocf_photo_loss_bwd(const ocf_tensor4* img1, const ocf_tensor4* im
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
   if (C == 3)
-    hipLaunchKernelGGL(photo_bwd_kernel<3>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
+    LaunchProf().launch(true, photo_bwd_kernel<3>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
                        mk(occ), scale, mk(gflow), mk(gpred), B, C, H, W, WarpGeom(H, W, 1), npix);
   else
-    hipLaunchKernelGGL(photo_bwd_kernel<0>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
+    LaunchProf().launch(true, photo_bwd_kernel<0>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img1), mk(img2), mk(flow),
                        mk(occ), scale, mk(gflow), mk(gpred), B, C, H, W, WarpGeom(H, W, 1), npix);
   return launch_status();
 }
@@ -551,7 +551,7 @@ extern "C" int ocf_masked_l1_fwd(const ocf_tensor4* pred, const ocf_tensor4* tar
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, 2 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(masked_l1_fwd_kernel, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(pred), mk(target), mk(mask), sums, B, C, H, W, npix);
+  LaunchProf().launch(true, masked_l1_fwd_kernel, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(pred), mk(target), mk(mask), sums, B, C, H, W, npix);
   return launch_status();
 }
 
@@ -561,7 +561,7 @@ extern "C" int ocf_masked_l1_bwd(const ocf_tensor4* pred, const ocf_tensor4* tar
   if (!pred || !target || !mask || !scale || !gpred || !pred->data || !target->data || !mask->data || !gpred->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(pred), mk(target), mk(mask), scale, mk(gpred),
+  LaunchProf().launch(true, masked_l1_bwd_kernel, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(pred), mk(target), mk(mask), scale, mk(gpred),
                      B, C, H, W, npix);
   return launch_status();
 }
@@ -575,9 +575,9 @@ extern "C" int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* fl
   if (hipMemsetAsync(sums, 0, 4 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
   const long npix = (long)B * H * W;
   if (C == 3)
-    hipLaunchKernelGGL(smooth_fwd_kernel<3>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
+    LaunchProf().launch(true, smooth_fwd_kernel<3>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
   else
-    hipLaunchKernelGGL(smooth_fwd_kernel<0>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
+    LaunchProf().launch(true, smooth_fwd_kernel<0>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
   return launch_status();
 }
 
@@ -588,10 +588,10 @@ extern "C" int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* fl
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
   if (C == 3)
-    hipLaunchKernelGGL(smooth_bwd_kernel<3>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
+    LaunchProf().launch(true, smooth_bwd_kernel<3>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
                        B, C, H, W, alpha, npix);
   else
-    hipLaunchKernelGGL(smooth_bwd_kernel<0>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
+    LaunchProf().launch(true, smooth_bwd_kernel<0>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
                        B, C, H, W, alpha, npix);
   return launch_status();
 }
@@ -605,8 +605,9 @@ extern "C" int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, 
   if (hipMemsetAsync(range, 0, npix * sizeof(float), st) != hipSuccess) return OCF_ELAUNCH;
   const int tiles_x = (W + RSW - 1) / RSW, tiles_y = (H + RSH - 1) / RSH;
   if ((long)B * tiles_x * tiles_y > 0x7fffffffL) return OCF_EUNSUPPORTED;
-  hipLaunchKernelGGL(range_splat_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(LB), 0, st, mk(flow), range, B, H, W, tiles_x, tiles_y);
-  if (occ) hipLaunchKernelGGL(occ_from_range_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, (const float*)range, occ, npix);
+  LaunchProf lp;
+  lp.launch(!occ, range_splat_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(LB), 0, st, mk(flow), range, B, H, W, tiles_x, tiles_y);
+  if (occ) lp.launch(true, occ_from_range_kernel, dim3(rgrid(npix)), dim3(LB), 0, st, (const float*)range, occ, npix);
   return launch_status();
 }
 
@@ -629,7 +630,7 @@ extern "C" int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, do
   int gx = (4096 + B * C - 1) / (B * C);  // ~4096 workgroups in total, each walking ntiles / gx tiles
   if (gx > ntiles) gx = ntiles;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(ssim_fwd_kernel, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(LB), 0, st, mk(img1), mk(img2), sums, C, H, W, Ho, Wo,
+  LaunchProf().launch(true, ssim_fwd_kernel, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(LB), 0, st, mk(img1), mk(img2), sums, C, H, W, Ho, Wo,
                      window_size, pad, win, tiles_x, ntiles);
   return launch_status();
 }

@@ -1,6 +1,7 @@
 // Shared device helpers for the OCFlow gfx950 kernels (wave = 64 lanes, 16-byte channel units).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "ocflow_hip.h"
 
@@ -220,6 +221,24 @@ struct ScopedProfile {
     p.start = nullptr; p.stop = nullptr;
   }
   ~ScopedProfile() { if (stop) (void)hipEventRecord(stop, st); }
+};
+// One-shot dispatch-stamped timing for launchers with one or several kernels: the request of ocf_profile_next_launch() is taken
+// once; the FIRST kernel launched through it gets the start event, a kernel launched with last = true the stop event
+// (hipExtLaunchKernelGGL stamps them with the dispatch's own begin / end: what rocprofv3's kernel trace reports).
+struct LaunchProf {
+  hipEvent_t start, stop;
+  LaunchProf() {
+    ProfileSlot& p = profile_slot();
+    start = p.start; stop = p.stop;
+    p.start = nullptr; p.stop = nullptr;
+  }
+  template <typename... KArgs, typename... Args>
+  void launch(bool last, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    hipEvent_t e0 = start, e1 = last ? stop : nullptr;
+    start = nullptr;
+    if (e0 || e1) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kern, grid, block, (unsigned)lds, st, args...);
+  }
 };
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? OCF_OK : OCF_ELAUNCH; }
 

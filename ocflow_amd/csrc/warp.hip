@@ -246,10 +246,11 @@ static int warp_fwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
     const int upp = (C + Unit<T>::U - 1) / Unit<T>::U;
     const long total = npix * upp;
     const dim3 g2(grid_for(total)), b2(256);
+    LaunchProf lp;
     if (vec == 16)
-      hipLaunchKernelGGL((warp_fwd_cl_kernel<T, 16>), g2, b2, 0, st, mk(img), mk(flow), mk(out), B, C, H, W, fs, wg, total, upp);
+      lp.launch(true, warp_fwd_cl_kernel<T, 16>, g2, b2, 0, st, mk(img), mk(flow), mk(out), B, C, H, W, fs, wg, total, upp);
     else
-      hipLaunchKernelGGL((warp_fwd_cl_kernel<T, 8>), g2, b2, 0, st, mk(img), mk(flow), mk(out), B, C, H, W, fs, wg, total, upp);
+      lp.launch(true, warp_fwd_cl_kernel<T, 8>, g2, b2, 0, st, mk(img), mk(flow), mk(out), B, C, H, W, fs, wg, total, upp);
     return launch_status();
   }
   const dim3 grid(grid_for(npix)), block(256);
@@ -276,8 +277,9 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
     while (G < 64 && C % (G * 2) == 0) G *= 2;
     const long total = npix * C;
     const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL((warp_bwd_cl_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg),
-                       mk(gflow), B, C, H, W, fs, wg, total, G);
+    LaunchProf lp;
+    lp.launch(true, warp_bwd_cl_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H,
+              W, fs, wg, total, G);
     return launch_status();
   }
   if (wvec_ok<T>(img) && wvec_ok<T>(gout))

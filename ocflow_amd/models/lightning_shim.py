@@ -1,6 +1,6 @@
 """`pl.LightningModule` when pytorch_lightning is installed, else a minimal stand-in with the hooks the reference's
 modules use (hparams, log, logger, global_step, current_epoch), so the same classes drop into a Lightning Trainer or
-into the plain loop of ocflow_amd.train (this image ships no pytorch_lightning)."""
+into the plain loop of `python -m ocflow_amd.train` (ocflow_amd/train.py; this image ships no pytorch_lightning)."""
 from __future__ import annotations
 
 import torch.nn as nn

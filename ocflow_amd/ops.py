@@ -56,6 +56,19 @@ def set_kernel_timer(timer):
     _KERNEL_TIMER = timer
 
 
+def _launch(name, meta, fn):
+    """run one C-ABI launcher; with a KernelTimer installed its kernels are bracketed by dispatch-stamped HIP events and tagged
+    with their algorithmic bytes (`meta()` is only evaluated then)"""
+    if _KERNEL_TIMER is not None:
+        return _KERNEL_TIMER.launch(name, meta(), fn)
+    return fn()
+
+
+# algorithmic bytes per pixel of the streaming kernels (SURVEY 8d4 / DESIGN.md section 4); es = feature element size
+def _meta(name_shape, nbytes, flops=0):
+    return {"bytes": int(nbytes), "flops": int(flops), "shape": name_shape}
+
+
 def corr_fwd_algorithmic(B, C, H, W, d, elem_size, has_flow, has_occ):
     """Bytes one fused correlation launch must move: read f1 and f2 once (2*C*s), the flow (8 B/px) and
     occlusion (4 B/px) fields when present, write (2d+1)^2 outputs (s each); FLOPs = 2*C per output."""
@@ -126,9 +139,13 @@ def _check4(t, name, C_=None):
 def _warp_fwd_raw(img, flow, flow_scale, align_corners):
     B, C_, H, W = img.shape
     out = _empty_like_layout(img, img.shape)
-    with torch.cuda.device(img.device):
-        _lib.check(_lib.load().ocf_warp_fwd(_t4(img), _t4(flow), _t4(out), B, C_, H, W, float(flow_scale),
-                                            int(bool(align_corners)), _dtype_code(img), _stream(img)), "ocf_warp_fwd")
+
+    def launch():
+        with torch.cuda.device(img.device):
+            _lib.check(_lib.load().ocf_warp_fwd(_t4(img), _t4(flow), _t4(out), B, C_, H, W, float(flow_scale),
+                                                int(bool(align_corners)), _dtype_code(img), _stream(img)), "ocf_warp_fwd")
+
+    _launch("warp_fwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (2 * C_ * img.element_size() + 8)), launch)
     return out
 
 
@@ -149,10 +166,15 @@ def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flo
         return gimg, gflow
     gimg = _zeros_like_layout(img, img.shape, torch.float32) if need_img else None
     gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32) if need_flow else None
-    with torch.cuda.device(img.device):
-        _lib.check(_lib.load().ocf_warp_bwd(_t4(img), _t4(flow), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W,
-                                            float(flow_scale), int(bool(align_corners)), _dtype_code(img), _stream(img)),
-                   "ocf_warp_bwd")
+
+    def launch():
+        with torch.cuda.device(img.device):
+            _lib.check(_lib.load().ocf_warp_bwd(_t4(img), _t4(flow), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W,
+                                                float(flow_scale), int(bool(align_corners)), _dtype_code(img), _stream(img)),
+                       "ocf_warp_bwd")
+
+    # read gout + img (es each), flow 8; write (atomics) fp32 grad_img 4C, grad_flow 8
+    _launch("warp_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (2 * C_ * img.element_size() + 4 * C_ + 16)), launch)
     if gimg is not None and gimg.dtype != img.dtype:
         gimg = gimg.to(img.dtype)
     return gimg, gflow
@@ -220,9 +242,16 @@ class _CorrWarpFn(Function):
             gw = _empty_like_layout(w2, w2.shape) if need_w2 else None
             gocc = torch.empty((B, 1, H, W), device=f1.device, dtype=torch.float32) if (needo and need_w2) else None
             occ32 = _f32(occ)
-            with torch.cuda.device(f1.device):
-                st = _lib.load().ocf_corr_occ_bwd(_t4(f1), _t4(w2), _t4(occ32), _t4(gout), _t4(g1), _t4(gw), _t4(gocc), B, C_, H, W, d,
-                                                  _dtype_code(f1), _stream(f1))
+            es = f1.element_size()
+
+            def launch_occ():
+                with torch.cuda.device(f1.device):
+                    return _lib.load().ocf_corr_occ_bwd(_t4(f1), _t4(w2), _t4(occ32), _t4(gout), _t4(g1), _t4(gw), _t4(gocc), B, C_, H, W,
+                                                        d, _dtype_code(f1), _stream(f1))
+
+            # read grad_out n*es, f1, w2 (C*es each), occ 4; write g1, g2 (C*es each), gocc 4
+            st = _launch("corr_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ * es + (2 * d + 1) ** 2 * es + 8),
+                                                   2 * 2 * C_ * (2 * d + 1) ** 2 * B * H * W), launch_occ)
             if st == _lib.OCF_EUNSUPPORTED:
                 gw = gocc = None  # layout the tiled kernels do not take: compose it from the plain launches below
             else:
@@ -234,9 +263,15 @@ class _CorrWarpFn(Function):
             w2o = w2 * occ.to(w2.dtype) if occ is not None else w2
             gw = _empty_like_layout(w2o, w2o.shape) if need_w2 else None
             if need1 or need_w2:
-                with torch.cuda.device(f1.device):
-                    _lib.check(_lib.load().ocf_corr_bwd(_t4(f1), _t4(w2o), _t4(gout), _t4(g1), _t4(gw), B, C_, H, W, d,
-                                                        _dtype_code(f1), _stream(f1)), "ocf_corr_bwd")
+                es = f1.element_size()
+
+                def launch_plain():
+                    with torch.cuda.device(f1.device):
+                        _lib.check(_lib.load().ocf_corr_bwd(_t4(f1), _t4(w2o), _t4(gout), _t4(g1), _t4(gw), B, C_, H, W, d,
+                                                            _dtype_code(f1), _stream(f1)), "ocf_corr_bwd")
+
+                _launch("corr_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ * es + (2 * d + 1) ** 2 * es),
+                                                  2 * 2 * C_ * (2 * d + 1) ** 2 * B * H * W), launch_plain)
             if need_w2 and occ is not None:
                 if needo:
                     gocc = (gw.float() * w2.float()).sum(dim=1, keepdim=True)
@@ -397,9 +432,14 @@ class _PhotoFn(Function):
     def forward(ctx, img1, img2, flow, occ):
         B, C_, H, W = img1.shape
         sums = torch.empty(2, device=img1.device, dtype=torch.float64)
-        with torch.cuda.device(img1.device):
-            _lib.check(_lib.load().ocf_photo_loss_fwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(sums.data_ptr()),
-                                                      B, C_, H, W, _stream(img1)), "ocf_photo_loss_fwd")
+
+        def launch():
+            with torch.cuda.device(img1.device):
+                _lib.check(_lib.load().ocf_photo_loss_fwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(sums.data_ptr()),
+                                                          B, C_, H, W, _stream(img1)), "ocf_photo_loss_fwd")
+
+        px_bytes = 8 * C_ + (8 if flow is not None else 0) + (4 if occ is not None else 0)  # 36 for RGB + flow + mask
+        _launch("photo_fwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * px_bytes), launch)
         ctx.save_for_backward(img1, img2, flow, occ)
         num, den = sums[0].float(), sums[1].float()
         ctx.mark_non_differentiable(den)
@@ -421,10 +461,14 @@ class _PhotoFn(Function):
         gflow = torch.empty((B, 2, H, W), device=img1.device, dtype=torch.float32) if (flow is not None and nf) else None
         gpred = torch.empty((B, C_, H, W), device=img1.device, dtype=torch.float32) if (flow is None and (n1 or n2)) else None
         if gflow is not None or gpred is not None:
-            with torch.cuda.device(img1.device):
-                _lib.check(_lib.load().ocf_photo_loss_bwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(scale.data_ptr()),
-                                                          _t4(gflow), _t4(gpred), B, C_, H, W, _stream(img1)),
-                           "ocf_photo_loss_bwd")
+            def launch():
+                with torch.cuda.device(img1.device):
+                    _lib.check(_lib.load().ocf_photo_loss_bwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(scale.data_ptr()),
+                                                              _t4(gflow), _t4(gpred), B, C_, H, W, _stream(img1)),
+                               "ocf_photo_loss_bwd")
+
+            px_bytes = 8 * C_ + (16 if flow is not None else 4 * C_) + (4 if occ is not None else 0)  # 44 for RGB + flow + mask
+            _launch("photo_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * px_bytes), launch)
         g1 = -gpred if (gpred is not None and n1) else None
         g2 = gpred if (gpred is not None and n2) else None
         return g1, g2, gflow, None
@@ -516,9 +560,13 @@ class _SmoothFn(Function):
     def forward(ctx, img, flow, alpha):
         B, C_, H, W = img.shape
         sums = torch.empty(4, device=img.device, dtype=torch.float64)
-        with torch.cuda.device(img.device):
-            _lib.check(_lib.load().ocf_smooth_loss_fwd(_t4(img), _t4(flow), C.c_void_p(sums.data_ptr()), B, C_, H, W,
-                                                       float(alpha), _stream(img)), "ocf_smooth_loss_fwd")
+
+        def launch():
+            with torch.cuda.device(img.device):
+                _lib.check(_lib.load().ocf_smooth_loss_fwd(_t4(img), _t4(flow), C.c_void_p(sums.data_ptr()), B, C_, H, W,
+                                                           float(alpha), _stream(img)), "ocf_smooth_loss_fwd")
+
+        _launch("smooth_fwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ + 8)), launch)
         ctx.save_for_backward(img, flow)
         ctx.alpha = float(alpha)
         return sums.float()
@@ -532,9 +580,13 @@ class _SmoothFn(Function):
         B, C_, H, W = img.shape
         coef = gsums.float().contiguous()
         gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32)
-        with torch.cuda.device(img.device):
-            _lib.check(_lib.load().ocf_smooth_loss_bwd(_t4(img), _t4(flow), C.c_void_p(coef.data_ptr()), _t4(gflow), B, C_, H, W,
-                                                       ctx.alpha, _stream(img)), "ocf_smooth_loss_bwd")
+
+        def launch():
+            with torch.cuda.device(img.device):
+                _lib.check(_lib.load().ocf_smooth_loss_bwd(_t4(img), _t4(flow), C.c_void_p(coef.data_ptr()), _t4(gflow), B, C_, H, W,
+                                                           ctx.alpha, _stream(img)), "ocf_smooth_loss_bwd")
+
+        _launch("smooth_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ + 16)), launch)
         return None, gflow, None
 
 
@@ -581,7 +633,8 @@ def _range_map(flow, want_occ):
             _lib.check(L.ocf_range_map_det(_t4(f), C.c_void_p(rng.data_ptr()), occ_p, C.c_void_p(ws.data_ptr()), B, H, W, _stream(f)),
                        "ocf_range_map_det")
         else:
-            _lib.check(_lib.load().ocf_range_map(_t4(f), C.c_void_p(rng.data_ptr()), occ_p, B, H, W, _stream(f)), "ocf_range_map")
+            _launch("range_map", lambda: _meta(f"B{B}x{H}x{W}", B * H * W * 16),
+                    lambda: _lib.check(_lib.load().ocf_range_map(_t4(f), C.c_void_p(rng.data_ptr()), occ_p, B, H, W, _stream(f)), "ocf_range_map"))
     return rng, occ
 
 

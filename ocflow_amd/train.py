@@ -1,0 +1,118 @@
+"""`python -m ocflow_amd.train config.yml` -- the reference's training launcher without Lightning.
+
+Reproduces test_unsupervised.py:35-128 for `network_type: flow` (and test.py:17-84 for the supervised surfaces): seed 42, read
+the YAML into `args`, build `hparams` exactly as the reference does (:44, :52-57), pick the module, fit.  The reference's
+`hparams['using_pretrained_inpainting']` KeyError for `network_type: flow` (:124) is read with `.get(..., False)`.
+`Trainer.fit` is replaced by a plain loop over `TrainStepper` (bf16 autocast, channels_last, optional hipGraph replay, one
+process per GPU under torch.distributed.run); the data module is either the caller's iterable of batches or, with no dataset on
+the box (`root` missing), synthetic Sintel-shaped batches of `image_size` -- the launcher's purpose here is the step loop, the
+checkpoint and the logged scalars, not file I/O (SURVEY 8f-3 lists the real input pipeline as a later row).
+
+    python -m ocflow_amd.train config/unsupervised_config.yml --steps 200 --override network_type=flow model=pwc
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+SUPERVISED = {"flow": "FlowModel", "flowocc": "FlowOccModel"}
+
+
+def load_config(path: str) -> dict:
+    with open(path) as f:
+        return yaml.load(f, Loader=yaml.FullLoader)  # the reference's configs use !!python/tuple (test_unsupervised.py:38)
+
+
+def build_module(args: dict):
+    """(module, hparams) as test_unsupervised.py:44-58 / test.py:36-50 build them"""
+    network_type = args["network_type"]
+    if network_type == "flow" and "photo_weight" in args:  # unsupervised stage (test_unsupervised.py:49-58)
+        from ocflow_amd.models.model import FlowStageModel
+        hparams = dict(network_type=network_type, model=args["model"], epochs=args["epochs"], batch_size=args["batch_size"],
+                       learning_rate=args["learning_rate"], log_every_n_steps=args.get("log_every_n_steps", 20),
+                       img_size=args.get("image_size", None), org=args.get("org", False))
+        assert hparams["model"] in ["simple", "flownets", "flownetc", "pwc", "flownet", "eflownet", "eflownet2"]
+        for k in ("photo_weight", "smooth1_weight", "smooth2_weight", "with_occ", "occ_aware", "displacement"):
+            hparams[k] = args[k]
+        return FlowStageModel(hparams), hparams
+    hparams = dict(args)
+    if network_type == "flow":  # supervised (test.py:38-42)
+        from ocflow_amd.models.flow_model import FlowModel
+        return FlowModel(hparams), hparams
+    if network_type == "flowocc":  # test.py:46-48
+        from ocflow_amd.models.flow_occ_model import FlowOccModel
+        return FlowOccModel(hparams), hparams
+    if network_type == "inpainting" and args.get("model", "simple") == "simple" and "loss_type" not in args:
+        from ocflow_amd.models.inpainting_model import InpaintingModel
+        return InpaintingModel(hparams), hparams
+    raise NotImplementedError(f"network_type '{network_type}' is outside the hot path of the MI355X build (SURVEY.md sections 2.1, 8f-4)")
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(prog="python -m ocflow_amd.train")
+    p.add_argument("config")
+    p.add_argument("--steps", type=int, default=None, help="stop after this many steps (default: epochs x steps_per_epoch)")
+    p.add_argument("--steps-per-epoch", type=int, default=100)
+    p.add_argument("--override", nargs="*", default=[], help="key=value pairs applied to the YAML (values parsed as YAML)")
+    p.add_argument("--graph", type=int, default=1, help="replay the step as a hipGraph (fixed-shape batches)")
+    p.add_argument("--fp32", action="store_true")
+    p.add_argument("--out", default=None, help="directory for the final state_dict + metrics.json")
+    a = p.parse_args(argv)
+
+    from ocflow_amd.runtime import TrainStepper, init_distributed, shutdown_distributed, synthetic_batch, use_repo_miopen_db
+    use_repo_miopen_db()
+    torch.manual_seed(42)  # pl.seed_everything(42), test_unsupervised.py:35
+    args = load_config(a.config)
+    for kv in a.override:
+        k, v = kv.split("=", 1)
+        args[k] = yaml.safe_load(v)
+    using_pretrained_inpainting = args.get("using_pretrained_inpainting", False) if args["network_type"] == "twostage" else False  # F7
+    assert not using_pretrained_inpainting
+    module, hparams = build_module(args)
+    env = init_distributed()
+    if env.device.type != "cuda":
+        raise SystemExit("ocflow_amd.train needs an MI355X: the hot path has no CPU fallback")
+    amp = None if a.fp32 else torch.bfloat16
+    stepper = TrainStepper(module, env, amp_dtype=amp, channels_last=True, fused_optimizer=True,
+                           dp_mode="flat" if (a.graph and env.world_size > 1) else "ddp", master_weights=amp is not None)
+    B = int(args["batch_size"])
+    per_rank = max(1, B // env.world_size)
+    size = args.get("image_size") or (436, 1024)
+    if args.get("root") and os.path.isdir(str(args["root"])):
+        raise NotImplementedError("dataset readers are not part of this build (SURVEY 8f-3); run without `root` for synthetic batches")
+    total = a.steps if a.steps is not None else int(args.get("epochs", 1)) * a.steps_per_epoch
+    batch = stepper.prepare(synthetic_batch(per_rank, int(size[0]), int(size[1]), env.device, seed=42, index_offset=env.rank * per_rank))
+    loss = stepper.step(batch, 0)
+    if a.graph:
+        stepper.enable_graph(batch)
+        batch = stepper._static_batch
+    log_every = int(hparams.get("log_every_n_steps", 20))
+    t0, history = time.perf_counter(), []
+    for i in range(1, total):
+        loss = stepper.step(batch, i)
+        if i % log_every == 0 or i == total - 1:
+            lv = float(loss)
+            history.append({"step": i, "train_loss": lv})
+            if env.is_main:
+                dt = time.perf_counter() - t0
+                print(f"step {i}: train_loss {lv:.5f}  ({per_rank * env.world_size * i / dt:.1f} pairs/s)", flush=True)
+            if lv != lv:
+                raise SystemExit(f"non-finite loss at step {i}")
+    torch.cuda.synchronize()
+    if a.out and env.is_main:
+        os.makedirs(a.out, exist_ok=True)
+        torch.save(stepper.module_state_dict(), os.path.join(a.out, "state_dict.pt"))  # same keys as the reference's save_state_dict
+        with open(os.path.join(a.out, "metrics.json"), "w") as f:
+            json.dump({"hparams": {k: (list(v) if isinstance(v, tuple) else v) for k, v in hparams.items()}, "history": history}, f)
+    shutdown_distributed()
+    return history
+
+
+if __name__ == "__main__":
+    main()

@@ -357,7 +357,98 @@ def gold_psnr():
     save("psnr", a=a, b=b, psnr=np.asarray(vals, dtype=np.float64))
 
 
+# ------------------------------------------- 11. whole networks at the benchmark's resolution (BASELINE configs[1])
+def _sub(t, k=4):
+    """every k-th pixel in y and x: the fixture keeps 1/16 of a full-resolution map (the input is regenerated by the test from
+    golden_util.smooth_field, the weights from rngfree_fill, so nothing else has to be stored)"""
+    return t[..., ::k, ::k].contiguous()
+
+
+def gold_fullsize():
+    arrs = {}
+    # FlowOccModel('flowoccnet') at the native Sintel size 1 x 6 x 436 x 1024 (FPN nets run there, SURVEY F5), eval mode
+    x = torch.from_numpy(smooth_field((1, 6, 436, 1024), seed=71, amp=1.0)).float().clamp(-1, 1)
+    m = FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"})
+    rngfree_fill(m)
+    m.eval()
+    with torch.no_grad():
+        fl, oc = m(x)
+    arrs.update(flowoccnet_436x1024_flow_sub4=_sub(fl), flowoccnet_436x1024_occ_sub4=_sub(oc),
+                flowoccnet_436x1024_flow_absmean=fl.abs().mean(), flowoccnet_436x1024_occ_mean=oc.mean())
+    # FlowNetCV ('pwc') at 1 x 6 x 448 x 1024 (sides divisible by 64, SURVEY F5), train mode like the Cfg1 fixture
+    x2 = torch.from_numpy(smooth_field((1, 6, 448, 1024), seed=72, amp=1.0)).float().clamp(-1, 1)
+    m = FlowModel({"learning_rate": 1e-3, "model": "pwc", "displacement": 4})
+    rngfree_fill(m)
+    with torch.no_grad():
+        full, quarter = m.flow_pred(x2)
+    arrs.update(flownetcv_448x1024_full_sub4=_sub(full), flownetcv_448x1024_quarter=quarter, flownetcv_448x1024_full_absmean=full.abs().mean())
+    save("fullsize", **arrs)
+
+
+# ------------------------------------------- 12. inpainting head (BASELINE configs[3]: KITTI-sized pairs, occlusion mask)
+def gold_inpainting():
+    from models.inpainting_model import InpaintingModel
+    from models.networks.image_inpainting_net import InpaintingNet
+    arrs = {}
+    manifest = None
+
+    def chain(net, imgs, flow, occ):
+        """models/inpainting_model.py:62-73 with the ONE fix the reference needs to run at all: `forward` must hand the
+        mask to InpaintingNet -- `self.model(img_occluded, occ)` instead of `self.model(img_occluded)`.  Everything else is the
+        reference's own code: its warp method, its network class, its loss expression."""
+        img1, img2 = imgs[:, 0:3], imgs[:, 3:6]
+        img_warped = InpaintingModel.warp(None, img2, flow)
+        img_occluded = img_warped * (1 - occ)
+        img_completed = net(img_occluded, occ)
+        loss = (torch.abs(img_completed - img1) * occ).sum() / (3 * occ.sum() + 1e-16)
+        return img_warped, img_completed, loss
+
+    # (a) small: everything stored, gradients of the network parameters and of the flow-free inputs
+    net = InpaintingNet()
+    rngfree_fill(net)
+    net.train()
+    imgs = torch.from_numpy(smooth_field((2, 6, 64, 96), seed=81, amp=1.0)).float().clamp(-1, 1)
+    flow = torch.randn((2, 2, 64, 96), generator=g(82)) * 2.0
+    occ = (torch.rand((2, 1, 64, 96), generator=g(83)) < 0.3).float()
+    warped, completed, loss = chain(net, imgs, flow, occ)
+    loss.backward()
+    arrs.update(s_imgs=imgs, s_flow=flow, s_occ=occ, s_warped=warped, s_completed=completed, s_loss=loss,
+                s_grad_down1_conv1=net.down1.conv1.weight.grad, s_grad_up6_conv3=net.up6.conv3.weight.grad)
+    manifest = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    # (b) KITTI render size 4 x 320 x 1216 (375 x 1242 through the reference's crop rule, datasets.py:146-150), eval mode
+    net = InpaintingNet()
+    rngfree_fill(net)
+    net.eval()
+    imgs = torch.from_numpy(smooth_field((4, 6, 320, 1216), seed=84, amp=1.0)).float().clamp(-1, 1)
+    flow = torch.from_numpy(smooth_field((4, 2, 320, 1216), seed=85, amp=6.0)).float()
+    occ = (torch.from_numpy(smooth_field((4, 1, 320, 1216), seed=86, amp=1.0)) > 0.35).float()
+    with torch.no_grad():
+        warped, completed, loss = chain(net, imgs, flow, occ)
+    arrs.update(k_loss=loss, k_completed_sub8=_sub(completed, 8), k_warped_sub8=_sub(warped, 8), k_occ_fraction=occ.mean())
+    # (c) op level at the raw KITTI size 375 x 1242 (no network: warp -> mask -> masked L1 against a given prediction)
+    img2 = torch.from_numpy(smooth_field((4, 3, 375, 1242), seed=87, amp=1.0)).float().clamp(-1, 1)
+    img1 = torch.from_numpy(smooth_field((4, 3, 375, 1242), seed=88, amp=1.0)).float().clamp(-1, 1)
+    flow = torch.from_numpy(smooth_field((4, 2, 375, 1242), seed=89, amp=8.0)).float()
+    occ = (torch.from_numpy(smooth_field((4, 1, 375, 1242), seed=90, amp=1.0)) > 0.3).float()
+    pred = InpaintingModel.warp(None, img2, flow) * (1 - occ)
+    pred.requires_grad_()
+    loss = (torch.abs(pred - img1) * occ).sum() / (3 * occ.sum() + 1e-16)
+    loss2 = (torch.abs(pred * 0.5 - img1) * occ).sum() / (3 * occ.sum() + 1e-16)
+    (gp,) = torch.autograd.grad(loss2, pred)
+    arrs.update(o_masked_sub8=_sub(pred.detach(), 8), o_loss=loss, o_loss_half=loss2, o_grad_half_sub8=_sub(gp, 8))
+    save("inpainting", **arrs)
+    import json
+    with open(os.path.join(HERE, "state_dict_manifest_inpainting.json"), "w") as f:
+        json.dump({"inpaintingnet": manifest}, f)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        gold_fullsize()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "inpainting":
+        gold_inpainting()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "psnr":
         gold_psnr()
         sys.exit(0)
@@ -376,3 +467,5 @@ if __name__ == "__main__":
     gold_ssim()
     gold_psnr()
     gold_nets()
+    gold_fullsize()
+    gold_inpainting()

@@ -1,0 +1,132 @@
+"""GPU tests of the BASELINE configs at their OWN sizes ("configs not exercised"):
+  configs[1]  FlowOccModel('flowoccnet') 1 x 6 x 436 x 1024 and FlowNetCV 1 x 6 x 448 x 1024, fp32, against goldens produced by the
+              reference at those sizes (tests/golden/fullsize.npz: every 4th pixel of the outputs; inputs from smooth_field, weights
+              from rngfree_fill) -- north_star bar: flow EPE and occlusion L1 < 1e-4;
+  configs[2]  FlowStageModel('pwc', occ_aware) training steps at 8 x 384 x 512 (bf16, channels_last): finite decreasing loss, range-map
+              mass conservation on the model's own backward flow;
+  configs[3]  the inpainting head at the KITTI render size 4 x 320 x 1216 and the op chain at 375 x 1242 against the reference."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import rngfree_fill, smooth_field
+from oracle import ocflow_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+@pytest.fixture(autouse=True)
+def _no_tf32():
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+
+
+def epe(a, b):
+    return float(torch.sqrt(((a.float().cpu() - T(b)) ** 2).sum(1)).mean())
+
+
+def test_config1_flowoccnet_at_436x1024(golden):
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    g = golden("fullsize")
+    x = T(smooth_field((1, 6, 436, 1024), seed=71, amp=1.0)).float().clamp(-1, 1).to(DEV)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"})).to(DEV).eval().to(memory_format=fmt)
+        with torch.no_grad():
+            fl, oc = m(x.contiguous(memory_format=fmt))
+        assert fl.shape == (1, 2, 436, 1024) and oc.shape == (1, 1, 436, 1024)
+        assert epe(fl[..., ::4, ::4], g["flowoccnet_436x1024_flow_sub4"]) < 1e-4
+        assert float((oc[..., ::4, ::4].cpu() - T(g["flowoccnet_436x1024_occ_sub4"])).abs().mean()) < 1e-4
+        assert abs(float(fl.abs().mean()) - float(g["flowoccnet_436x1024_flow_absmean"])) < 1e-4
+        assert abs(float(oc.mean()) - float(g["flowoccnet_436x1024_occ_mean"])) < 1e-4
+
+
+def test_config1_flownetcv_at_448x1024(golden):
+    from ocflow_amd.models.flow_model import FlowModel
+    g = golden("fullsize")
+    x = T(smooth_field((1, 6, 448, 1024), seed=72, amp=1.0)).float().clamp(-1, 1).to(DEV)
+    m = rngfree_fill(FlowModel({"learning_rate": 1e-3, "model": "pwc", "displacement": 4})).to(DEV)
+    with torch.no_grad():
+        full, quarter = m.flow_pred(x)
+    assert epe(full[..., ::4, ::4], g["flownetcv_448x1024_full_sub4"]) < 1e-4
+    np.testing.assert_allclose(quarter.cpu().numpy(), g["flownetcv_448x1024_quarter"], rtol=1e-4, atol=1e-4)
+
+
+def test_config2_pwc_unsupervised_steps_at_8x384x512():
+    """BASELINE configs[2]: unsupervised_config.yml weights with network_type 'flow', model 'pwc', batch 8 at 384 x 512"""
+    from ocflow_amd import ops
+    from ocflow_amd.models.model import FlowStageModel
+    from ocflow_amd.runtime import DistEnv, TrainStepper, synthetic_batch
+    torch.manual_seed(3)
+    hp = dict(learning_rate=1e-4, model="pwc", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0, with_occ=False,
+              occ_aware=True)
+    env = DistEnv(device=torch.device(DEV))
+    st = TrainStepper(FlowStageModel(hp), env, amp_dtype=torch.bfloat16, channels_last=True, fused_optimizer=True)
+    batch = st.prepare(synthetic_batch(8, 384, 512, DEV, seed=5))
+    losses = [float(st.step(batch, i)) for i in range(12)]
+    assert all(np.isfinite(losses)), losses
+    assert min(losses[6:]) < losses[0], losses  # the photometric + smoothness objective goes down on a fixed batch
+    gmax = max(float(p.grad.abs().max()) for p in st.raw.parameters() if p.grad is not None)
+    assert np.isfinite(gmax) and gmax < 1e4
+    # range-map mass of the model's own backward flow: sum(range) == number of in-bounds bilinear weight (oracle), occ in [0, 1]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        back = st.raw(torch.cat((batch[0][:, 3:6], batch[0][:, 0:3]), 1))[0].float()
+    rm = ops.compute_range_map(back)
+    ref = O.compute_range_map(back.cpu())
+    assert abs(float(rm.double().sum()) - float(ref.double().sum())) <= 1e-5 * float(ref.double().sum())
+    occ = ops.occlusion_from_flow(back)
+    assert float(occ.min()) >= 0.0 and float(occ.max()) <= 1.0
+
+
+def test_config3_inpainting_head_at_kitti_size(golden):
+    """4 x 320 x 1216 (375 x 1242 through the reference's crop rule): warp -> mask -> InpaintingNet -> masked L1, eval mode, fp32"""
+    from ocflow_amd.data.flow_io import render_size
+    from ocflow_amd.models.inpainting_model import InpaintingModel
+    g = golden("inpainting")
+    assert render_size(375, 1242) == (320, 1216)
+    imgs = T(smooth_field((4, 6, 320, 1216), seed=84, amp=1.0)).float().clamp(-1, 1).to(DEV)
+    flow = T(smooth_field((4, 2, 320, 1216), seed=85, amp=6.0)).float().to(DEV)
+    occ = (T(smooth_field((4, 1, 320, 1216), seed=86, amp=1.0)) > 0.35).float().to(DEV)
+    m = InpaintingModel({"learning_rate": 1e-4}).to(DEV)
+    rngfree_fill(m.model)
+    m.eval()
+    with torch.no_grad():
+        warped = m.warp(imgs[:, 3:6], flow)
+        completed = m(warped * (1 - occ), occ)
+        loss = m.general_step((imgs, flow, occ), 0, "val")
+    # (at W = 1216 an fp32 sample coordinate resolves ~1e-4 px: the reference's normalised grid and the kernel's closed form differ there)
+    np.testing.assert_allclose(warped[..., ::8, ::8].cpu().numpy(), g["k_warped_sub8"], rtol=1e-4, atol=1e-4)
+    assert float((completed[..., ::8, ::8].cpu() - T(g["k_completed_sub8"])).abs().mean()) < 1e-4
+    assert abs(float(loss) - float(g["k_loss"])) < 1e-4 * max(1.0, abs(float(g["k_loss"])))
+    # one bf16 training step of the head runs and produces finite gradients
+    m.train()
+    opt = m.configure_optimizers()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        l2 = m.training_step((imgs, flow, occ), 0)
+    l2.backward()
+    opt.step()
+    assert torch.isfinite(l2) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_config3_op_chain_at_375x1242(golden):
+    """op level at the raw KITTI size: AC-False warp of img2, (1 - occ) mask, masked L1 and its gradient vs the reference"""
+    from ocflow_amd import ops
+    g = golden("inpainting")
+    img2 = T(smooth_field((4, 3, 375, 1242), seed=87, amp=1.0)).float().clamp(-1, 1).to(DEV)
+    img1 = T(smooth_field((4, 3, 375, 1242), seed=88, amp=1.0)).float().clamp(-1, 1).to(DEV)
+    flow = T(smooth_field((4, 2, 375, 1242), seed=89, amp=8.0)).float().to(DEV)
+    occ = (T(smooth_field((4, 1, 375, 1242), seed=90, amp=1.0)) > 0.3).float().to(DEV)
+    pred = (ops.warp(img2, flow, align_corners=False) * (1 - occ)).requires_grad_()
+    np.testing.assert_allclose(pred.detach()[..., ::8, ::8].cpu().numpy(), g["o_masked_sub8"], rtol=1e-4, atol=1e-4)
+    assert abs(float(ops.masked_l1(pred, img1, occ)) - float(g["o_loss"])) < 2e-5 * abs(float(g["o_loss"]))
+    loss_half = ops.masked_l1(pred * 0.5, img1, occ)
+    assert abs(float(loss_half) - float(g["o_loss_half"])) < 2e-5 * abs(float(g["o_loss_half"]))
+    (gp,) = torch.autograd.grad(loss_half, pred)
+    np.testing.assert_allclose(gp[..., ::8, ::8].cpu().numpy(), g["o_grad_half_sub8"], rtol=1e-5, atol=1e-10)
+    # strided views (the [B,6,H,W] batch) and a channels_last prediction go through the stride ABI unchanged
+    both = torch.cat((img1, img2), 1)
+    assert abs(float(ops.masked_l1(pred.detach().contiguous(memory_format=torch.channels_last), both[:, 0:3], occ)) - float(g["o_loss"])) < 2e-5
+    with pytest.raises(RuntimeError, match="no CPU fallback|HIP"):
+        ops.masked_l1(pred.detach().cpu(), img1.cpu(), occ.cpu())

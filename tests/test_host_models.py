@@ -146,3 +146,50 @@ def test_unsupervised_stage_step(cpu_ops, golden, occ_aware, tag):
     loss.backward()
     close(m.flow_pred.predict_flow2.weight.grad[:, :16], g[f"stage_{tag}_grad_predict_flow2"], 5e-5)
     close(m.flow_pred.conv1a[0].weight.grad, g[f"stage_{tag}_grad_conv1a"], 5e-4)
+
+
+def test_inpainting_head_cpu(cpu_ops, golden):
+    """InpaintingNet / InpaintingModel mirror: state_dict keys + shapes + order of the reference's network, and the whole
+    configs[3] chain (AC-False warp -> mask -> InpaintingNet -> masked L1) against the reference's golden at 2 x 64 x 96,
+    including two weight gradients"""
+    from ocflow_amd.models.inpainting_model import InpaintingModel
+    from ocflow_amd.models.networks.image_inpainting_net import InpaintingNet
+    g = golden("inpainting")
+    with open(os.path.join(GOLDEN, "state_dict_manifest_inpainting.json")) as f:
+        want = [(k, tuple(s)) for k, s in json.load(f)["inpaintingnet"]]
+    net = InpaintingNet()
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == want
+    m = InpaintingModel({"learning_rate": 1e-4})
+    rngfree_fill(m.model)
+    m.train()
+    batch = (T(g["s_imgs"]), T(g["s_flow"]), T(g["s_occ"]))
+    close(m.warp(batch[0][:, 3:6], batch[1]), g["s_warped"], 1e-5)
+    loss = m.training_step(batch, 0)
+    close(loss, g["s_loss"], 1e-5)
+    loss.backward()
+    close(m.model.down1.conv1.weight.grad, g["s_grad_down1_conv1"], 2e-5)
+    close(m.model.up6.conv3.weight.grad, g["s_grad_up6_conv3"], 2e-5)
+    with torch.no_grad():
+        m2 = InpaintingModel({"learning_rate": 1e-4})
+        rngfree_fill(m2.model)
+        m2.train()
+        img_occluded = m2.warp(batch[0][:, 3:6], batch[1]) * (1 - batch[2])
+        close(m2(img_occluded, batch[2]), g["s_completed"], 2e-5)
+    assert isinstance(m.configure_optimizers(), torch.optim.Adam)
+
+
+def test_launcher_builds_the_reference_hparams(tmp_path):
+    """`python -m ocflow_amd.train`: YAML -> hparams -> module as test_unsupervised.py:35-58 (network_type 'flow'), the shipped config,
+    the !!python/tuple image_size, and the out-of-scope stages"""
+    from ocflow_amd import train
+    from ocflow_amd.models.model import FlowStageModel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = train.load_config(os.path.join(root, "config", "unsupervised_flow.yml"))
+    assert args["image_size"] == (384, 512) and args["network_type"] == "flow"
+    m, hp = train.build_module(args)
+    assert isinstance(m, FlowStageModel) and m.model == "pwc" and m.occ_aware and m.photo_weight == 4.0 and m.smooth2_weight == 0.0
+    assert hp["batch_size"] == 8 and hp["img_size"] == (384, 512) and "using_pretrained_inpainting" not in hp
+    with pytest.raises(NotImplementedError):
+        train.build_module({**args, "network_type": "twostage"})
+    sup, _ = train.build_module({"network_type": "flowocc", "model": "flowoccnet", "learning_rate": 1e-3})
+    assert type(sup).__name__ == "FlowOccModel"
