@@ -192,6 +192,16 @@ int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int H, int W, 
 int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W, int window_size,
                  void* stream);
 
+/* SSIM as a differentiable photometric term: gradient of  sum_b coef[b] * sums[b]  w.r.t. img1 (the first argument;
+ * by the symmetry of the formula the gradient w.r.t. img2 is the same call with the images swapped).  Two launches: the forward pass
+ * again, storing the derivatives of the quotient w.r.t. the three windowed moments that involve img1 in `workspace`
+ * (ocf_ssim_bwd_workspace_bytes), then the transposed separable Gaussian filter of those planes combined with the images.
+ * coef: device fp32 [B]; gimg1: fp32 [B,C,H,W], any strides, written.
+ * replaces: autograd of _ssim  inpainting_metrics/ssim/ssim.py:17-37 (5 conv backward passes + the elementwise chain) */
+int ocf_ssim_bwd_workspace_bytes(int B, int C, int H, int W, int window_size, int64_t* bytes);
+int ocf_ssim_bwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const float* coef, const ocf_tensor4* gimg1, void* workspace, int B,
+                 int C, int H, int W, int window_size, void* stream);
+
 /* ---- PSNR metric (sibling of SSIM in the reference's inpainting_metrics) ------------------------------------------------------
  * sums[b] = sum over (C,H,W) of (img1 - img2)^2 of sample b (fp64, zeroed by the launcher); img1 / img2 fp32, any strides.
  * replaces: psnr()  inpainting_metrics/psnr/psnr.py:4-11  (numpy mean((a-b)^2) per image after a device-to-host copy,

@@ -55,6 +55,8 @@ SIGNATURES = {
     "ocf_range_map": [_T4P, _vp, _vp, _i, _i, _i, _vp],
     "ocf_moments": [_T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_ssim_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
+    "ocf_ssim_bwd_workspace_bytes": [_i, _i, _i, _i, _i, C.POINTER(C.c_int64)],
+    "ocf_ssim_bwd": [_T4P, _T4P, _vp, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_sqdiff": [_T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
     "ocf_bias_act_fwd": [_T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],

@@ -408,8 +408,11 @@ struct SsimWin { float w[16]; };
 // filtered horizontally into LDS and vertically into registers: 2*ws taps per output instead of ws^2 (ws = 11: 22 vs 121,
 // 877 -> ~150 us at 8 x 3 x 436 x 1024), then the SSIM quotient; block reduce -> one fp64 atomic per block and sample.
 constexpr int STW = 32, STH = 8, SMAXW = 16, SPH = STH + SMAXW - 1, SPW = STW + SMAXW - 1;
+// dmaps != nullptr (backward pass 1): besides the sums, store at every output pixel the partial derivatives of the SSIM quotient
+// w.r.t. the three windowed moments that depend on the FIRST image, times coef[sample]:
+//   D0 = dS/d mu1,  D1 = dS/d E[a^2],  D2 = dS/d E[ab]      (planes [3][B][C][Ho][Wo] fp32)
 __global__ __launch_bounds__(LB) void ssim_fwd_kernel(T4 a, T4 b, double* sums, int C, int H, int W, int Ho, int Wo, int ws, int pad,
-                                                      SsimWin win, int tiles_x, int ntiles) {
+                                                      SsimWin win, int tiles_x, int ntiles, float* dmaps, const float* coef) {
   __shared__ float sa[SPH][SPW + 1], sb[SPH][SPW + 1];
   __shared__ float hm[5][SPH][STW];
   const int bi = blockIdx.z, c = blockIdx.y;
@@ -460,10 +463,71 @@ __global__ __launch_bounds__(LB) void ssim_fwd_kernel(T4 a, T4 b, double* sums, 
       }
       const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
       const float v11 = s11 - m1 * m1, v22 = s22 - m2 * m2, v12 = s12 - m1 * m2;
-      acc[0] += (double)(((2.f * m1 * m2 + c1) * (2.f * v12 + c2)) / ((m1 * m1 + m2 * m2 + c1) * (v11 + v22 + c2)));
+      const float A1 = 2.f * m1 * m2 + c1, A2 = 2.f * v12 + c2, B1 = m1 * m1 + m2 * m2 + c1, B2 = v11 + v22 + c2;
+      const float S = (A1 * A2) / (B1 * B2);
+      acc[0] += (double)S;
+      if (dmaps) {
+        const float k = coef[bi], inv = 1.f / (B1 * B2);
+        const long plane = (long)Ho * Wo, o = ((long)bi * C + c) * plane + (long)yo * Wo + xo, stride = (long)gridDim.z * C * plane;
+        dmaps[o] = k * (2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S / B1 + 2.f * m1 * S / B2);
+        dmaps[o + stride] = -k * S / B2;
+        dmaps[o + 2 * stride] = k * 2.f * A1 * inv;
+      }
     }
   }
   block_reduce_atomic<1>(acc, sums + bi);
+}
+
+// backward pass 2: grad_a[p] = (G^T * D0)(p) + 2 a(p) (G^T * D1)(p) + b(p) (G^T * D2)(p), G^T = the transposed (correlation) form of
+// the zero-padded Gaussian filter; separable through LDS like the forward.  One workgroup = a 32 x 8 tile of INPUT pixels.
+__global__ __launch_bounds__(LB) void ssim_bwd_kernel(T4 a, T4 b, const float* dmaps, T4 ga, int B, int C, int H, int W, int Ho, int Wo, int ws,
+                                                      int pad, SsimWin win, int tiles_x) {
+  __shared__ float sd[3][SPH][SPW + 1];
+  __shared__ float hm[3][SPH][STW];
+  const int bi = blockIdx.z, c = blockIdx.y;
+  const int ty0 = (blockIdx.x / tiles_x) * STH, tx0 = (blockIdx.x % tiles_x) * STW;
+  const int ph = STH + ws - 1, pw = STW + ws - 1;
+  const long plane = (long)Ho * Wo, stride = (long)B * C * plane;
+  const float* dp = dmaps + ((long)bi * C + c) * plane;
+  const int uy0 = ty0 + pad - (ws - 1), ux0 = tx0 + pad - (ws - 1);  // first output row / column that reaches this tile
+  for (int e = threadIdx.x; e < ph * pw; e += LB) {
+    const int r = e / pw, x = e - r * pw;
+    const int uy = uy0 + r, ux = ux0 + x;
+    const bool ok = uy >= 0 && uy < Ho && ux >= 0 && ux < Wo;
+    const long o = (long)(uy < 0 ? 0 : (uy >= Ho ? Ho - 1 : uy)) * Wo + (ux < 0 ? 0 : (ux >= Wo ? Wo - 1 : ux));
+    const float d0 = dp[o], d1 = dp[o + stride], d2 = dp[o + 2 * stride];
+    sd[0][r][x] = ok ? d0 : 0.f;
+    sd[1][r][x] = ok ? d1 : 0.f;
+    sd[2][r][x] = ok ? d2 : 0.f;
+  }
+  __syncthreads();
+  // out(p) = sum_t w[t] D(p + pad - t): in patch coordinates x + (ws-1) - t, i.e. tap i = ws-1-t at offset i with weight w[ws-1-i]
+  for (int e = threadIdx.x; e < ph * STW; e += LB) {
+    const int r = e / STW, x = e - r * STW;
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+    for (int i = 0; i < ws; i++) {
+      const float w = win.w[ws - 1 - i];
+      h0 = __builtin_fmaf(w, sd[0][r][x + i], h0);
+      h1 = __builtin_fmaf(w, sd[1][r][x + i], h1);
+      h2 = __builtin_fmaf(w, sd[2][r][x + i], h2);
+    }
+    hm[0][r][x] = h0; hm[1][r][x] = h1; hm[2][r][x] = h2;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (STW - 1), ly = threadIdx.x >> 5;
+  const int y = ty0 + ly, x = tx0 + lx;
+  if (y < H && x < W) {
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int i = 0; i < ws; i++) {
+      const float w = win.w[ws - 1 - i];
+      g0 = __builtin_fmaf(w, hm[0][ly + i][lx], g0);
+      g1 = __builtin_fmaf(w, hm[1][ly + i][lx], g1);
+      g2 = __builtin_fmaf(w, hm[2][ly + i][lx], g2);
+    }
+    const float va = ((const float*)a.p)[(long)bi * a.sb + (long)c * a.sc + (long)y * a.sh + (long)x * a.sw];
+    const float vb = ((const float*)b.p)[(long)bi * b.sb + (long)c * b.sc + (long)y * b.sh + (long)x * b.sw];
+    ((float*)ga.p)[(long)bi * ga.sb + (long)c * ga.sc + (long)y * ga.sh + (long)x * ga.sw] = g0 + 2.f * va * g1 + vb * g2;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ PSNR
@@ -611,8 +675,30 @@ extern "C" int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, 
   return launch_status();
 }
 
+static int ssim_launch(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W, int window_size,
+                       void* stream, float* dmaps, const float* coef, const ocf_tensor4* ga);
+
 extern "C" int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W,
                             int window_size, void* stream) {
+  return ssim_launch(img1, img2, sums, B, C, H, W, window_size, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int ocf_ssim_bwd_workspace_bytes(int B, int C, int H, int W, int window_size, int64_t* bytes) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || window_size < 1 || !bytes) return OCF_EINVAL;
+  const int pad = window_size / 2;
+  *bytes = 3LL * B * C * (int64_t)(H + 2 * pad - window_size + 1) * (W + 2 * pad - window_size + 1) * 4 + (int64_t)B * 8;
+  return OCF_OK;
+}
+
+extern "C" int ocf_ssim_bwd(const ocf_tensor4* img1, const ocf_tensor4* img2, const float* coef, const ocf_tensor4* gimg1, void* workspace,
+                            int B, int C, int H, int W, int window_size, void* stream) {
+  if (!coef || !gimg1 || !gimg1->data || !workspace) return OCF_EINVAL;
+  // workspace = [B doubles of scratch sums][3 derivative planes]
+  return ssim_launch(img1, img2, (double*)workspace, B, C, H, W, window_size, stream, (float*)((double*)workspace + B), coef, gimg1);
+}
+
+static int ssim_launch(const ocf_tensor4* img1, const ocf_tensor4* img2, double* sums, int B, int C, int H, int W, int window_size,
+                       void* stream, float* dmaps, const float* coef, const ocf_tensor4* ga) {
   ocf::clear_stale_error();
   if (!img1 || !img2 || !sums || !img1->data || !img2->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || window_size < 1) return OCF_EINVAL;
@@ -630,8 +716,14 @@ extern "C" int ocf_ssim_fwd(const ocf_tensor4* img1, const ocf_tensor4* img2, do
   int gx = (4096 + B * C - 1) / (B * C);  // ~4096 workgroups in total, each walking ntiles / gx tiles
   if (gx > ntiles) gx = ntiles;
   if (gx < 1) gx = 1;
-  LaunchProf().launch(true, ssim_fwd_kernel, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(LB), 0, st, mk(img1), mk(img2), sums, C, H, W, Ho, Wo,
-                     window_size, pad, win, tiles_x, ntiles);
+  LaunchProf lp;
+  lp.launch(!ga, ssim_fwd_kernel, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(LB), 0, st, mk(img1), mk(img2), sums, C, H, W, Ho, Wo,
+            window_size, pad, win, tiles_x, ntiles, dmaps, coef);
+  if (ga) {
+    const int btx = (W + STW - 1) / STW, bty = (H + STH - 1) / STH;
+    lp.launch(true, ssim_bwd_kernel, dim3((unsigned)(btx * bty), (unsigned)C, (unsigned)B), dim3(LB), 0, st, mk(img1), mk(img2), (const float*)dmaps,
+              mk(ga), B, C, H, W, Ho, Wo, window_size, pad, win, btx);
+  }
   return launch_status();
 }
 

@@ -40,6 +40,14 @@ class FlowStageModel(HotPathHelpers, LightningModule):
         self.log_every_n_steps = hparams.get("log_every_n_steps", 20)
         self.occ_aware = hparams.get("occ_aware", False)
         self.displacement = hparams.get("displacement", 4)
+        # photometric term: 'charbonnier' = the reference's robust-L1 (models/model.py:27-46, the default and the only mode the
+        # reference trains with); 'ssim' = 1 - SSIM(warp(img2, flow), img1) with the reference's own SSIM definition
+        # (inpainting_metrics/ssim/ssim.py:17-37, Gaussian window `ssim_window`), the SURVEY 8f-2 option.  SSIM has no per-pixel
+        # mask: the occlusion mask is ignored in that mode.
+        self.photo_mode = hparams.get("photo_mode", "charbonnier")
+        if self.photo_mode not in ("charbonnier", "ssim"):
+            raise ValueError(f"Unsupported photo_mode: {self.photo_mode}")
+        self.ssim_window = hparams.get("ssim_window", 11)
         self.model = hparams.get("model", "simple")
         self.flow_pred = build_flow_network(self.model, self.displacement)
 
@@ -68,7 +76,10 @@ class FlowStageModel(HotPathHelpers, LightningModule):
     def _losses(self, imgs, flow_gt, occ_mask, pred=None):
         img1, img2 = imgs[:, 0:3], imgs[:, 3:6]
         flow_pred, flow_s, img_s = pred if pred is not None else self._predict(imgs)
-        photo = ops.warp_photometric_error(img1, img2, flow_pred, occ_mask)
+        if self.photo_mode == "ssim":
+            photo = 1.0 - ops.ssim(ops.warp(img2.float(), flow_pred.float(), align_corners=True), img1, self.ssim_window)
+        else:
+            photo = ops.warp_photometric_error(img1, img2, flow_pred, occ_mask)
         smooth1, smooth2 = ops.smoothness_losses(img_s, flow_s)
         flow_error = F.mse_loss(flow_pred.float(), flow_gt)
         return flow_pred, photo, smooth1, smooth2, flow_error

@@ -650,10 +650,46 @@ def occlusion_from_flow(flow):
 
 
 # -------------------------------------------------------------------------------------------------- SSIM
+class _SsimFn(Function):
+    """per-sample sums of the SSIM map; differentiable w.r.t. BOTH images (the gradient w.r.t. the second is the same kernel pair with
+    the images swapped: the formula is symmetric)"""
+
+    @staticmethod
+    def forward(ctx, a, b, ws):
+        B, C_, H, W = a.shape
+        sums = torch.empty(B, device=a.device, dtype=torch.float64)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.load().ocf_ssim_fwd(_t4(a), _t4(b), C.c_void_p(sums.data_ptr()), B, C_, H, W, ws, _stream(a)), "ocf_ssim_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.ws = ws
+        return sums.float()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gsums):
+        a, b = ctx.saved_tensors
+        B, C_, H, W = a.shape
+        L = _lib.load()
+        coef = gsums.float().contiguous()
+        grads = []
+        for need, x, y in ((ctx.needs_input_grad[0], a, b), (ctx.needs_input_grad[1], b, a)):
+            if not need:
+                grads.append(None)
+                continue
+            g = torch.empty((B, C_, H, W), device=a.device, dtype=torch.float32)
+            ws_buf = _workspace(L.ocf_ssim_bwd_workspace_bytes, B, C_, H, W, ctx.ws, device=a.device)
+            with torch.cuda.device(a.device):
+                _lib.check(L.ocf_ssim_bwd(_t4(x), _t4(y), C.c_void_p(coef.data_ptr()), _t4(g), C.c_void_p(ws_buf.data_ptr()), B, C_, H, W,
+                                          ctx.ws, _stream(a)), "ocf_ssim_bwd")
+            grads.append(g)
+        return grads[0], grads[1], None
+
+
 def ssim(img1, img2, window_size=11, size_average=True):
-    """Drop-in for inpainting_metrics/ssim/ssim.py:65-75 (metric only: evaluated under no_grad by calculate_ssim,
-    inpainting_metrics/__init__.py:10-25; no gradient is implemented).  One kernel instead of five depthwise convolutions
-    and an elementwise chain.  Returns the mean SSIM, or the per-sample means when size_average is False."""
+    """Drop-in for inpainting_metrics/ssim/ssim.py:65-75: mean SSIM (Gaussian window sigma 1.5, zero padding window_size // 2), or the
+    per-sample means when size_average is False.  One kernel instead of five depthwise convolutions and an elementwise chain;
+    DIFFERENTIABLE w.r.t. both images (two kernels per image instead of autograd through the chain), which is what the
+    `photo_mode='ssim'` option of FlowStageModel trains with."""
     _check4(img1, "img1")
     _check4(img2, "img2")
     if img1.shape != img2.shape:
@@ -662,14 +698,12 @@ def ssim(img1, img2, window_size=11, size_average=True):
     if ws < 1 or ws > 16:
         raise ValueError(f"ssim: window_size must be in [1, 16] for the MI355X kernel, got {ws}")
     _require_hip(img1, img2)
-    a, b = _f32(img1.detach()), _f32(img2.detach())
+    a, b = _f32(img1), _f32(img2)
     B, C_, H, W = a.shape
-    sums = torch.empty(B, device=a.device, dtype=torch.float64)
-    with torch.cuda.device(a.device):
-        _lib.check(_lib.load().ocf_ssim_fwd(_t4(a), _t4(b), C.c_void_p(sums.data_ptr()), B, C_, H, W, ws, _stream(a)), "ocf_ssim_fwd")
+    sums = _SsimFn.apply(a, b, ws)
     pad = ws // 2
     n = C_ * (H + 2 * pad - ws + 1) * (W + 2 * pad - ws + 1)
-    per_sample = (sums / n).float()
+    per_sample = sums / n
     return per_sample.mean() if size_average else per_sample
 
 

@@ -340,6 +340,15 @@ def gold_ssim():
         arrs[f"ssim_ws{ws}_mean"] = ref_ssim.ssim(a, b, window_size=ws, size_average=True)
         arrs[f"ssim_ws{ws}_per_sample"] = ref_ssim.ssim(a, b, window_size=ws, size_average=False)
     arrs["ssim_identical"] = ref_ssim.ssim(a, a, window_size=11)
+    # gradients (SSIM as a differentiable photometric term): autograd of the reference's own _ssim
+    for ws in (4, 11):
+        ag, bg = a.clone().requires_grad_(), b.clone().requires_grad_()
+        ga, gb = torch.autograd.grad(ref_ssim.ssim(ag, bg, window_size=ws, size_average=True), (ag, bg))
+        arrs[f"ssim_ws{ws}_grad_a"], arrs[f"ssim_ws{ws}_grad_b"] = ga, gb
+    cw = torch.tensor([0.3, -1.7])
+    ag = a.clone().requires_grad_()
+    (ga,) = torch.autograd.grad((ref_ssim.ssim(ag, b, window_size=11, size_average=False) * cw).sum(), ag)
+    arrs["ssim_ws11_weights"], arrs["ssim_ws11_grad_a_weighted"] = cw, ga
     save("ssim", **arrs)
 
 

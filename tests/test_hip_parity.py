@@ -347,6 +347,27 @@ def test_ssim_golden(ops, golden):
         ops.ssim(a, b, 17)
 
 
+def test_ssim_gradients_golden(ops, golden):
+    """SSIM as a differentiable term: gradients w.r.t. both images against autograd of the reference's _ssim (odd window 11, the even
+    window 4 with its (H+1) x (W+1) map), per-sample weights, and a Sintel-sized frame against autograd of the oracle"""
+    g = golden("ssim")
+    for ws in (4, 11):
+        a, b = dev(g["a"], True), dev(g["b"], True)
+        ga, gb = torch.autograd.grad(ops.ssim(a, b, ws, True), (a, b))
+        close(ga, g[f"ssim_ws{ws}_grad_a"], 1e-5)
+        close(gb, g[f"ssim_ws{ws}_grad_b"], 1e-5)
+    a = dev(g["a"], True)
+    (ga,) = torch.autograd.grad((ops.ssim(a, dev(g["b"]), 11, False) * dev(g["ssim_ws11_weights"])).sum(), a)
+    close(ga, g["ssim_ws11_grad_a_weighted"], 1e-5)
+    gen = torch.Generator().manual_seed(14)
+    imgs = torch.rand((2, 6, 109, 256), generator=gen) * 2 - 1
+    xa = imgs[:, :3].clone().requires_grad_()
+    (gref,) = torch.autograd.grad(O.ssim(xa, imgs[:, 3:], 11), xa)
+    da = imgs.to(DEV)[:, :3].clone().requires_grad_()
+    (got,) = torch.autograd.grad(ops.ssim(da, imgs.to(DEV)[:, 3:], 11), da)
+    np.testing.assert_allclose(got.cpu().numpy(), gref.numpy(), rtol=1e-4, atol=1e-9)
+
+
 # ------------------------------------------------------------------------------------- convolution epilogue
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape,cl", [((2, 32, 33, 47), True), ((2, 96, 17, 30), True), ((1, 12, 9, 21), True), ((3, 2, 16, 16), True),

@@ -95,6 +95,30 @@ def test_unsupervised_stage_step(golden, occ_aware, tag):
     close(m.flow_pred.predict_flow2.weight.grad[:, :16], g[f"stage_{tag}_grad_predict_flow2"], 1e-3)
 
 
+def test_ssim_photo_mode_step():
+    """photo_mode='ssim' (SURVEY 8f-2): the unsupervised step with 1 - SSIM(warp(img2, flow), img1) as the photometric term equals the
+    same expression built from the oracle's SSIM and warp on the model's own predicted flow, and its gradient reaches the network"""
+    from ocflow_amd.models.model import FlowStageModel
+    from oracle import ocflow_oracle as O
+    hp = dict(learning_rate=1e-5, model="flownet", displacement=4, photo_weight=1.0, smooth1_weight=0.0, smooth2_weight=0.0,
+              with_occ=False, occ_aware=False, photo_mode="ssim")
+    m = rngfree_fill(FlowStageModel(hp)).to(DEV).eval()
+    gen = torch.Generator().manual_seed(2)
+    imgs = (torch.rand((2, 6, 64, 96), generator=gen) * 2 - 1).to(DEV)
+    batch = (imgs, torch.zeros((2, 2, 64, 96), device=DEV))
+    loss = m.training_step(batch, 0)
+    with torch.no_grad():
+        flow = m(imgs).float().cpu()
+    ref = 1.0 - O.ssim(O.warp(imgs[:, 3:6].cpu(), flow, True), imgs[:, 0:3].cpu(), 11)
+    assert abs(float(loss) - float(ref)) < 1e-5
+    loss.backward()
+    g = m.flow_pred.feature_pyramid_network.conv1[0].weight.grad if hasattr(m.flow_pred.feature_pyramid_network, "conv1") else None
+    grads = [p.grad for p in m.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(x).all() for x in grads) and any(float(x.abs().max()) > 0 for x in grads)
+    with pytest.raises(ValueError):
+        FlowStageModel({**hp, "photo_mode": "census"})
+
+
 def test_bf16_autocast_step_runs():
     """throughput mode: bf16 autocast + channels_last; checks the step runs, is finite and stays near the fp32 flow"""
     from ocflow_amd.models.flow_occ_model import FlowOccModel
