@@ -225,6 +225,17 @@ int ocf_bias_act_fwd(const ocf_tensor4* x, const float* bias, int B, int C, int 
 int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, float* gbias, int B, int C, int H, int W,
                      float negative_slope, int accumulate, int dtype, void* stream);
 
+/* ---- weight gradient of the 3x3, stride-1, padding == dilation convolutions of the estimator / context networks ------
+ * gw[co][ci][ky][kx] += sum_{b,y,x} gy[b,co,y,x] * x[b,ci, y + (ky-1)*dilation, x + (kx-1)*dilation]   (zero outside the image)
+ * x [B,Ci,H,W], gy [B,Co,H,W]: dense channels_last bf16, Ci % 8 == 0, Co % 8 == 0, dilation <= 16 (anything else: OCF_EUNSUPPORTED,
+ * the caller keeps the framework's convolution backward).  gw: fp32, element strides (gw_so, gw_si, gw_sky, gw_skx), ACCUMULATED into
+ * with float atomics (split-K over image rows): the caller zeroes it -- one buffer for every layer of a step instead of MIOpen's
+ * per-layer fp32 workspace fill + bf16 cast.
+ * replaces: the weight half of autograd's convolution_backward for conv() / nn.Conv2d(k=3, s=1, p=d, dilation=d) in
+ *           flow_net.py:11-37, flow_occ_net.py:11-67, context_net.py:11-17, cost_volume_flow_net.py:58-112 */
+int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky, int64_t gw_skx,
+                      int B, int Ci, int Co, int H, int W, int dilation, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

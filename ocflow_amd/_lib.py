@@ -58,6 +58,7 @@ SIGNATURES = {
     "ocf_ssim_bwd_workspace_bytes": [_i, _i, _i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_ssim_bwd": [_T4P, _T4P, _vp, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_sqdiff": [_T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
+    "ocf_conv3x3_wgrad": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_bias_act_fwd": [_T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
 }

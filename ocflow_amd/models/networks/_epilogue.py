@@ -11,12 +11,25 @@ import torch.nn.functional as F
 from ocflow_amd import ops
 
 
+def _conv_nobias(conv: nn.Conv2d, x):
+    """the convolution proper.  3x3 / stride-1 / same layers in the bf16 channels_last throughput configuration take their weight
+    gradient from the hand-written MFMA kernel (ops.conv3x3: ocf_conv3x3_wgrad); forward and input gradient stay MIOpen's.
+    Opt-in (OCFLOW_NATIVE_WGRAD=1): the first version of that kernel is parity-green and level with MIOpen's kernel + helper launches
+    on the large layers (profiles/r2_*_wgrad.txt) but not yet a net win for the whole step."""
+    if _native_wgrad() and ops.conv3x3_wgrad_eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
+        return ops.conv3x3(x, conv.weight, conv.dilation[0])
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def _native_wgrad() -> bool:
+    return os.environ.get("OCFLOW_NATIVE_WGRAD", "0") == "1"
+
+
 def conv_lrelu(conv: nn.Conv2d, x, negative_slope: float = 0.1):
     # OCFLOW_UNFUSED_EPILOGUE=1: the reference's own op chain (A/B switch for measurements and bisecting, not a fallback)
     if conv.bias is None or conv.padding_mode != "zeros" or _unfused():
         return F.leaky_relu(conv(x), negative_slope)
-    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-    return ops.bias_leaky_relu(y, conv.bias, negative_slope)
+    return ops.bias_leaky_relu(_conv_nobias(conv, x), conv.bias, negative_slope)
 
 
 def _unfused() -> bool:
@@ -27,8 +40,7 @@ def conv_bias(conv: nn.Conv2d, x):
     """nn.Conv2d(bias=True) without activation (prediction layers): bias-free convolution + in-place bias kernel"""
     if conv.bias is None or conv.padding_mode != "zeros" or _unfused():
         return conv(x)
-    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-    return ops.bias_add(y, conv.bias)
+    return ops.bias_add(_conv_nobias(conv, x), conv.bias)
 
 
 def deconv_bias(deconv: nn.ConvTranspose2d, x, output_size=None):

@@ -24,7 +24,7 @@ from . import _lib
 __all__ = [
     "compute_cost_volume", "corr_warp", "warp", "normalize_features", "robust_l1", "photometric_error",
     "warp_photometric_error", "gradient", "first_order_smoothness_loss", "second_order_smoothness_loss",
-    "smoothness_losses", "compute_range_map", "occlusion_from_flow", "ssim", "psnr", "set_deterministic", "masked_l1",
+    "smoothness_losses", "compute_range_map", "occlusion_from_flow", "ssim", "psnr", "set_deterministic", "masked_l1", "conv3x3", "conv3x3_wgrad",
 ]
 
 MAX_DISPLACEMENT = 4
@@ -727,9 +727,72 @@ def psnr(img1, img2, pixel_max=255.0, per_sample=True):
     return val if per_sample else val.mean()
 
 
+# ------------------------------------------------------------------------- 3x3 convolution, weight gradient
+def conv3x3_wgrad(x, gy, dilation=1, out=None):
+    """Weight gradient of a 3x3 / stride-1 / padding == dilation convolution (the estimator / context network layers: flow_net.py:11-37,
+    flow_occ_net.py:11-67, context_net.py:11-17) on the matrix cores: x [B,Ci,H,W], gy [B,Co,H,W] dense channels_last bf16 ->
+    fp32 [Co,Ci,3,3] in channels_last weight strides.  `out`: an fp32 tensor of that shape to ACCUMULATE into (split-K float atomics);
+    None allocates a zeroed one.  Raises for operands the kernel does not take (the callers check `conv3x3_wgrad_eligible` first)."""
+    _require_hip(x, gy)
+    B, Ci, H, W = x.shape
+    Co = gy.shape[1]
+    if out is None:
+        out = torch.zeros((Co, Ci, 3, 3), device=x.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    so, si, sky, skx = out.stride()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ocf_conv3x3_wgrad(_t4(x), _t4(gy), C.c_void_p(out.data_ptr()), so, si, sky, skx, B, Ci, Co, H, W, int(dilation),
+                                                 _dtype_code(x), _stream(x)), "ocf_conv3x3_wgrad")
+    return out
+
+
+def conv3x3_wgrad_eligible(x, weight, stride, padding, dilation, groups) -> bool:
+    """operands ocf_conv3x3_wgrad takes: bf16, dense channels_last activations, 3x3, stride 1, padding == dilation <= 16, one group,
+    channel counts that are multiples of 8 (16-byte pixels)"""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4):
+        return False
+    if tuple(weight.shape[2:]) != (3, 3) or groups != 1 or tuple(stride) != (1, 1):
+        return False
+    d = tuple(dilation)
+    if d[0] != d[1] or tuple(padding) != d or d[0] > 16:
+        return False
+    Ci, Co = weight.shape[1], weight.shape[0]
+    return Ci % 8 == 0 and Co % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last) and x.size(1) > 1
+
+
+class _Conv3x3Fn(Function):
+    """`F.conv2d(x, w, None, 1, d, d)` whose backward takes the INPUT gradient from the framework (MIOpen) and the WEIGHT gradient from
+    ocf_conv3x3_wgrad: one launch per layer instead of MIOpen's workspace fill + split-K kernel + cast."""
+
+    @staticmethod
+    def forward(ctx, x, w, d):
+        ctx.save_for_backward(x, w)
+        ctx.d = d
+        return torch.ops.aten.convolution(x, w, None, (1, 1), (d, d), (d, d), False, (0, 0), 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        d = ctx.d
+        gx = gw = None
+        if not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            acc = _take_zeros(w.numel(), gy.device).as_strided(w.shape, w.stride())
+            gw = conv3x3_wgrad(x, gy.to(x.dtype), d, out=acc)
+        return gx, gw, None
+
+
+def conv3x3(x, weight, dilation=1):
+    """3x3 / stride-1 / same convolution without bias (the epilogue kernels add it) with the hand-written weight gradient"""
+    return _Conv3x3Fn.apply(x, weight, int(dilation))
+
+
 # ---------------------------------------------------------------------------------- convolution epilogue
 _ZERO_POOL = {}  # device index -> [fp32 buffer of zeros, next free element, graph-capture id it was filled in (0 = eager)]
-_ZERO_POOL_ELEMS = 1 << 16
+_ZERO_POOL_ELEMS = 1 << 22  # 16 MB: bias gradients and (ocf_conv3x3_wgrad) whole fp32 weight gradients of a step
 _CAPTURE_ID = C.c_ulonglong(0)
 
 

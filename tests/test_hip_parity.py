@@ -607,3 +607,46 @@ def test_psnr_golden(ops, golden):
     np.testing.assert_allclose(ops.psnr(cl[:, :3], cl[:, 3:]).cpu().numpy(), want, rtol=1e-5)
     with pytest.raises(ValueError):
         ops.psnr(a, b[:, :2])
+
+
+# ----------------------------------------------------------------- 3x3 convolution weight gradient (first slice)
+@pytest.mark.parametrize("shape,d", [((2, 32, 16, 21, 45), 1), ((1, 128, 128, 9, 70), 1), ((2, 96, 64, 17, 33), 2), ((1, 64, 32, 40, 64), 4),
+                                      ((1, 16, 8, 5, 130), 1), ((1, 128, 96, 35, 40), 16), ((3, 40, 24, 7, 9), 8), ((1, 8, 160, 6, 66), 1)])
+def test_conv3x3_wgrad_vs_fp32_reference(ops, shape, d):
+    """ocf_conv3x3_wgrad (MFMA split-K kernel, transposing LDS reads) against the fp32 weight gradient of the same convolution on the
+    bf16-rounded operands: every dilation of the context network, partial 32-channel blocks (Ci = 40, Co = 24 / 96 / 160 > 128),
+    widths that are not a multiple of the 64-pixel k-tile, accumulate-into semantics"""
+    B, Ci, Co, H, W = shape
+    gen = torch.Generator().manual_seed(Ci * 3 + Co + d)
+    x = torch.randn((B, Ci, H, W), generator=gen).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((B, Co, H, W), generator=gen).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros((Co, Ci, 3, 3), device=DEV)
+    ref = torch.ops.aten.convolution_backward(gy.float(), x.float(), w, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, [False, True, False])[1]
+    got = ops.conv3x3_wgrad(x, gy, d)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
+    again = ops.conv3x3_wgrad(x, gy, d, out=got.clone())  # accumulates
+    np.testing.assert_allclose(again.cpu().numpy(), 2 * ref.cpu().numpy(), rtol=2e-4, atol=4e-4 * float(ref.abs().max()))
+
+
+def test_conv3x3_autograd_path_matches_framework(ops):
+    """ops.conv3x3 (framework forward + input gradient, hand-written weight gradient) against F.conv2d autograd in bf16: same output, same
+    input gradient bit for bit, weight gradient within bf16 rounding of the fp32-accumulated value"""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.randn((2, 64, 30, 50), generator=gen).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    w0 = (torch.randn((96, 64, 3, 3), generator=gen) * 0.05).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    go = torch.randn((2, 96, 30, 50), generator=gen).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fn in (lambda a, b: F.conv2d(a, b, None, 1, 2, 2), lambda a, b: ops.conv3x3(a, b, 2)):
+        x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+        assert ops.conv3x3_wgrad_eligible(x, w, (1, 1), (2, 2), (2, 2), 1)
+        y = fn(x, w)
+        gx, gw = torch.autograd.grad(y, (x, w), go)
+        res.append((y, gx, gw))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[1][2].dtype == torch.bfloat16 and res[1][2].stride() == w0.stride()
+    scale = float(res[0][2].float().abs().max())
+    np.testing.assert_allclose(res[1][2].float().cpu().numpy(), res[0][2].float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
+    assert not ops.conv3x3_wgrad_eligible(x0.float(), w0.float(), (1, 1), (1, 1), (1, 1), 1)
+    assert not ops.conv3x3_wgrad_eligible(x0, w0, (2, 2), (1, 1), (1, 1), 1)
