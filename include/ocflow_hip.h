@@ -121,11 +121,22 @@ int ocf_corr_occ_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_ten
  *           flow_model.py:49-79 (AC-True)  [grid build + F.grid_sample] */
 int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* out, int B, int C, int H, int W,
                  float flow_scale, int align_corners, int dtype, void* stream);
-/* gimg  : fp32 [B,C,H,W] accumulation buffer, MUST be zeroed by the caller (float atomics);
+/* gimg  : fp32 [B,C,H,W]; the scatter kernel accumulates into it with float atomics and needs it ZEROED by the caller, the gather
+ *         kernel pair (channels_last, >= 1M (pixel, channel) pairs) overwrites it: ocf_warp_bwd_plan() says which (bit 0 of its
+ *         result = "zero grad_img first"; a caller that always zeroes is always correct);
  * gflow : fp32 [B,2,H,W], written (gradient w.r.t. the UNSCALED flow, i.e. includes s). */
+int ocf_warp_bwd_plan(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C, int H,
+                      int W, int dtype);
 int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
                  const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners, int dtype,
                  void* stream);
+
+/* Kernel selection of ocf_warp_bwd for channels_last operands (process-wide; same results up to float summation order):
+ * 0 = automatic: the gather kernel (per-destination-pixel lists in LDS, plain stores; sources whose taps lie within 6 pixels) + the
+ *     per-source kernel (grad_flow, float atomics for the remaining far sources) when the tensor has >= 1M (pixel, channel) pairs,
+ *     else the scatter kernel;  1 = scatter kernel (global float atomics) always;  2 = gather pair whenever the layout allows
+ * -- for A/B measurements and for testing both paths at any size. */
+int ocf_warp_bwd_select(int policy);
 
 /* Deterministic variant: the same contributions accumulated through 64-bit fixed-point integer atomics
  * (2^-36 resolution, |sum| < 1.3e8) in a caller-provided workspace of ocf_warp_bwd_det_workspace_bytes() bytes (zeroed by the

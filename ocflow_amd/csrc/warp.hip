@@ -226,6 +226,188 @@ __global__ __launch_bounds__(256) void warp_bwd_cl_kernel(T4 img, T4 flow, T4 go
   }
 }
 
+static int g_warp_bwd_policy = 0;  // ocf_warp_bwd_select: 0 = gather + per-source kernels where they pay, 1 = scatter kernel only, 2 = gather whenever eligible
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward, channels_last, without the global float-atomic bound (warp_bwd_cl_kernel runs at the chip-wide atomic rate: 4 atomics per
+// (pixel, channel), 114 MB of them at the 8 x 32 x 109 x 256 level = 100 us).  Measured on the way: LDS float atomics are no way out --
+// ds_add_f32 retires ~1 wave instruction per 120 cycles and ds_add_u32 per ~20-30, so a destination tile accumulated with them ran
+// 180 / 40 us.  What is fast is a GATHER, and LDS integer atomics are only needed to build its index:
+//   kernel A (warp_bwd_gather_kernel): one workgroup owns a 32 x 8 tile of grad_img pixels x 32 channels.  Phase 1, lanes = the source
+//     pixels within NEAR_R of the tile: each bilinear tap that lands inside the tile is pushed onto that destination pixel's linked
+//     list in LDS (one slot counter, one ds_wrxchg per tap: ~2000 integer atomics per tile instead of 61,000 float ones).  Phase 2,
+//     lanes = (destination pixel, channel): walk the pixel's list, sum weight * grad_out[source] in a register, store -- plain
+//     stores, no zero-fill of grad_img, eight pixels per half-wave in flight so that the grad_out loads (L2) overlap.
+//     A source is "near" when its four taps lie within NEAR_R pixels of itself; near sources are handled here, by exactly the tiles
+//     their taps fall into.
+//   kernel B (warp_bwd_flow_kernel), afterwards: lanes = (source pixel, 16-byte channel unit): grad_flow = sum_c grad_out * d(sample)/
+//     d(flow) by a shuffle reduction over the pixel's unit lanes, written with a plain store (no zero-fill, no atomics), and the
+//     grad_img float atomics of the FAR sources (large motion) only.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int WT_W = 32, WT_H = 8, NEAR_R = 6, WWIN_W = WT_W + 2 * NEAR_R, WWIN_H = WT_H + 2 * NEAR_R, WWIN = WWIN_W * WWIN_H;
+constexpr unsigned WL_END = 0xffffu;
+
+__device__ __forceinline__ bool warp_is_near(const Bilin& s, int x, int y) {
+  return s.x0 >= x - NEAR_R && s.x0 + 1 <= x + NEAR_R && s.y0 >= y - NEAR_R && s.y0 + 1 <= y + NEAR_R;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(T4 flow, T4 gout, T4 gimg, int B, int C, int H, int W, float fs, WarpGeom wg,
+                                                              int tiles_x, int tiles_y) {
+  constexpr int ES = (int)sizeof(T), U = Unit<T>::U, NU = 32 / U;  // 16-byte units per 32-channel block
+  __shared__ float s_w[4 * WWIN];        // list entry (window source i, tap k) lives in slot 4 i + k: weight
+  __shared__ unsigned s_nx[4 * WWIN];    //                                                            next entry of the same pixel
+  __shared__ unsigned s_head[WT_W * WT_H];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x, c0 = blockIdx.y * 32;
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi, trem = tile - b * tpi;
+  const int ty0 = (trem / tiles_x) * WT_H, tx0 = (trem % tiles_x) * WT_W;
+  const float* fl = (const float*)flow.p + (long)b * flow.sb;
+  s_head[tid] = WL_END;  // 256 threads == WT_W * WT_H
+  __syncthreads();
+  // ---- phase 1, lanes = window sources: push every in-tile, in-image tap of every near source onto its destination pixel's list.
+  // The slot of an entry is fixed (4 i + k), so the only atomic is the exchange on the pixel's head; the four of a lane are
+  // independent and in flight together.
+  for (int i = tid; i < WWIN; i += 256) {
+    const int wy = i / WWIN_W, wx = i - wy * WWIN_W;
+    const int sx = tx0 - NEAR_R + wx, sy = ty0 - NEAR_R + wy;
+    if (sx >= 0 && sx < W && sy >= 0 && sy < H) {
+      const long fo = (long)sy * flow.sh + (long)sx * flow.sw;
+      const float uu = fl[fo] * fs, vv = fl[fo + flow.sc] * fs;
+      const Bilin s = bilin_setup(((float)sx + uu) * wg.ax + wg.bx, ((float)sy + vv) * wg.ay + wg.by, H, W);
+      if (warp_is_near(s, sx, sy)) {
+        unsigned prev[4];
+        bool push[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int ddx = k & 1, ddy = k >> 1;
+          const int lx = s.x0 + ddx - tx0, ly = s.y0 + ddy - ty0;
+          push[k] = ((ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0)) && lx >= 0 && lx < WT_W && ly >= 0 && ly < WT_H;
+          prev[k] = WL_END;
+          if (push[k]) prev[k] = atomicExch(&s_head[ly * WT_W + lx], (unsigned)(4 * i + k));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (push[k]) {
+            s_w[4 * i + k] = ((k & 1) ? s.wx1 : 1.f - s.wx1) * ((k >> 1) ? s.wy1 : 1.f - s.wy1);
+            s_nx[4 * i + k] = prev[k];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: ONE THREAD PER DESTINATION PIXEL: walk the pixel's list two entries at a time, 32 channel sums in registers, 16-byte
+  // loads of the sources' grad_out rows (L2).  (Lanes = (pixel, channel) with a half-wave per pixel serialised 32 list walks per thread
+  // and ran 100 us at the level-2 shape: every walk is a chain of dependent reads.)
+  const char* gb = gout.p + (long)b * gout.sb * ES;
+  float acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = 0.f;
+  auto src_row = [&](unsigned e) __attribute__((always_inline)) {
+    const int i = (int)(e >> 2);
+    const int wy = i / WWIN_W, wx = i - wy * WWIN_W;
+    return gb + ((long)(ty0 - NEAR_R + wy) * gout.sh + (long)(tx0 - NEAR_R + wx) * gout.sw + c0) * ES;
+  };
+  T4 gv = gout;  // unit loader view: pixel base pointer, channel offset relative to c0
+  for (unsigned cur = s_head[tid]; cur != WL_END;) {
+    const unsigned n0 = s_nx[cur];
+    const bool two = n0 != WL_END;
+    const unsigned e1 = two ? n0 : cur;
+    const float w0 = s_w[cur], w1 = two ? s_w[e1] : 0.f;
+    const char* r0 = src_row(cur);
+    const char* r1 = src_row(e1);
+    float f0[NU][U], f1[NU][U];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      gv.p = (char*)r0; load_unit_f<T, VEC>(gv, 0, u * U, C - c0, f0[u]);
+      gv.p = (char*)r1; load_unit_f<T, VEC>(gv, 0, u * U, C - c0, f1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++)
+#pragma unroll
+      for (int k = 0; k < U; k++) acc[u * U + k] = __builtin_fmaf(w1, f1[u][k], __builtin_fmaf(w0, f0[u][k], acc[u * U + k]));
+    cur = two ? s_nx[e1] : WL_END;
+  }
+  const int y = ty0 + tid / WT_W, x = tx0 + (tid % WT_W);
+  if (y < H && x < W) {
+    float* gi = (float*)gimg.p + (long)b * gimg.sb + (long)y * gimg.sh + (long)x * gimg.sw + c0;
+    if (c0 + 32 <= C && ((gimg.sw | gimg.sh | gimg.sb) & 3) == 0) {
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) *(f32x4*)(gi + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; k++)
+        if (c0 + k < C) gi[k] = acc[k];
+    }
+  }
+}
+
+// kernel B: lanes = (source pixel, 16-byte channel unit).  UPP = units per pixel (a power of two <= 64 so that a pixel's lanes share a wave)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void warp_bwd_flow_kernel(T4 img, T4 flow, T4 gout, T4 gimg, T4 gflow, int B, int C, int H, int W, float fs,
+                                                            WarpGeom wg, long total, int upp, int upp_pad) {
+  constexpr int U = Unit<T>::U;
+  const float* fl = (const float*)flow.p;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = idx < total;
+  const long pix = live ? idx / upp_pad : 0;
+  const int un = live ? (int)(idx - pix * upp_pad) : 0;
+  const int c0 = un * U;
+  const bool on = live && un < upp;
+  const int x = pix % W;
+  const long r = pix / W;
+  const int y = r % H, b = r / H;
+  float gx = 0.f, gy = 0.f;
+  const long fo = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
+  const float uu = fl[fo] * fs, vv = fl[fo + flow.sc] * fs;
+  const Bilin s = bilin_setup(((float)x + uu) * wg.ax + wg.bx, ((float)y + vv) * wg.ay + wg.by, H, W);
+  if (on) {
+    float g[U], v[4][U];
+    load_unit_f<T, VEC>(gout, (long)b * gout.sb + (long)y * gout.sh + (long)x * gout.sw, c0, C, g);
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int ddx = n & 1, ddy = n >> 1;
+      const bool ok = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
+      const int xc = min(max(s.x0 + ddx, 0), W - 1), yc = min(max(s.y0 + ddy, 0), H - 1);
+      load_unit_f<T, VEC>(img, (long)b * img.sb + (long)yc * img.sh + (long)xc * img.sw, c0, C, v[n]);
+      if (!ok) {
+#pragma unroll
+        for (int k = 0; k < U; k++) v[n][k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      gx = __builtin_fmaf(g[k], (1.f - s.wy1) * (v[1][k] - v[0][k]) + s.wy1 * (v[3][k] - v[2][k]), gx);
+      gy = __builtin_fmaf(g[k], (1.f - s.wx1) * (v[2][k] - v[0][k]) + s.wx1 * (v[3][k] - v[1][k]), gy);
+    }
+    if (gimg.p && !warp_is_near(s, x, y)) {  // far source: the gather kernel did not take it
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        const int ddx = n & 1, ddy = n >> 1;
+        if ((ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0)) {
+          const float w = (ddx ? s.wx1 : 1.f - s.wx1) * (ddy ? s.wy1 : 1.f - s.wy1);
+          float* dst = (float*)gimg.p + (long)b * gimg.sb + (long)(s.y0 + ddy) * gimg.sh + (long)(s.x0 + ddx) * gimg.sw + c0;
+#pragma unroll
+          for (int k = 0; k < U; k++)
+            if (c0 + k < C) atomicAdd(dst + k, w * g[k]);
+        }
+      }
+    }
+  }
+  if (gflow.p) {
+    for (int o = upp_pad >> 1; o > 0; o >>= 1) {
+      gx += __shfl_xor(gx, o, 64);
+      gy += __shfl_xor(gy, o, 64);
+    }
+    if (live && un == 0) {
+      float* gf = (float*)gflow.p + (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
+      gf[0] = gx * wg.ax * fs;
+      gf[gflow.sc] = gy * wg.ay * fs;
+    }
+  }
+}
+
 template <typename T> static bool wvec_ok(const ocf_tensor4* t) {
   constexpr int U = Unit<T>::U;
   return t->sc == 1 && ((uintptr_t)t->data % 16 == 0) && t->sw % U == 0 && t->sh % U == 0 && t->sb % U == 0;
@@ -263,6 +445,20 @@ static int warp_fwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
   return launch_status();
 }
 
+// does the gather + flow kernel pair take this request?  (channels_last, 8/16-byte aligned pixels, enough work to pay for two launches:
+// below ~1M (pixel, channel) pairs the single scatter kernel is faster -- 8.1 vs 14.7 us at 8 x 196 x 7 x 16)
+template <typename T>
+static bool warp_bwd_use_gather(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C,
+                                int H, int W) {
+  const long npix = (long)B * H * W;
+  const bool cl = img->sc == 1 && gout->sc == 1 && gimg && gimg->sc == 1 && C >= 4;
+  const bool gf_dense = !gflow || (gflow->sw == 1 && gflow->sh == W && gflow->sc == (long)H * W && gflow->sb == 2L * H * W);
+  if (!cl || !gf_dense || npix * C >= (1L << 40) || g_warp_bwd_policy == 1 || (g_warp_bwd_policy == 0 && npix * C < (1L << 20))) return false;
+  const int vec = min_vec(vec_width<T>(img), vec_width<T>(gout));
+  const int upp = (C + Unit<T>::U - 1) / Unit<T>::U;
+  return vec >= 8 && upp <= 64 && C % (vec / (int)sizeof(T)) == 0;
+}
+
 template <typename T>
 static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
                       const ocf_tensor4* gflow, int B, int C, int H, int W, float fs, int ac, hipStream_t st) {
@@ -272,11 +468,39 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
   const bool cl = img->sc == 1 && gout->sc == 1 && (!gimg || gimg->sc == 1) && C >= 4;
   const bool gf_dense = !gflow || (gflow->sw == 1 && gflow->sh == W && gflow->sc == (long)H * W && gflow->sb == 2L * H * W);
   if (cl && gf_dense && npix * C < (1L << 40)) {
-    if (gflow && hipMemsetAsync(gflow->data, 0, (size_t)npix * 2 * sizeof(float), st) != hipSuccess) return OCF_ELAUNCH;
     int G = 1;
     while (G < 64 && C % (G * 2) == 0) G *= 2;
     const long total = npix * C;
     const long blocks = (total + 255) / 256;
+    const int vec = min_vec(vec_width<T>(img), vec_width<T>(gout));
+    const int upp = (C + Unit<T>::U - 1) / Unit<T>::U;
+    if (warp_bwd_use_gather<T>(img, gout, gimg, gflow, B, C, H, W)) {
+      // gather kernel for the near sources (plain stores: writes the whole of grad_img, no zero-fill needed), then the per-source
+      // kernel: grad_flow (plain stores) + float atomics for the far sources
+      const int tx = (W + WT_W - 1) / WT_W, ty = (H + WT_H - 1) / WT_H;
+      const long tiles = (long)B * tx * ty;
+      int upp_pad = 1;
+      while (upp_pad < upp) upp_pad *= 2;
+      const long totalb = npix * upp_pad;
+      if (tiles <= 0x7fffffffL && (totalb + 255) / 256 <= 0x7fffffffL) {
+        LaunchProf lp;
+        if (vec == 16)
+          lp.launch(false, warp_bwd_gather_kernel<T, 16>, dim3((unsigned)tiles, (unsigned)((C + 31) / 32)), dim3(256), 0, st, mk(flow), mk(gout),
+                    mk(gimg), B, C, H, W, fs, wg, tx, ty);
+        else
+          lp.launch(false, warp_bwd_gather_kernel<T, 8>, dim3((unsigned)tiles, (unsigned)((C + 31) / 32)), dim3(256), 0, st, mk(flow), mk(gout),
+                    mk(gimg), B, C, H, W, fs, wg, tx, ty);
+        const dim3 gb((unsigned)((totalb + 255) / 256));
+        if (vec == 16)
+          lp.launch(true, warp_bwd_flow_kernel<T, 16>, gb, dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, fs, wg,
+                    totalb, upp, upp_pad);
+        else
+          lp.launch(true, warp_bwd_flow_kernel<T, 8>, gb, dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, fs, wg,
+                    totalb, upp, upp_pad);
+        return launch_status();
+      }
+    }
+    if (gflow && hipMemsetAsync(gflow->data, 0, (size_t)npix * 2 * sizeof(float), st) != hipSuccess) return OCF_ELAUNCH;
     LaunchProf lp;
     lp.launch(true, warp_bwd_cl_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H,
               W, fs, wg, total, G);
@@ -302,6 +526,23 @@ extern "C" int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, con
   if (dtype == OCF_F32) return ocf::warp_fwd_t<float>(img, flow, out, B, C, H, W, flow_scale, align_corners, st);
   if (dtype == OCF_BF16) return ocf::warp_fwd_t<ocf::bf16>(img, flow, out, B, C, H, W, flow_scale, align_corners, st);
   return OCF_EINVAL;
+}
+
+extern "C" int ocf_warp_bwd_select(int policy) {
+  if (policy < 0 || policy > 2) return OCF_EINVAL;
+  ocf::g_warp_bwd_policy = policy;
+  return OCF_OK;
+}
+
+extern "C" int ocf_warp_bwd_plan(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C,
+                                 int H, int W, int dtype) {
+  if (!img || !gout || !img->data || !gout->data) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  bool gather = false;
+  if (dtype == OCF_F32) gather = ocf::warp_bwd_use_gather<float>(img, gout, gimg, gflow, B, C, H, W);
+  else if (dtype == OCF_BF16) gather = ocf::warp_bwd_use_gather<ocf::bf16>(img, gout, gimg, gflow, B, C, H, W);
+  else return OCF_EINVAL;
+  return gather ? 0 : 1;  // bit 0: grad_img must be zeroed by the caller (scatter kernel: float atomics)
 }
 
 extern "C" int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,

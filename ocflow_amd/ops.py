@@ -164,8 +164,11 @@ def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flo
         if gimg is not None and gimg.dtype != img.dtype:
             gimg = gimg.to(img.dtype)
         return gimg, gflow
-    gimg = _zeros_like_layout(img, img.shape, torch.float32) if need_img else None
+    gimg = _empty_like_layout(img, img.shape, torch.float32) if need_img else None
     gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32) if need_flow else None
+    # the scatter kernel accumulates into grad_img with float atomics (zero it first); the gather kernels overwrite it
+    if gimg is not None and _lib.load().ocf_warp_bwd_plan(_t4(img), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W, _dtype_code(img)) != 0:
+        gimg.zero_()
 
     def launch():
         with torch.cuda.device(img.device):

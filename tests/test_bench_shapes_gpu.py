@@ -249,3 +249,30 @@ def test_range_map_full_batch_vs_oracle(ops):
         ref = O.compute_range_map(flow)
         assert_close(rm, ref, 1e-4, 1e-6, "range map")
         assert_close(oc, O.occlusion_from_range(ref), 1e-4, 1e-5, "occlusion")
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 23, 45), (1, 196, 7, 16), (3, 8, 9, 33), (1, 32, 40, 70), (2, 64, 5, 130)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ac", [False, True])
+def test_warp_backward_gather_kernels_small_shapes(ops, lib, shape, dtype, ac):
+    """the gather + per-source kernel pair forced on (ocf_warp_bwd_select(2)) at shapes the automatic policy would give to the scatter
+    kernel: partial tiles, channel counts that are not a multiple of 32 (40, 196: 8-byte aligned pixels), fp32, both sampling
+    conventions, flows with many FAR sources (|displacement| > 6 px: the float-atomic path inside the per-source kernel) and sources
+    that leave the image -- against autograd of the oracle's grid_sample warp, and bit-identical grad_img on a second run"""
+    Bb, Cc, h, w = shape
+    gen = torch.Generator().manual_seed(sum(shape) + int(ac))
+    img = torch.randn(shape, generator=gen).to(dtype)
+    flow = torch.randn((Bb, 2, h, w), generator=gen) * 5.0
+    cot = torch.randn(shape, generator=gen).to(dtype)
+    a, f = img.float().requires_grad_(), flow.clone().requires_grad_()
+    gir, gfr = torch.autograd.grad(O.warp(a, f, ac), (a, f), cot.float())
+    L = lib.load()
+    try:
+        assert L.ocf_warp_bwd_select(2) == 0
+        x, fl = cl(img).requires_grad_(), flow.to(DEV).requires_grad_()
+        gi, gf = torch.autograd.grad(ops.warp(x, fl, ac), (x, fl), cl(cot))
+    finally:
+        L.ocf_warp_bwd_select(0)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_close(gi, gir, tol * 5, tol, "grad img")
+    assert_close(gf, gfr, tol * 5, tol, "grad flow", outliers=2e-3)

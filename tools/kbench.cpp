@@ -77,7 +77,11 @@ int main(int argc, char** argv) {
     float eg1 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, nullptr, B, C, H, W, 4, dt, st); }, st, 50);
     float eg2 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, nullptr, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
     float e2 = time_us([&] { ocf_corr_occ_bwd(&t1, &t2, &tc, &to, &tg1, &tg2, &tgo, B, C, H, W, 4, dt, st); }, st, 50);
+    ocf_warp_bwd_select(1);
+    float f_scatter = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, st); }, st, 50);
+    ocf_warp_bwd_select(0);
     float f = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, st); }, st, 50);
+    printf("  warp_bwd: destination-tile + far scatter %.1f us | scatter only (+ grad_img memset outside) %.1f us\n", f, f_scatter);
     double px = (double)np, bytes_plain = px * (2.0 * C * es + 81.0 * es);
     printf("%3dx%3dx%4d | corr %7.1f us %6.0f GB/s | +occ %7.1f us %6.0f | fused %7.1f us %6.0f | warp %6.1f us %6.0f | corr_bwd %7.1f us %6.0f (g1 %5.1f g2 %5.1f) | +occ %7.1f us | warp_bwd %7.1f us %6.0f\n",
            C, H, W, a, bytes_plain / a / 1e3, b, (bytes_plain + px * 4) / b / 1e3, c, (bytes_plain + px * 12) / c / 1e3, d, px * (2.0 * C * es + 8) / d / 1e3,
