@@ -187,6 +187,10 @@ int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const f
  * replaces: flow_to_warp + compute_range_map  models/model.py:223-305 (dup flow_model.py:81-163), model.py:391 */
 int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, int B, int H, int W, void* stream);
 
+/* kernel selection (process-wide, same results up to float summation order): 1 = LDS-window splat (default: 99 us at 8 x 436 x 1024),
+ * 0 = per-pixel gather through LDS lists + float atomics for sources displaced by more than 8 pixels (137 us; its near-source part
+ * is bit-reproducible) */
+int ocf_range_map_select(int policy);
 /* deterministic variant (fixed-point integer atomics, see ocf_warp_bwd_det); workspace: ocf_range_map_det_workspace_bytes() */
 int ocf_range_map_det_workspace_bytes(int B, int H, int W, int64_t* bytes);
 int ocf_range_map_det(const ocf_tensor4* flow, float* range, float* occ, void* workspace, int B, int H, int W, void* stream);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ocf_warp_bwd_plan": [_T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i],
     "ocf_warp_bwd_det_workspace_bytes": [_i, _i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_warp_bwd_det": [_T4P, _T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ocf_range_map_select": [_i],
     "ocf_range_map_det_workspace_bytes": [_i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_range_map_det": [_T4P, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ocf_photo_loss_fwd": [_T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _vp],

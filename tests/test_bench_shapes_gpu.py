@@ -237,8 +237,10 @@ def test_range_map_full_batch_vs_oracle(ops):
     gen = torch.Generator().manual_seed(21)
     flow = torch.nn.functional.interpolate(torch.randn((B, 2, 28, 64), generator=gen) * 6, size=(436, 1024), mode="bilinear")
     flow[:, :, :3, :] *= 20.0  # far out of the window / out of the image
-    for det in (False, True):
+    from ocflow_amd import _lib
+    for det, policy in ((False, 1), (False, 0), (True, 1)):  # splat kernel, gather + far kernels, fixed-point deterministic kernel
         ops.set_deterministic(det)
+        _lib.load().ocf_range_map_select(policy)
         try:
             rm = ops.compute_range_map(flow.to(DEV))
             oc = ops.occlusion_from_flow(flow.to(DEV))
@@ -246,6 +248,7 @@ def test_range_map_full_batch_vs_oracle(ops):
                 assert torch.equal(rm, ops.compute_range_map(flow.to(DEV)))
         finally:
             ops.set_deterministic(False)
+            _lib.load().ocf_range_map_select(1)
         ref = O.compute_range_map(flow)
         assert_close(rm, ref, 1e-4, 1e-6, "range map")
         assert_close(oc, O.occlusion_from_range(ref), 1e-4, 1e-5, "occlusion")

@@ -115,7 +115,11 @@ int main(int argc, char** argv) {
     float b = time_us([&] { ocf_photo_loss_bwd(&t1, &t2, &tf, &to, coef, &tg, nullptr, B, C, H, W, st); }, st, 50);
     float c = time_us([&] { ocf_smooth_loss_fwd(&t1, &tf, sums, B, C, H, W, 100.f, st); }, st, 50);
     float d = time_us([&] { ocf_smooth_loss_bwd(&t1, &tf, coef, &tg, B, C, H, W, 100.f, st); }, st, 50);
+    ocf_range_map_select(1);
+    float e_old = time_us([&] { ocf_range_map(&tf, rng, oc, B, H, W, st); }, st, 50);
+    ocf_range_map_select(0);
     float e = time_us([&] { ocf_range_map(&tf, rng, oc, B, H, W, st); }, st, 50);
+    printf("range map: gather + far %.1f us | LDS-window splat %.1f us\n", e, e_old);
     float f = time_us([&] { ocf_ssim_fwd(&t1, &t2, sums, B, C, H, W, 11, st); }, st, 20);
     float ms16 = time_us([&] { CK(hipMemsetAsync(sums, 0, 16, st)); }, st, 200);
     float ms14m = time_us([&] { CK(hipMemsetAsync(rng, 0, np * 4, st)); }, st, 50);
