@@ -15,5 +15,20 @@ import os as _os
 # previous contents) as soon as the host synchronises between two replays: gradients fill with garbage within 2-3 replays
 # (scripts/long_run.py --every 1 reproduces it; DESIGN.md "hipGraph").  The regular enqueue path is correct and just as fast
 # (measured 421 vs 426 pairs/s).  The flag is read when the HIP runtime initialises, so it is set at import, before any HIP
-# call; runtime.TrainStepper.enable_graph refuses to capture when it is not in effect.
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# call; runtime.TrainStepper.enable_graph refuses to capture when it is not in effect.  "In effect" is checked, not assumed: when the
+# variable was absent and the process had already initialised HIP (torch.cuda in use before this import), setting it now changes
+# nothing -- GRAPH_ENV_LATE records that, and enable_graph refuses.
+import sys as _sys
+
+
+def _graph_env_guard() -> bool:
+    """Set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 unless the caller chose a value; True when that came too late to take effect."""
+    if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in _os.environ:
+        return False  # the launcher's choice (a value other than "0" is refused by enable_graph itself)
+    torch = _sys.modules.get("torch")
+    late = bool(torch is not None and torch.cuda.is_initialized())
+    _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    return late
+
+
+GRAPH_ENV_LATE = _graph_env_guard()

@@ -334,6 +334,11 @@ class TrainStepper:
             # OCFLOW_UNSAFE_GRAPH=1 exists only to reproduce the corruption (scripts/long_run.py)
             raise RuntimeError("TrainStepper.enable_graph: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be set before the HIP runtime "
                                "initialises (import ocflow_amd first); the packet-capture replay path of ROCm 7 corrupts this graph")
+        import ocflow_amd
+        if ocflow_amd.GRAPH_ENV_LATE and os.environ.get("OCFLOW_UNSAFE_GRAPH", "0") != "1":
+            raise RuntimeError("TrainStepper.enable_graph: ocflow_amd was imported after the HIP runtime had initialised, so "
+                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is not in effect in this process; import ocflow_amd (or export the "
+                               "variable) before the first torch.cuda call")
         # Adam must keep its step counter on the device to be capturable
         for g in self.optimizer.param_groups:
             g["capturable"] = True

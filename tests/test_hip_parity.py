@@ -612,8 +612,9 @@ def test_psnr_golden(ops, golden):
 # ----------------------------------------------------------------- 3x3 convolution weight gradient (first slice)
 @pytest.mark.parametrize("shape,d", [((2, 32, 16, 21, 45), 1), ((1, 128, 128, 9, 70), 1), ((2, 96, 64, 17, 33), 2), ((1, 64, 32, 40, 64), 4),
                                       ((1, 16, 8, 5, 130), 1), ((1, 128, 96, 35, 40), 16), ((3, 40, 24, 7, 9), 8), ((1, 8, 160, 6, 66), 1)])
-def test_conv3x3_wgrad_vs_fp32_reference(ops, shape, d):
-    """ocf_conv3x3_wgrad (MFMA split-K kernel, transposing LDS reads) against the fp32 weight gradient of the same convolution on the
+@pytest.mark.parametrize("version", [1, 2])
+def test_conv3x3_wgrad_vs_fp32_reference(ops, shape, d, version):
+    """ocf_conv3x3_wgrad (both kernel versions: register-staged, and the LDS-DMA ring) against the fp32 weight gradient of the same convolution on the
     bf16-rounded operands: every dilation of the context network, partial 32-channel blocks (Ci = 40, Co = 24 / 96 / 160 > 128),
     widths that are not a multiple of the 64-pixel k-tile, accumulate-into semantics"""
     B, Ci, Co, H, W = shape
@@ -622,11 +623,18 @@ def test_conv3x3_wgrad_vs_fp32_reference(ops, shape, d):
     gy = torch.randn((B, Co, H, W), generator=gen).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
     w = torch.zeros((Co, Ci, 3, 3), device=DEV)
     ref = torch.ops.aten.convolution_backward(gy.float(), x.float(), w, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, [False, True, False])[1]
-    got = ops.conv3x3_wgrad(x, gy, d)
-    assert got.dtype == torch.float32 and got.shape == ref.shape
-    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
-    again = ops.conv3x3_wgrad(x, gy, d, out=got.clone())  # accumulates
-    np.testing.assert_allclose(again.cpu().numpy(), 2 * ref.cpu().numpy(), rtol=2e-4, atol=4e-4 * float(ref.abs().max()))
+    from ocflow_amd import _lib
+    lib = _lib.load()
+    assert lib.ocf_conv3x3_wgrad_select(version) == 0
+    try:
+        got = ops.conv3x3_wgrad(x, gy, d)
+        assert got.dtype == torch.float32 and got.shape == ref.shape
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
+        again = ops.conv3x3_wgrad(x, gy, d, out=got.clone())  # accumulates
+        np.testing.assert_allclose(again.cpu().numpy(), 2 * ref.cpu().numpy(), rtol=2e-4, atol=4e-4 * float(ref.abs().max()))
+    finally:
+        lib.ocf_conv3x3_wgrad_select(0)
+    assert lib.ocf_conv3x3_wgrad_select(3) != 0
 
 
 def test_conv3x3_autograd_path_matches_framework(ops):

@@ -193,3 +193,22 @@ def test_launcher_builds_the_reference_hparams(tmp_path):
         train.build_module({**args, "network_type": "twostage"})
     sup, _ = train.build_module({"network_type": "flowocc", "model": "flowoccnet", "learning_rate": 1e-3})
     assert type(sup).__name__ == "FlowOccModel"
+
+
+def test_graph_env_guard_detects_late_import(monkeypatch):
+    """ocflow_amd/__init__.py: the hipGraph environment switch is read when HIP initialises.  The guard reports 'late' exactly when the
+    variable was absent and torch.cuda had already been initialised at import; a value chosen by the launcher is left alone."""
+    import ocflow_amd
+    import torch
+
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    assert ocflow_amd._graph_env_guard() is True
+    assert os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"
+    assert ocflow_amd._graph_env_guard() is False  # now present: nothing to decide
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
+    assert ocflow_amd._graph_env_guard() is False
+    monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    assert ocflow_amd._graph_env_guard() is False and os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "1"
