@@ -251,6 +251,11 @@ int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tens
 int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky, int64_t gw_skx,
                       int B, int Ci, int Co, int H, int W, int dilation, int dtype, void* stream);
 
+/* kernel choice of ocf_corr_bwd / ocf_corr_occ_bwd (process-wide; same results up to float summation order): 0 = automatic, 1 = the
+ * vector kernel only, 2 = the matrix-core band-GEMM kernel whenever its preconditions hold (bf16, d = 4, channel-contiguous operands,
+ * 8-byte aligned pixels) */
+int ocf_corr_bwd_select(int policy);
+
 /* kernel version of ocf_conv3x3_wgrad (process-wide; same results up to float summation order): 0 = automatic, 1 = register-staged kernel,
  * 2 = LDS-DMA three-stage ring kernel (eight-wave workgroups, two Ci blocks per workgroup) */
 int ocf_conv3x3_wgrad_select(int policy);

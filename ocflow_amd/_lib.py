@@ -63,6 +63,7 @@ SIGNATURES = {
     "ocf_sqdiff": [_T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
     "ocf_conv3x3_wgrad": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_conv3x3_wgrad_select": [_i],
+    "ocf_corr_bwd_select": [_i],
     "ocf_bias_act_fwd": [_T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
 }

@@ -1,0 +1,373 @@
+// Cost-volume backward on the matrix cores (bf16, channels_last, d = 4): both gradients as BAND GEMMs along image rows.
+//   g1[y][x][c] = 1/C sum_{dy} sum_{x'} G1_dy[x][x'] * w2[y+dy][x'][c],   G1_dy[x][x'] = gout[y][x][(dy+4)*9 + (x'-x)+4],  |x'-x| <= 4
+//   g2[y][x][c] = 1/C sum_{dy} sum_{x'} G2_dy[x][x'] * f1[y-dy][x'][c],   G2_dy[x][x'] = gout[y-dy][x'][(dy+4)*9 + (x-x')+4], |x-x'| <= 4
+// (reference semantics: autograd of compute_cost_volume, cost_volume_flow_net.py:153-181 / flow_occ_net.py, as the vector kernel
+// corr_bwd_tiled in corr.hip, which remains the path for fp32, other layouts and small problems.)
+// Per 16-pixel strip of a row and per dy that is ONE v_mfma_f32_16x16x32_bf16 per 16 channels: D[c][x] = sum_k F^T[c][k] * G[k][x]
+// with k = 32 source pixels around the strip (24 can be non-zero).  The vector kernel spent 648 FMAs + 81 LDS unit reads per thread on
+// it and was VALU/LDS bound at 47-50 us per pass at 8x32x109x256; the MFMA count here is 1.6 us worth.  What remains is operand
+// delivery:
+//   F side (w2 / f1, [pixel][channel] in memory, k = pixel is the STRIDED direction): staged in LDS as [halo row][pixel][32 ch] and
+//       read with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, transposed on the way out);
+//   G side, g1: the 8 consecutive k of a lane are 8 consecutive taps of ITS pixel -- one unaligned 16-byte global load straight into
+//       the operand registers, out-of-band taps masked (no LDS, no staging pass);
+//   G side, g2: the 8 k of a lane are 8 different source pixels (160 bytes apart): the 36-tap windows of the halo pixels are copied
+//       to LDS once per tile and the operand is assembled from 2-byte LDS reads (6 per fragment: k is PERMUTED, k = 8 G + j <->
+//       source pixel 4 j + G, so that the four lane groups of a read sit on four different bank octets, and j = 6, 7 are never in
+//       the band).  The F side applies the same permutation through the addresses of its transposing reads.
+// One workgroup = 4 rows x 32 pixels x one 32-channel block (grid.y = channel blocks); wave w owns row w (2 strips x 9 dy x 2
+// channel sub-blocks = 36 MFMAs).  D puts 4 consecutive channels of one pixel in a lane: 8-byte stores.
+#include "corr_internal.h"
+#include "ocf_common.h"
+
+namespace ocf {
+namespace bm {
+constexpr int D = 4, N = 9, NK = 81;
+constexpr int TH = 4, TW = 32, HR = TH + 2 * D, HWP = TW + 2 * D;  // halo: 12 rows x 40 pixels
+constexpr int FP1 = 96;  // g1: bytes per staged halo pixel (64 of data).  A transposing read takes 4 CONSECUTIVE pixels: 24 dwords apart
+                         // = bank octets 0, 24, 16, 8
+constexpr int FP2 = 72;  // g2: the 4 pixels of a read are 4 apart (permuted k): 72 dwords apart = bank octets 0, 8, 16, 24
+constexpr int WT = TH * N;   // taps of the window kept per halo pixel in the g2 pass (4 tap rows)
+constexpr int GP = 80;       // bytes per halo pixel of that window (72 of data; 8-byte aligned chunks)
+}  // namespace bm
+
+typedef short s4v_ __attribute__((ext_vector_type(4)));
+typedef short s8v_ __attribute__((ext_vector_type(8)));
+struct __attribute__((packed, aligned(2))) U16B { u32x4 v; };
+struct __attribute__((packed, aligned(2))) U8B { u32x2 v; };
+
+// two transposing reads -> the 8 k values of this lane's channel; a0 / a1: this lane's chunk address for k 0-3 / 4-7
+__device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
+  typedef s4v_ __attribute__((address_space(3))) * lds_s4;
+  const s4v_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)a0);
+  const s4v_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)a1);
+  const s8v_ v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool G2>
+__global__ __launch_bounds__(256, G2 ? 2 : 3) void corr_bwd_mfma(T4 other, T4 g, T4 dst, T4 occ, T4 w2own, T4 gocc, int B, int C, int H,
+                                                                int W, int tiles_x, int tiles_y, int ablate) {
+  using namespace bm;
+#ifndef OCF_TUNING_BUILD
+  ablate = 0;  // phase-skipping switches of the tuning build (scripts/ablate_corr_bwd.sh)
+#endif
+  constexpr int FP = G2 ? FP2 : FP1;
+  __shared__ __attribute__((aligned(16))) char s_f[HR * HWP * FP];
+  __shared__ __attribute__((aligned(16))) char s_g[G2 ? HR * HWP * GP + 64 : 16];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (ablate & 16) {  // dispatch floor: the grid with its LDS allocation and nothing else
+    if (tid == 0) s_f[0] = 1;
+    return;
+  }
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, G = lane >> 4, q = i >> 2, p = i & 3;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi;
+  const int trem = tile - b * tpi;
+  const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+  const int cbase = (int)blockIdx.y * 32;
+  const int y = ty0 + w;
+  const float invC = 1.f / (float)C;
+
+  // Address arithmetic is what this kernel would otherwise be bound by (the first version spent ~2000 instructions per wave, most of
+  // them 64-bit index math, and took 21 us with every memory access and the MFMA loop switched off): all per-image offsets are 32-bit
+  // (host-checked), the batch base is scalar, and the staging loops give a lane a FIXED column and walk rows that are uniform.
+  const int osh = (int)other.sh, osw = (int)other.sw, gsh = (int)g.sh, gsw = (int)g.sw;
+  const char* obase = other.p + (long)b * other.sb * 2;
+  const char* gbase = g.p + (long)b * g.sb * 2;
+
+  // ---- g1: the G operands straight from global memory.  Lane (x = i, group G) of (strip s, dy): taps 8G - i + 0..7 of tap row dy
+  // of pixel (y, x): 16 bytes at a 2-byte aligned address.  Taps outside 0..8 are other data and are masked; in the workgroups that
+  // hold the first / last pixel of the tensor such a window can leave the tensor: there the address is clamped into it and the
+  // window shifted back.
+  u32x4 bfr[G2 ? 1 : 2][G2 ? 1 : N], msk = {0u, 0u, 0u, 0u};
+  int dlt[G2 ? 1 : 2][G2 ? 1 : N];  // edge workgroups: bytes each window was moved
+  const bool edge = !G2 && ((b == 0 && ty0 == 0 && tx0 == 0) || (b == B - 1 && ty0 + TH >= H && tx0 + TW >= W));
+  if (!G2) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int t0 = 8 * G + 2 * r - i, t1 = t0 + 1;
+      msk[r] = ((t0 >= 0 && t0 <= 8) ? 0xffffu : 0u) | ((t1 >= 0 && t1 <= 8) ? 0xffff0000u : 0u);
+    }
+    if (y >= H || G == 3 || (ablate & 1)) msk = u32x4{0u, 0u, 0u, 0u};
+    const int yc = y < H ? y : H - 1;
+    // (values are only loaded here; masks and the edge fix-up are applied after the staging loads below have been issued too)
+    if (!edge) {
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int x = tx0 + 16 * s + i;
+        const int xc = x < W ? x : W - 1;
+        const char* pix = gbase + ((ablate & 1) ? 0 : (yc * gsh + xc * gsw + (G < 3 ? 8 * G - i : 0)) * 2);
+#pragma unroll
+        for (int dyi = 0; dyi < N; dyi++) bfr[s][dyi] = ((const U16B*)(pix + dyi * (N * 2)))->v;
+      }
+    } else {
+      const char* lo = g.p;
+      const char* hi = g.p + (((long)(B - 1) * g.sb + (long)(H - 1) * g.sh + (long)(W - 1) * g.sw + NK) * 2 - 16);
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int x = tx0 + 16 * s + i;
+        const int xc = x < W ? x : W - 1;
+        const char* pix = gbase + (yc * gsh + xc * gsw + 8 * G - i) * 2;
+#pragma unroll
+        for (int dyi = 0; dyi < N; dyi++) {
+          const char* a = pix + dyi * (N * 2);
+          const char* ac = a < lo ? lo : (a > hi ? hi : a);
+          bfr[s][dyi] = ((const U16B*)ac)->v;
+          dlt[s][dyi] = (int)(ac - a);
+        }
+      }
+    }
+  }
+
+  // ---- g2: the tap windows of the halo pixels -> LDS.  Halo row hr (source row ty0 - 4 + hr) serves the targets w = 0..3 with tap
+  // row dyi = w + 8 - hr: the window keeps tap rows ws .. ws + 3, ws = clamp(8 - hr, 0, 5).  360 eight-byte chunks per halo row:
+  // chunk tid of every row (lane-fixed pixel and chunk, uniform row), then the remaining 104 per row spread over the workgroup.
+  constexpr int WCH = WT * 2 / 8, WRC = HWP * WCH;  // 9 chunks per pixel, 360 per row
+  constexpr int WNB = HR * (WRC - 256), WSB = (WNB + 255) / 256;
+  u32x2 va[G2 ? HR : 1], vb[G2 ? WSB : 1];
+  int ob[G2 ? WSB : 1];
+  const int wpA = tid / WCH, wcA = tid - wpA * WCH;
+  if (G2) {
+    constexpr int CH = WCH, RC = WRC;
+    const int pA = wpA, cA = wcA;
+    const int gxA = tx0 - D + pA;
+    const bool okA = gxA >= 0 && gxA < W;
+    const int offA = ((ablate & 1) ? 0 : (gxA < 0 ? 0 : (gxA >= W ? W - 1 : gxA)) * gsw * 2) + cA * 8;
+#pragma unroll
+    for (int r = 0; r < HR; r++) {
+      const int gy = ty0 - D + r;
+      const int ws = 8 - r < 0 ? 0 : (8 - r > 5 ? 5 : 8 - r);
+      const int gyc = (ablate & 1) ? 0 : (gy < 0 ? 0 : (gy >= H ? H - 1 : gy));
+      const u32x2 ld = ((const U8B*)(gbase + gyc * gsh * 2 + ws * (N * 2) + offA))->v;
+      const unsigned m = (okA && gy >= 0 && gy < H) ? 0xffffffffu : 0u;
+      va[r] = u32x2{ld[0] & m, ld[1] & m};
+    }
+    constexpr int NB = WNB, SB = WSB;
+#pragma unroll
+    for (int j = 0; j < SB; j++) {
+      const int it = tid + 256 * j;
+      const int itc = it < NB ? it : 0;
+      const int r = itc / (RC - 256), ch = 256 + itc - r * (RC - 256);
+      const int px = ch / CH, c = ch - px * CH;
+      const int gy = ty0 - D + r, gx = tx0 - D + px;
+      const int ws = 8 - r < 0 ? 0 : (8 - r > 5 ? 5 : 8 - r);
+      const int gyc = (ablate & 1) ? 0 : (gy < 0 ? 0 : (gy >= H ? H - 1 : gy)), gxc = (ablate & 1) ? 0 : (gx < 0 ? 0 : (gx >= W ? W - 1 : gx));
+      const u32x2 ld = ((const U8B*)(gbase + (gyc * gsh + gxc * gsw + ws * N) * 2 + c * 8))->v;
+      const unsigned m = (it < NB && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xffffffffu : 0u;
+      vb[j] = u32x2{ld[0] & m, ld[1] & m};
+      ob[j] = it < NB ? (r * HWP + px) * GP + c * 8 : -1;
+    }
+  }
+
+  // ---- the halo tile of the other operand for this channel block: [halo row][pixel][32 ch] in 8-byte chunks, 320 per halo row:
+  // chunk tid of every row (lane-fixed pixel and channels, uniform row), then chunks 256..319: wave w takes rows w, w + 4, w + 8.
+  {
+    const int u8 = tid & 7, c0 = cbase + 4 * u8;
+    const int c0c = c0 < C ? c0 : 0;
+    const int pA = tid >> 3, pB = 32 + ((tid & 63) >> 3);
+    const int gxA = tx0 - D + pA, gxB = tx0 - D + pB;
+    const bool okA = gxA >= 0 && gxA < W && c0 < C, okB = gxB >= 0 && gxB < W && c0 < C;
+    const int gxAc = (ablate & 2) ? 0 : (gxA < 0 ? 0 : (gxA >= W ? W - 1 : gxA)), gxBc = (ablate & 2) ? 0 : (gxB >= W ? W - 1 : gxB);
+    const int offA = (gxAc * osw + c0c) * 2, offB = (gxBc * osw + c0c) * 2;
+    const bool use_occ = !G2 && occ.p;
+    const float* occb = (const float*)occ.p + (long)b * occ.sb;
+    const int csh = (int)occ.sh;
+    u32x2 sv[HR + 3];
+    float so[HR + 3];
+#pragma unroll
+    for (int r = 0; r < HR + 3; r++) {
+      const int hr = r < HR ? r : w + 4 * (r - HR);
+      const int gy = ty0 - D + hr;
+      const int gyc = (ablate & 2) ? 0 : (gy < 0 ? 0 : (gy >= H ? H - 1 : gy));
+      const u32x2 ld = *(const u32x2*)(obase + gyc * osh * 2 + (r < HR ? offA : offB));
+      const unsigned m = ((r < HR ? okA : okB) && gy >= 0 && gy < H) ? 0xffffffffu : 0u;
+      sv[r] = u32x2{ld[0] & m, ld[1] & m};
+      so[r] = 1.f;
+      if (use_occ) so[r] = occb[gyc * csh + (r < HR ? gxAc : gxBc)];
+    }
+    if (!G2 && edge) {
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int dyi = 0; dyi < N; dyi++) {
+          unsigned __int128 x128 = __builtin_bit_cast(unsigned __int128, bfr[s][dyi]);
+          const int dl = dlt[s][dyi];
+          if (dl > 0) x128 = dl >= 16 ? 0 : x128 << (8 * dl);
+          if (dl < 0) x128 = dl <= -16 ? 0 : x128 >> (-8 * dl);
+          bfr[s][dyi] = __builtin_bit_cast(u32x4, x128);
+        }
+    }
+    if (G2) {  // (stored only now: every global load of the tile is in flight before the first wait)
+#pragma unroll
+      for (int r = 0; r < HR; r++) *(u32x2*)(s_g + r * (HWP * GP) + wpA * GP + wcA * 8) = va[r];
+#pragma unroll
+      for (int j = 0; j < WSB; j++)
+        if (ob[j] >= 0) *(u32x2*)(s_g + ob[j]) = vb[j];
+    }
+#pragma unroll
+    for (int r = 0; r < HR + 3; r++) {
+      u32x2 v = sv[r];
+      if (use_occ) {  // rounded like the materialised product w2 * occ
+        const float o = so[r];
+        const float f0 = __builtin_bit_cast(float, v[0] << 16) * o, f1 = __builtin_bit_cast(float, v[0] & 0xffff0000u) * o;
+        const float f2 = __builtin_bit_cast(float, v[1] << 16) * o, f3 = __builtin_bit_cast(float, v[1] & 0xffff0000u) * o;
+        const bf16x2 lo2 = {(bf16)f0, (bf16)f1}, hi2 = {(bf16)f2, (bf16)f3};
+        v = u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
+      }
+      const int hr = r < HR ? r : w + 4 * (r - HR);
+      *(u32x2*)(s_f + (hr * HWP + (r < HR ? pA : pB)) * FP + u8 * 8) = v;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) acc[s][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (ablate & 4) {
+  } else if (!G2) {
+#pragma unroll
+    for (int dyi = 0; dyi < N; dyi++) {
+      const char* frow = s_f + (w + dyi) * (HWP * FP) + p * 8;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        // k = 8G + 4h + q <-> halo pixel 16 s + k (clamped: k >= 24 is outside the band and, for s = 1, partly outside the halo)
+        const int h0 = 16 * s + 8 * G + q, h1 = h0 + 4;
+        const int p0 = h0 < HWP ? h0 : HWP - 1, p1 = h1 < HWP ? h1 : HWP - 1;
+        const bool xin = tx0 + 16 * s + i < W;
+        const bf16x8 bq = __builtin_bit_cast(bf16x8, bfr[s][dyi] & (xin ? msk : u32x4{0u, 0u, 0u, 0u}));
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+          const bf16x8 a = tr_pair(frow + p0 * FP + nb * 32, frow + p1 * FP + nb * 32);
+          acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc[s][nb], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    // element j of the lane: source pixel 4 j + G of the strip's 32, tap (x - x') + 4 = i - 4 j - G + 8
+    unsigned gm[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int t0 = i - 8 * r - G + 8, t1 = t0 - 4;
+      gm[r] = ((t0 >= 0 && t0 <= 8) ? 0xffffu : 0u) | ((t1 >= 0 && t1 <= 8) ? 0xffff0000u : 0u);
+    }
+    const char* glane = s_g + G * GP + (i - G + 8) * 2;
+#pragma unroll
+    for (int dyi = 0; dyi < N; dyi++) {
+      const int hr = w + 8 - dyi;  // source row y - dy
+      const int ws = dyi - w < 0 ? 0 : (dyi - w > 5 ? 5 : dyi - w);  // = clamp(8 - hr, 0, 5)
+      const char* grow = glane + hr * (HWP * GP) + (dyi - ws) * (N * 2);
+      const char* frow = s_f + hr * (HWP * FP) + p * 8;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const char* gs = grow + 16 * s * GP;
+        u32x4 bv;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const unsigned e0 = *(const unsigned short*)(gs + (2 * r) * (4 * GP - 8));
+          const unsigned e1 = *(const unsigned short*)(gs + (2 * r + 1) * (4 * GP - 8));
+          bv[r] = (e0 | (e1 << 16)) & gm[r];
+        }
+        bv[3] = 0u;
+        const bf16x8 bq = __builtin_bit_cast(bf16x8, bv);
+        const int h0 = 16 * s + 4 * q + G, h1 = h0 + 16;
+        const int p1 = h1 < HWP ? h1 : HWP - 1;
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+          const bf16x8 a = tr_pair(frow + h0 * FP + nb * 32, frow + p1 * FP + nb * 32);
+          acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc[s][nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane (i, G) holds channels cbase + 16 nb + 4 G + 0..3 of pixel (y, tx0 + 16 s + i)
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int x = tx0 + 16 * s + i;
+    const bool inimg = y < H && x < W;
+    float o = 1.f, part = 0.f;
+    if (G2 && occ.p && inimg) o = ((const float*)occ.p)[(long)b * occ.sb + y * (int)occ.sh + x * (int)occ.sw];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+      const int c0 = cbase + 16 * nb + 4 * G;
+      const bool live = inimg && c0 < C;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = acc[s][nb][r] * invC;
+      if (G2 && occ.p) {
+        if (gocc.p && live) {
+          // the reference chain rounds the gradient w.r.t. (w2*occ) to the feature dtype before this product
+          const u32x2 wv = *(const u32x2*)(w2own.p + (long)b * w2own.sb * 2 + (y * (int)w2own.sh + x * (int)w2own.sw + c0) * 2);
+          part = __builtin_fmaf((float)(bf16)v[0], __builtin_bit_cast(float, wv[0] << 16), part);
+          part = __builtin_fmaf((float)(bf16)v[1], __builtin_bit_cast(float, wv[0] & 0xffff0000u), part);
+          part = __builtin_fmaf((float)(bf16)v[2], __builtin_bit_cast(float, wv[1] << 16), part);
+          part = __builtin_fmaf((float)(bf16)v[3], __builtin_bit_cast(float, wv[1] & 0xffff0000u), part);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = (float)(bf16)v[r] * o;
+      }
+      if (live && !(ablate & 8)) {
+        const bf16x2 lo2 = {(bf16)v[0], (bf16)v[1]}, hi2 = {(bf16)v[2], (bf16)v[3]};
+        *(u32x2*)(dst.p + (long)b * dst.sb * 2 + (y * (int)dst.sh + x * (int)dst.sw + c0) * 2) =
+            u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
+      }
+    }
+    if (G2 && occ.p && gocc.p) {  // one fp32 atomic per pixel and channel block (the four lane groups reduced by shuffle)
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      if (inimg && G == 0) atomicAdd((float*)gocc.p + (long)b * gocc.sb + (y * (int)gocc.sh + x * (int)gocc.sw), part);
+    }
+  }
+}
+
+static int g_corr_bwd_policy = 0;  // ocf_corr_bwd_select: 0 = automatic, 1 = vector kernel only, 2 = matrix-core kernel whenever eligible
+
+void corr_bwd_set_policy(int policy) { g_corr_bwd_policy = policy; }
+
+static bool px8(const ocf_tensor4* t) {  // channel-contiguous, pixels and rows 8-byte aligned, forward strides
+  return t->sc == 1 && t->sw > 0 && t->sh > 0 && t->sb > 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sb % 4 == 0 && (uintptr_t)t->data % 8 == 0;
+}
+
+bool corr_bwd_mfma_eligible(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* g, const ocf_tensor4* g1, const ocf_tensor4* g2,
+                            int B, int C, int H, int W, int d) {
+  if (g_corr_bwd_policy == 1 || d != bm::D || C % 4 != 0) return false;
+  if (!px8(f1) || !px8(w2) || (g1 && !px8(g1)) || (g2 && !px8(g2))) return false;
+  if (!(g->sc == 1 && g->sw >= bm::NK && g->sh > 0 && g->sb > 0)) return false;
+  // byte offsets inside one image are 32-bit in the kernel
+  auto span = [&](const ocf_tensor4* t, long c) { return ((long)t->sh * H + (long)t->sw * W + c) * 2; };
+  if (span(f1, C) >= (1L << 31) || span(w2, C) >= (1L << 31) || span(g, bm::NK) >= (1L << 31)) return false;
+  if ((g1 && span(g1, C) >= (1L << 31)) || (g2 && span(g2, C) >= (1L << 31))) return false;
+  return true;  // measured faster than the vector kernel at every pyramid level of the benchmark (profiles/r2_e_kbench.txt)
+}
+
+int corr_bwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* g, const ocf_tensor4* g1, const ocf_tensor4* g2,
+                       int B, int C, int H, int W, hipStream_t st, const ocf_tensor4* occ, const ocf_tensor4* gocc) {
+  using namespace bm;
+  const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
+  const dim3 grid((unsigned)(B * tx * ty), (unsigned)((C + 31) / 32)), block(256);
+#ifdef OCF_TUNING_BUILD
+  const int ablate = getenv("OCF_ABLATE_BWD") ? atoi(getenv("OCF_ABLATE_BWD")) : 0;
+#else
+  constexpr int ablate = 0;
+#endif
+  LaunchProf lp;
+  if (g1) lp.launch(!g2, corr_bwd_mfma<false>, grid, block, 0, st, mk(w2), mk(g), mk(g1), mk(occ), mk((const ocf_tensor4*)nullptr),
+                    mk((const ocf_tensor4*)nullptr), B, C, H, W, tx, ty, ablate);
+  if (g2) lp.launch(true, corr_bwd_mfma<true>, grid, block, 0, st, mk(f1), mk(g), mk(g2), mk(occ), mk(w2), mk(gocc), B, C, H, W, tx, ty, ablate);
+  return launch_status();
+}
+
+}  // namespace ocf
+
+extern "C" int ocf_corr_bwd_select(int policy) {
+  if (policy < 0 || policy > 2) return OCF_EINVAL;
+  ocf::corr_bwd_set_policy(policy);
+  return OCF_OK;
+}

@@ -16,4 +16,10 @@ int corr_rows_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_te
                       int d);
 int corr_fwd_bf16_rows(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* occ, const ocf_tensor4* out, int B, int C, int H,
                        int W, hipStream_t st);
+// matrix-core backward (corr_bwd_mfma.hip): bf16, d = 4, channel-contiguous operands with 8-byte aligned pixels
+bool corr_bwd_mfma_eligible(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* g, const ocf_tensor4* g1, const ocf_tensor4* g2,
+                            int B, int C, int H, int W, int d);
+int corr_bwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* g, const ocf_tensor4* g1, const ocf_tensor4* g2,
+                       int B, int C, int H, int W, hipStream_t st, const ocf_tensor4* occ, const ocf_tensor4* gocc);
+void corr_bwd_set_policy(int policy);
 }  // namespace ocf

@@ -591,6 +591,50 @@ def test_corr_backward_odd_shapes(ops, shape, d, dtype, with_occ):
         np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=tol * 5, atol=tol * scale)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 21, 45), (1, 64, 12, 40), (1, 196, 7, 16), (1, 100, 13, 17), (1, 64, 1, 50), (1, 16, 50, 1),
+                                   (3, 32, 17, 16), (2, 32, 4, 70), (1, 36, 9, 33)])
+@pytest.mark.parametrize("with_occ", [False, True])
+@pytest.mark.parametrize("sliced", [False, True])
+def test_corr_backward_matrix_core_kernel(ops, shape, with_occ, sliced):
+    """the band-GEMM backward (corr_bwd_mfma.hip), forced with ocf_corr_bwd_select(2) at shapes the automatic policy leaves to the vector
+    kernel: edge tiles in both directions, 1-pixel-wide / 1-pixel-high maps, channel counts that are not a multiple of the 32-channel
+    block (196, 100, 36), the gradient arriving as a 2-byte aligned channel slice (first and last pixels of the tensor: the clamped
+    and shifted operand windows), occlusion (d/docc by-product).  Against fp32 autograd of the oracle, and against the vector kernel
+    (same products, different summation order: within one bf16 rounding of the gradient scale)."""
+    from ocflow_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(sum(shape) * 5 + with_occ)
+    B, C_, H, W = shape
+    f1 = torch.randn(shape, generator=gen).bfloat16()
+    f2 = torch.randn(shape, generator=gen).bfloat16()
+    occ = torch.rand((B, 1, H, W), generator=gen) if with_occ else None
+    E = 36 if sliced else 0
+    extra = torch.randn((B, E, H, W), generator=gen).bfloat16()
+    cot = torch.randn((B, 81 + E, H, W), generator=gen).bfloat16()
+    a, b = f1.float().requires_grad_(), f2.float().requires_grad_()
+    o = occ.clone().requires_grad_() if with_occ else None
+    ref = torch.cat([O.compute_cost_volume(a, b * o if with_occ else b, 4), extra.float()], 1)
+    want = torch.autograd.grad(ref, (a, b, o) if with_occ else (a, b), cot.float())
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+    def run(policy):
+        assert lib.ocf_corr_bwd_select(policy) == 0
+        try:
+            x, y = cl(f1).requires_grad_(), cl(f2).requires_grad_()
+            oc = occ.to(DEV).requires_grad_() if with_occ else None
+            out = torch.cat([ops.corr_warp(x, y, None, oc, 4), cl(extra)], 1)
+            return torch.autograd.grad(out, (x, y, oc) if with_occ else (x, y), cl(cot))
+        finally:
+            lib.ocf_corr_bwd_select(0)
+
+    got, vec = run(2), run(1)
+    for g_, v_, w_ in zip(got, vec, want):
+        scale = float(w_.abs().max()) + 1e-12
+        np.testing.assert_allclose(g_.float().cpu().numpy(), w_.numpy(), rtol=0.1, atol=2e-2 * scale)
+        np.testing.assert_allclose(g_.float().cpu().numpy(), v_.float().cpu().numpy(), rtol=0, atol=1e-2 * scale)
+    assert lib.ocf_corr_bwd_select(3) != 0
+
+
 def test_psnr_golden(ops, golden):
     """ops.psnr (one reduction kernel over the batch) against the reference's per-image numpy psnr, incl. the identical-pair case
     (100) and a strided view of a [B,6,H,W] batch at a Sintel-sized frame against the oracle"""

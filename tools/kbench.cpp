@@ -6,6 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <cmath>
+#include <cstring>
+#include <algorithm>
 #include "ocflow_hip.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -73,6 +76,37 @@ int main(int argc, char** argv) {
     float c = time_us([&] { ocf_corr_fwd(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, 1.25f, 0, dt, st); }, st);
     float d = time_us([&] { ocf_warp_fwd(&t2, &tf, &tg1, B, C, H, W, 1.25f, 0, dt, st); }, st);
     ocf_tensor4 tgo = mkt(gflow, B, 1, H, W, false);  // d/docc written into the gflow scratch buffer
+    // corr backward: vector kernel vs matrix-core kernel (max abs difference of the two g1 / g2 / d occ results, relative to the max)
+    {
+      ocf_tensor4 tgo1 = mkt(gflow, B, 1, H, W, false);
+      const size_t ng = np * C;
+      std::vector<unsigned short> r1(ng), r2(ng), m1(ng), m2(ng);
+      std::vector<float> ro(np), mo(np);
+      ocf_corr_bwd_select(1);
+      float v1 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, nullptr, B, C, H, W, 4, dt, st); }, st, 50);
+      float v2 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, nullptr, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
+      float vo = time_us([&] { ocf_corr_occ_bwd(&t1, &t2, &tc, &to, &tg1, &tg2, &tgo1, B, C, H, W, 4, dt, st); }, st, 50);
+      CK(hipStreamSynchronize(st));
+      CK(hipMemcpy(r1.data(), g1, ng * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(r2.data(), g2, ng * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(ro.data(), gflow, np * 4, hipMemcpyDeviceToHost));
+      ocf_corr_bwd_select(2);
+      float w1 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, nullptr, B, C, H, W, 4, dt, st); }, st, 50);
+      float w2t = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, nullptr, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
+      float wo = time_us([&] { ocf_corr_occ_bwd(&t1, &t2, &tc, &to, &tg1, &tg2, &tgo1, B, C, H, W, 4, dt, st); }, st, 50);
+      CK(hipStreamSynchronize(st));
+      CK(hipMemcpy(m1.data(), g1, ng * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(m2.data(), g2, ng * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(mo.data(), gflow, np * 4, hipMemcpyDeviceToHost));
+      ocf_corr_bwd_select(0);
+      auto bf = [](unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+      double d1 = 0, d2 = 0, dm = 0, mx1 = 0, mx2 = 0, mxo = 0;
+      for (size_t i = 0; i < ng; i++) {
+        d1 = std::max(d1, (double)fabsf(bf(r1[i]) - bf(m1[i]))); mx1 = std::max(mx1, (double)fabsf(bf(r1[i])));
+        d2 = std::max(d2, (double)fabsf(bf(r2[i]) - bf(m2[i]))); mx2 = std::max(mx2, (double)fabsf(bf(r2[i])));
+      }
+      for (size_t i = 0; i < np; i++) { dm = std::max(dm, (double)fabsf(ro[i] - mo[i])); mxo = std::max(mxo, (double)fabsf(ro[i])); }
+      printf("  corr_bwd: vector g1 %.1f g2 %.1f +occ(both) %.1f us | mfma g1 %.1f g2 %.1f +occ(both) %.1f us | max diff / max: g1(occ) %.2e g2(occ) %.2e docc %.2e\n",
+             v1, v2, vo, w1, w2t, wo, d1 / (mx1 + 1e-30), d2 / (mx2 + 1e-30), dm / (mxo + 1e-30));
+    }
     float e = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
     float eg1 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, nullptr, B, C, H, W, 4, dt, st); }, st, 50);
     float eg2 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, nullptr, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
