@@ -98,6 +98,12 @@ def load():
             fn.restype = C.c_int
         lib.ocf_status_string.argtypes = [C.c_int]
         lib.ocf_status_string.restype = C.c_char_p
+        # kernel-choice knobs for A/B runs of a whole model (same results; see the *_select entries of include/ocflow_hip.h)
+        for env, fn in (("OCFLOW_WARP_BWD_POLICY", lib.ocf_warp_bwd_select), ("OCFLOW_CORR_BWD_POLICY", lib.ocf_corr_bwd_select),
+                        ("OCFLOW_RANGE_MAP_POLICY", lib.ocf_range_map_select), ("OCFLOW_WGRAD_POLICY", lib.ocf_conv3x3_wgrad_select)):
+            if os.environ.get(env):
+                if fn(int(os.environ[env])) != OCF_OK:
+                    raise RuntimeError(f"ocflow_amd: {env}={os.environ[env]} is not a valid policy")
         _lib = lib
     return _lib
 
