@@ -5,10 +5,53 @@ The reference writes either `F.leaky_relu(self.convN(x), 0.1)` or `nn.Sequential
 the convolution runs without its bias and `ops.bias_leaky_relu` applies bias + activation in place on its output."""
 import os
 
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ocflow_amd import ops
+
+CHANNEL_ALIGN = 32  # channels; see cat_aligned
+
+
+def cat_aligned(parts, dim: int = 1):
+    """torch.cat(parts, 1) for a tensor that feeds convolutions (the decoder inputs: cost volume + features + flow ...; reference
+    flow_occ_net.py:153-176, flow_net.py:104-121).  Those concatenations have 117, 66, 149, 34 ... channels, and on 2-byte-aligned pixels
+    the framework's bf16 channels_last convolutions fall to slow solvers: 117->128 at 8x109x256 takes 285 / 475 / 256 us (forward /
+    input gradient / weight gradient) against 112 / 123 / 144 us at 120 channels (profiles/r2_f_pad_channels.txt) -- 1.6 ms of the
+    16.6 ms step over the ten such layers.  In the 16-bit channels_last configuration the concatenation is therefore rounded up to a
+    multiple of 32 channels with ZERO channels at the end (8 is enough for the speed; 32 keeps every implicit-GEMM tile of the
+    library whole -- a find-mode search over the multiple-of-8 shapes ran into a faulting vector-1 input-gradient kernel of the
+    library); `_conv_nobias` pads the weight's input channels with zeros to match, so
+    every output and every parameter gradient is the same sum with zero terms added.  Parameters keep the reference's shapes.
+    OCFLOW_UNPADDED_CAT=1 switches it off (A/B runs)."""
+    x0 = parts[0]
+    if dim == 1 and x0.is_cuda and x0.dim() == 4 and x0.dtype in (torch.bfloat16, torch.float16) and not _unpadded_cat():
+        pad = -sum(int(t.shape[1]) for t in parts) % CHANNEL_ALIGN
+        if pad:
+            cl = x0.is_contiguous(memory_format=torch.channels_last)
+            if cl:  # (torch.zeros takes no memory_format: a channels_last view of an NHWC allocation)
+                z = x0.new_zeros((x0.shape[0], x0.shape[2], x0.shape[3], pad)).permute(0, 3, 1, 2)
+            else:
+                z = x0.new_zeros((x0.shape[0], pad, x0.shape[2], x0.shape[3]))
+            parts = list(parts) + [z]
+    return torch.cat(list(parts), dim)
+
+
+def _unpadded_cat() -> bool:
+    return os.environ.get("OCFLOW_UNPADDED_CAT", "0") == "1"
+
+
+def _match_in_channels(weight, cin: int, dim: int = 1):
+    """the weight with zero input channels appended up to `cin` (the input came from `cat_aligned`); autograd slices the gradient back"""
+    extra = cin - weight.shape[dim]
+    if extra == 0:
+        return weight
+    if extra < 0 or extra >= CHANNEL_ALIGN:
+        raise RuntimeError(f"convolution input has {cin} channels, the weight expects {weight.shape[dim]}")
+    pad = [0, 0] * (weight.dim() - 1 - dim) + [0, extra]
+    w = F.pad(weight, pad)
+    return w.contiguous(memory_format=torch.channels_last) if weight.is_contiguous(memory_format=torch.channels_last) else w
 
 
 def _conv_nobias(conv: nn.Conv2d, x):
@@ -16,9 +59,10 @@ def _conv_nobias(conv: nn.Conv2d, x):
     gradient from the hand-written MFMA kernel (ops.conv3x3: ocf_conv3x3_wgrad); forward and input gradient stay MIOpen's.
     Opt-in (OCFLOW_NATIVE_WGRAD=1): the first version of that kernel is parity-green and level with MIOpen's kernel + helper launches
     on the large layers (profiles/r2_*_wgrad.txt) but not yet a net win for the whole step."""
-    if _native_wgrad() and ops.conv3x3_wgrad_eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
-        return ops.conv3x3(x, conv.weight, conv.dilation[0])
-    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    w = _match_in_channels(conv.weight, x.shape[1]) if conv.groups == 1 else conv.weight
+    if _native_wgrad() and ops.conv3x3_wgrad_eligible(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+        return ops.conv3x3(x, w, conv.dilation[0])
+    return F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 def _native_wgrad() -> bool:
@@ -28,8 +72,15 @@ def _native_wgrad() -> bool:
 def conv_lrelu(conv: nn.Conv2d, x, negative_slope: float = 0.1):
     # OCFLOW_UNFUSED_EPILOGUE=1: the reference's own op chain (A/B switch for measurements and bisecting, not a fallback)
     if conv.bias is None or conv.padding_mode != "zeros" or _unfused():
-        return F.leaky_relu(conv(x), negative_slope)
+        return F.leaky_relu(_conv_module(conv, x), negative_slope)
     return ops.bias_leaky_relu(_conv_nobias(conv, x), conv.bias, negative_slope)
+
+
+def _conv_module(conv: nn.Conv2d, x):
+    """conv(x) with the module's own bias / padding mode, for an input that may carry the alignment channels of `cat_aligned`"""
+    if x.shape[1] == conv.weight.shape[1] or conv.groups != 1:
+        return conv(x)
+    return conv._conv_forward(x, _match_in_channels(conv.weight, x.shape[1]), conv.bias)
 
 
 def _unfused() -> bool:
@@ -39,7 +90,7 @@ def _unfused() -> bool:
 def conv_bias(conv: nn.Conv2d, x):
     """nn.Conv2d(bias=True) without activation (prediction layers): bias-free convolution + in-place bias kernel"""
     if conv.bias is None or conv.padding_mode != "zeros" or _unfused():
-        return conv(x)
+        return _conv_module(conv, x)
     return ops.bias_add(_conv_nobias(conv, x), conv.bias)
 
 

@@ -6,7 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ocflow_amd import ops
-from ._epilogue import conv_bias, conv_lrelu, deconv_bias
+from ._epilogue import cat_aligned, conv_bias, conv_lrelu, deconv_bias
 from .context_net import ContextNetwork
 from .feature_pyramid_net import FeaturePyramidNet
 
@@ -72,15 +72,15 @@ class FlowNet(nn.Module):
             f1, f2 = pyr1[i], pyr2[i]
             if flow_up is None:
                 corr = ops.compute_cost_volume(f1, f2)
-                x = torch.cat([corr.to(f1.dtype), f1], dim=1)
+                x = cat_aligned([corr.to(f1.dtype), f1])
             else:
                 # warp(feat2, flow_up * 20 / 2^level) fused into the correlation's window gather
                 corr = ops.corr_warp(f1, f2, flow_up, None, 4, 20.0 / (2.0 ** level), False)
-                x = torch.cat([corr.to(f1.dtype), f1, flow_up.to(f1.dtype), feat_up.to(f1.dtype)], dim=1)
+                x = cat_aligned([corr.to(f1.dtype), f1, flow_up.to(f1.dtype), feat_up.to(f1.dtype)])
             est = self.opticalflow_estimators[i]
             if level == 2:
                 flow, feat = est(x)
             else:
                 flow, flow_up, feat_up = est(x, pyr1[i + 1].size(2), pyr1[i + 1].size(3))
-        refined = flow + self.context_network(torch.cat([feat, flow], dim=1))
+        refined = flow + self.context_network(cat_aligned([feat, flow.to(feat.dtype)]))
         return self.upsample(refined)  # no *20: flow_net.py:127-128

@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ocflow_amd import ops
-from ._epilogue import conv_bias, conv_lrelu, deconv_bias
+from ._epilogue import cat_aligned, conv_bias, conv_lrelu, deconv_bias
 from .context_net import ContextNetwork
 from .cost_volume_net import CostVolumeLayer
 from .feature_pyramid_net import FeaturePyramidNet
@@ -75,10 +75,10 @@ class FlowOccNet(nn.Module):
             size = () if last else (pyr1[i + 1].size(2), pyr1[i + 1].size(3))
             if flow_up is None:
                 warped2 = f2
-                occ_in = torch.cat([f1, warped2], dim=1)
+                occ_in = cat_aligned([f1, warped2])
             else:
                 warped2 = ops.warp(f2, flow_up, False, flow_scale=20.0 / (2.0 ** level))
-                occ_in = torch.cat([f1, warped2.to(f1.dtype), occ_feat_up.to(f1.dtype), occ_up.to(f1.dtype)], dim=1)
+                occ_in = cat_aligned([f1, warped2.to(f1.dtype), occ_feat_up.to(f1.dtype), occ_up.to(f1.dtype)])
             if last:
                 occ = self.occlusion_estimators[i](occ_in)
             else:
@@ -88,10 +88,10 @@ class FlowOccNet(nn.Module):
             parts = [corr.to(f1.dtype), f1]
             if flow_up is not None:
                 parts += [flow_up.to(f1.dtype), flow_feat_up.to(f1.dtype)]
-            x = torch.cat(parts, dim=1)
+            x = cat_aligned(parts)
             if last:
                 flow, flow_feat = self.opticalflow_estimators[i](x)
             else:
                 flow, flow_up, flow_feat_up = self.opticalflow_estimators[i](x, *size)
-        refined = flow + self.context_network(torch.cat([flow_feat, flow], dim=1))
+        refined = flow + self.context_network(cat_aligned([flow_feat, flow.to(flow_feat.dtype)]))
         return self.upsample1(refined), self.upsample2(occ)

@@ -142,6 +142,50 @@ def test_bf16_autocast_step_runs():
     assert float((f32 - fbf.float()).abs().mean()) < 0.25 * float(f32.abs().mean()) + 0.05
 
 
+@pytest.mark.parametrize("model_name", ["flowoccnet", "flownet"])
+def test_aligned_concatenation_is_the_same_network(monkeypatch, model_name):
+    """_epilogue.cat_aligned: in the bf16 channels_last configuration the decoder inputs (117, 66, 149, 34 ... channels) are
+    concatenated with zero channels up to a multiple of 32 and the consuming convolution gets zero input channels appended to its
+    weight.  Same network: outputs and EVERY parameter gradient (reference shapes) agree with the unpadded run (OCFLOW_UNPADDED_CAT=1)
+    to bf16 rounding of a different summation order; on fp32 inputs the helper is plain torch.cat."""
+    from ocflow_amd.models.networks._epilogue import cat_aligned
+    a, b = torch.randn((1, 5, 4, 6), device=DEV), torch.randn((1, 4, 4, 6), device=DEV)
+    assert torch.equal(cat_aligned([a, b]), torch.cat([a, b], 1))
+    padded = cat_aligned([a.bfloat16().contiguous(memory_format=torch.channels_last), b.bfloat16().contiguous(memory_format=torch.channels_last)])
+    assert padded.shape == (1, 32, 4, 6) and padded.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(padded[:, :9], torch.cat([a, b], 1).bfloat16()) and float(padded[:, 9:].abs().max()) == 0.0
+
+    def run(unpadded):
+        monkeypatch.setenv("OCFLOW_UNPADDED_CAT", "1" if unpadded else "0")
+        torch.manual_seed(3)
+        if model_name == "flowoccnet":
+            from ocflow_amd.models.flow_occ_model import FlowOccModel
+            m = FlowOccModel({"learning_rate": 1e-4, "model": "flowoccnet"})
+        else:
+            from ocflow_amd.models.flow_model import FlowModel
+            m = FlowModel({"learning_rate": 1e-4, "model": "flownet"})
+        m = m.to(DEV).to(memory_format=torch.channels_last)
+        gen = torch.Generator().manual_seed(5)
+        x = (torch.rand((2, 6, 128, 192), generator=gen) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+        gt_flow = torch.randn((2, 2, 128, 192), generator=gen).to(DEV)
+        gt_occ = (torch.rand((2, 1, 128, 192), generator=gen) < 0.3).float().to(DEV)
+        batch = (x, gt_flow, gt_occ) if model_name == "flowoccnet" else (x, gt_flow)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = m.training_step(batch, 0)
+        loss.backward()
+        return float(loss), {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+
+    (l0, g0), (l1, g1) = run(False), run(True)
+    assert abs(l0 - l1) <= 2e-2 * abs(l1) + 1e-3
+    assert g0.keys() == g1.keys()
+    worst = 0.0
+    for k in g0:
+        assert g0[k].shape == g1[k].shape
+        denom = float(g1[k].abs().max()) + 1e-6
+        worst = max(worst, float((g0[k] - g1[k]).abs().max()) / denom)
+    assert worst < 0.25, worst  # bf16 network, two different solver choices: a few per cent; a wrong channel mapping gives O(1)
+
+
 def _stepper(fused, graph, amp=None, batch=None, steps=6):
     """train `steps` steps of the supervised FlowOccModel step on one fixed batch; returns (losses, parameters)"""
     from ocflow_amd.models.flow_occ_model import FlowOccModel
