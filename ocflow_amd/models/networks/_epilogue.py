@@ -24,7 +24,9 @@ def cat_aligned(parts, dim: int = 1):
     library whole -- a find-mode search over the multiple-of-8 shapes ran into a faulting vector-1 input-gradient kernel of the
     library); `_conv_nobias` pads the weight's input channels with zeros to match, so
     every output and every parameter gradient is the same sum with zero terms added.  Parameters keep the reference's shapes.
-    OCFLOW_UNPADDED_CAT=1 switches it off (A/B runs)."""
+    OCFLOW_UNPADDED_CAT=1 switches it off (A/B runs).  Used by FlowNet / FlowOccNet (the benchmark models).  The PWC-style nets
+    (FlowNetCV, FlowOccNetCV) keep plain torch.cat: with their dense blocks padded, the library's heuristic solver choice for the new
+    shapes ended in a GPU memory fault inside a library kernel at 8x384x512 (no find-db entry exists for them); not pursued."""
     x0 = parts[0]
     if dim == 1 and x0.is_cuda and x0.dim() == 4 and x0.dtype in (torch.bfloat16, torch.float16) and not _unpadded_cat():
         pad = -sum(int(t.shape[1]) for t in parts) % CHANNEL_ALIGN
@@ -96,10 +98,11 @@ def conv_bias(conv: nn.Conv2d, x):
 
 def deconv_bias(deconv: nn.ConvTranspose2d, x, output_size=None):
     """nn.ConvTranspose2d(bias=True)(x, output_size=...) as a bias-free transposed convolution + in-place bias kernel"""
-    if deconv.bias is None or deconv.padding_mode != "zeros" or _unfused():
-        return deconv(x, output_size=output_size)
+    w = _match_in_channels(deconv.weight, x.shape[1], dim=0) if deconv.groups == 1 else deconv.weight  # (weight is [in, out, kh, kw])
     output_padding = deconv._output_padding(x, output_size, deconv.stride, deconv.padding, deconv.kernel_size, 2, deconv.dilation)
-    y = F.conv_transpose2d(x, deconv.weight, None, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
+    if deconv.bias is None or deconv.padding_mode != "zeros" or _unfused():
+        return F.conv_transpose2d(x, w, deconv.bias, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
+    y = F.conv_transpose2d(x, w, None, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
     return ops.bias_add(y, deconv.bias)
 
 
