@@ -251,6 +251,24 @@ int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tens
 int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky, int64_t gw_skx,
                       int B, int Ci, int Co, int H, int W, int dilation, int dtype, void* stream);
 
+/* ---- BatchNorm2d (batch statistics) + LeakyReLU of the feature-pyramid encoder
+ * replaces: nn.BatchNorm2d + nn.LeakyReLU(0.1) of the reference's `conv_bn_relu` blocks (models/networks/feature_pyramid_net.py:5-95), i.e.
+ * torch.batch_norm(training) + leaky_relu and their autograd.  Dense channels_last x / y / gy / gx of `dtype` (OCF_F32 / OCF_BF16), C a
+ * multiple of 4 (OCF_EUNSUPPORTED otherwise: use the framework operators); gamma, beta, statistics and parameter gradients fp32.
+ *   training != 0: batch statistics; save_mean / save_invstd [C] receive mean and 1/sqrt(var + eps) (biased variance) for backward,
+ *                  running_mean / running_var (optional) are updated with `momentum` (unbiased variance, as torch), *num_batches_tracked
+ *                  (optional, int64) is incremented.  `workspace`: ocf_bn_act_workspace_bytes(C) bytes of scratch (any contents); one
+ *                  workspace serves consecutive launches on one stream.
+ *   training == 0: y = lrelu((x - running_mean) / sqrt(running_var + eps) * gamma + beta); no statistics pass, no workspace.
+ * backward (training-mode forward only): gx, dgamma [C], dbeta [C] (overwritten). */
+int ocf_bn_act_workspace_bytes(int C, int64_t* bytes);
+int ocf_bn_act_fwd(const ocf_tensor4* x, const ocf_tensor4* y, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, void* workspace, int B, int C,
+                   int H, int W, float eps, float momentum, float negative_slope, int training, int dtype, void* stream);
+int ocf_bn_act_bwd(const ocf_tensor4* x, const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, const float* gamma,
+                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, int B, int C, int H, int W,
+                   float negative_slope, int dtype, void* stream);
+
 /* kernel choice of ocf_corr_bwd / ocf_corr_occ_bwd (process-wide; same results up to float summation order): 0 = automatic, 1 = the
  * vector kernel only, 2 = the matrix-core band-GEMM kernel whenever its preconditions hold (bf16, d = 4, channel-contiguous operands,
  * 8-byte aligned pixels) */

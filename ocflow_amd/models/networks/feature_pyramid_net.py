@@ -1,8 +1,19 @@
-"""Feature pyramid encoder (reference: models/networks/feature_pyramid_net.py:5-95).  Stays in PyTorch-ROCm
-(MIOpen -> MFMA); only the parameter names / shapes are contractual (state_dict compatibility)."""
+"""Feature pyramid encoder (reference: models/networks/feature_pyramid_net.py:5-95).  Convolutions stay in PyTorch-ROCm
+(MIOpen -> MFMA); BatchNorm + LeakyReLU run as the fused HIP passes of ops.batchnorm_lrelu (csrc/bn.hip) in the channels_last
+configuration.  Module structure, parameter and buffer names are the reference's (state_dict compatibility)."""
+import os
+
 import torch.nn as nn
 
+from ocflow_amd import ops
 from ._epilogue import deconv_bias
+
+
+def _bn_act(bn: nn.BatchNorm2d, act: nn.LeakyReLU, x):
+    # OCFLOW_UNFUSED_BN=1: the reference's own op chain (A/B switch for measurements and bisecting, not a fallback)
+    if os.environ.get("OCFLOW_UNFUSED_BN", "0") == "1":
+        return act(bn(x))
+    return ops.batchnorm_lrelu(x, bn, act.negative_slope)
 
 _SLOPE = 0.1
 _WIDTHS = (3, 16, 32, 64, 96, 128, 196)
@@ -22,7 +33,9 @@ class DoubleConv(nn.Module):
                                          *_conv_bn_act(out_channels, out_channels, 3, 1))
 
     def forward(self, x):
-        return self.double_conv(x)
+        s = self.double_conv
+        x = _bn_act(s[1], s[2], s[0](x))
+        return _bn_act(s[4], s[5], s[3](x))
 
 
 class Upsample(nn.Module):
@@ -35,7 +48,7 @@ class Upsample(nn.Module):
         self.leaky = nn.LeakyReLU(negative_slope=_SLOPE)
 
     def forward(self, x, y):
-        return self.leaky(self.batchnorm(deconv_bias(self.deconv, x, y.size()))) + y
+        return _bn_act(self.batchnorm, self.leaky, deconv_bias(self.deconv, x, y.size())) + y
 
 
 class FeaturePyramidNet(nn.Module):
@@ -52,7 +65,7 @@ class FeaturePyramidNet(nn.Module):
         for lvl in range(1, 7):
             x = getattr(self, f"layer{lvl}")(x)
             skips.append(x)
-        p = self.pyr_top(skips[5])
+        p = _bn_act(self.pyr_top[1], self.pyr_top[2], self.pyr_top[0](skips[5]))
         pyramid = [p]
         for lvl in range(5, 1, -1):
             p = getattr(self, f"upsample{lvl}")(p, skips[lvl - 1])

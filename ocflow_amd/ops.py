@@ -887,6 +887,96 @@ def bias_leaky_relu(x, bias, negative_slope=0.1):
     return _BiasActFn.apply(x, bias, float(negative_slope))
 
 
+_BN_WS = {}  # device -> scratch of the batch-norm kernels (per-block partial sums between their two passes)
+
+
+def _bn_workspace(C_, device):
+    n = C.c_int64(0)
+    _lib.check(_lib.load().ocf_bn_act_workspace_bytes(int(C_), C.byref(n)), "ocf_bn_act_workspace_bytes")
+    ws = _BN_WS.get(device)
+    if ws is None or ws.numel() < n.value:
+        ws = torch.empty(max(n.value, 1 << 20), device=device, dtype=torch.uint8)
+        _BN_WS[device] = ws
+    return ws
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _BnActFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, slope):
+        B, C_, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C_, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C_, device=x.device, dtype=torch.float32)
+        ws = _bn_workspace(C_, x.device)
+        with torch.cuda.device(x.device):
+            st = _lib.load().ocf_bn_act_fwd(_t4(x), _t4(y), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                            _ptr(mean), _ptr(invstd), _ptr(ws), B, C_, H, W, float(eps), float(momentum), float(slope), 1,
+                                            _dtype_code(x), _stream(x))
+        _lib.check(st, "ocf_bn_act_fwd")
+        ctx.save_for_backward(x, y, weight, mean, invstd)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        B, C_, H, W = x.shape
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        if gy.stride() != x.stride():
+            gy = torch.empty_like(x).copy_(gy)
+        gx = torch.empty_like(x)
+        dgamma = torch.empty(C_, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(C_, device=x.device, dtype=torch.float32)
+        ws = _bn_workspace(C_, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().ocf_bn_act_bwd(_t4(x), _t4(y), _t4(gy), _t4(gx), _ptr(weight), _ptr(mean), _ptr(invstd), _ptr(dgamma),
+                                                  _ptr(dbeta), _ptr(ws), B, C_, H, W, ctx.slope, _dtype_code(x), _stream(x)), "ocf_bn_act_bwd")
+        return gx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batchnorm_lrelu_supported(x, bn) -> bool:
+    """does `batchnorm_lrelu` take this call with the HIP kernels?  (dense channels_last fp32 / bf16 on the GPU, affine fp32 parameters,
+    tracked running statistics with a fixed momentum, C a multiple of 4; training mode, or evaluation without a gradient)"""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    if x.shape[1] % 4 != 0 or x.numel() == 0 or not x.is_contiguous(memory_format=torch.channels_last) or x.shape[1] == 1:
+        return False
+    if bn.weight is None or bn.bias is None or bn.weight.dtype != torch.float32 or bn.bias.dtype != torch.float32:
+        return False
+    if not bn.track_running_stats or bn.running_mean is None or bn.momentum is None or bn.running_mean.dtype != torch.float32:
+        return False
+    if not bn.training and (x.requires_grad or bn.weight.requires_grad) and torch.is_grad_enabled():
+        return False
+    return x.shape[0] * x.shape[2] * x.shape[3] > 1 or not bn.training
+
+
+def batchnorm_lrelu(x, bn, negative_slope=0.1):
+    """`F.leaky_relu(bn(x), negative_slope)` for an nn.BatchNorm2d `bn` -- the reference's conv -> BatchNorm2d -> LeakyReLU(0.1) blocks
+    of the feature pyramid (models/networks/feature_pyramid_net.py:5-95).  Two HIP passes per direction instead of the framework's nine
+    launches per site (statistics with a last-block fp64 reduction, normalise + activation; the running statistics and
+    num_batches_tracked are updated by the statistics pass).  Same module, same parameters and buffers; layouts / modes the kernels do
+    not take (NCHW, evaluation with gradients, momentum=None ...) go through the framework's own operators."""
+    if not batchnorm_lrelu_supported(x, bn):
+        return torch.nn.functional.leaky_relu(bn(x), negative_slope)
+    _require_hip(x)
+    if bn.training:
+        return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps),
+                              float(negative_slope))
+    B, C_, H, W = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ocf_bn_act_fwd(_t4(x), _t4(y), _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), None,
+                                              None, None, None, B, C_, H, W, float(bn.eps), 0.0, float(negative_slope), 0, _dtype_code(x),
+                                              _stream(x)), "ocf_bn_act_fwd")
+    return y
+
+
 def bias_add(x, bias):
     """`x + bias[None, :, None, None]` IN PLACE on the bias-free output of an nn.Conv2d / nn.ConvTranspose2d without activation
     (prediction layers, up-convolutions: flow_net.py:38-40, flow_occ_net.py:32-34, feature_pyramid_net.py:31).  Backward is one

@@ -653,6 +653,68 @@ def test_psnr_golden(ops, golden):
         ops.psnr(a, b[:, :2])
 
 
+# ----------------------------------------------------------------- BatchNorm2d + LeakyReLU of the feature pyramid (csrc/bn.hip)
+@pytest.mark.parametrize("shape", [(2, 16, 21, 45), (2, 196, 7, 16), (8, 32, 28, 64), (1, 96, 13, 17), (3, 4, 5, 6), (2, 128, 14, 32),
+                                   (1, 1024, 3, 5)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_lrelu_vs_framework(ops, shape, dtype):
+    """ops.batchnorm_lrelu (two HIP passes per direction, last-block fp64 reduction of the statistics) against the reference's op chain
+    nn.BatchNorm2d -> nn.LeakyReLU(0.1) (feature_pyramid_net.py:5-95) evaluated in fp32 on the same (rounded) input: output, running
+    statistics and batch counter after two training calls, gradients w.r.t. input / gamma / beta, evaluation mode; 16-byte units
+    (C % 8 == 0 bf16, C % 4 == 0 fp32), 8-byte units (C = 196 bf16, C = 4), 245-of-256-thread blocks (G = 49), more channels than
+    threads (1024)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    B, C_, H, W = shape
+    gen = torch.Generator().manual_seed(C_ + H)
+    x0 = (torch.randn(shape, generator=gen) * 1.7 + 0.4).to(dtype)
+    cot = torch.randn(shape, generator=gen).to(dtype)
+    bn_ref, bn = nn.BatchNorm2d(C_), nn.BatchNorm2d(C_).to(DEV)
+    with torch.no_grad():
+        w = torch.rand(C_, generator=gen) + 0.5
+        b = torch.randn(C_, generator=gen) * 0.3
+        for m in (bn_ref, bn):
+            m.weight.copy_(w); m.bias.copy_(b)
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2
+    for it in range(2):  # twice: the ticket counter of the workspace must come back to zero, the running statistics accumulate
+        xr = x0.float().requires_grad_()
+        yr = F.leaky_relu(bn_ref(xr), 0.1)
+        gxr, gwr, gbr = torch.autograd.grad(yr, (xr, bn_ref.weight, bn_ref.bias), cot.float())
+        x = x0.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+        assert ops.batchnorm_lrelu_supported(x, bn)
+        y = ops.batchnorm_lrelu(x, bn, 0.1)
+        assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+        gx, gw, gb = torch.autograd.grad(y, (x, bn.weight, bn.bias), cot.to(DEV).contiguous(memory_format=torch.channels_last))
+        close(y, yr, tol)
+        np.testing.assert_allclose(gx.float().cpu().numpy(), gxr.numpy(), rtol=tol * 5, atol=tol * float(gxr.abs().max()) * 2)
+        n = B * H * W
+        np.testing.assert_allclose(gw.cpu().numpy(), gwr.numpy(), rtol=tol * 5, atol=tol * np.sqrt(n) * 3)
+        np.testing.assert_allclose(gb.cpu().numpy(), gbr.numpy(), rtol=tol * 5, atol=tol * np.sqrt(n) * 3)
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn_ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == it + 1 == int(bn_ref.num_batches_tracked)
+    bn.eval(); bn_ref.eval()
+    with torch.no_grad():
+        close(ops.batchnorm_lrelu(x0.to(DEV).contiguous(memory_format=torch.channels_last), bn, 0.1), F.leaky_relu(bn_ref(x0.float()), 0.1), tol)
+    assert int(bn.num_batches_tracked) == 2
+
+
+def test_batchnorm_lrelu_framework_path_for_other_layouts(ops):
+    """layouts / modes the kernels do not take go through the framework's own operators: same values as the module chain, bit for bit"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(4)
+    bn = nn.BatchNorm2d(6).to(DEV)
+    x = torch.randn((2, 6, 5, 7), generator=gen).to(DEV)  # NCHW, C % 4 != 0
+    assert not ops.batchnorm_lrelu_supported(x, bn)
+    import copy
+    bn2 = copy.deepcopy(bn)
+    assert torch.equal(ops.batchnorm_lrelu(x, bn, 0.1), F.leaky_relu(bn2(x), 0.1))
+    assert torch.equal(bn.running_var, bn2.running_var)
+    bn8 = nn.BatchNorm2d(8, momentum=None).to(DEV)  # cumulative moving average: not taken
+    assert not ops.batchnorm_lrelu_supported(torch.zeros((2, 8, 4, 4), device=DEV).contiguous(memory_format=torch.channels_last), bn8)
+
+
 # ----------------------------------------------------------------- 3x3 convolution weight gradient (SURVEY 8f-1, first slice)
 @pytest.mark.parametrize("shape,d", [((2, 32, 16, 21, 45), 1), ((1, 128, 128, 9, 70), 1), ((2, 96, 64, 17, 33), 2), ((1, 64, 32, 40, 64), 4),
                                       ((1, 16, 8, 5, 130), 1), ((1, 128, 96, 35, 40), 16), ((3, 40, 24, 7, 9), 8), ((1, 8, 160, 6, 66), 1)])
