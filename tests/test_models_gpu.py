@@ -297,8 +297,11 @@ def test_bf16_graph_step_finite():
     assert np.mean(l[-5:]) < np.mean(l[:5]), l
 
 
-def test_graph_replay_full_size_is_clean(monkeypatch):
-    """the benchmark step at the benchmark shape (8 x 436x1024, bf16, fused Adam) replayed from its hipGraph WITH a host sync and
+@pytest.mark.parametrize("real_bce", [False, True])
+def test_graph_replay_full_size_is_clean(monkeypatch, real_bce):
+    """(real_bce: the product's own F.binary_cross_entropy with its device-side range assert, as the benchmark runs it; the soft variant
+    first, so that a regression shows up as a failed assertion before it can take the process down.)
+    The benchmark step at the benchmark shape (8 x 436x1024, bf16, fused Adam) replayed from its hipGraph WITH a host sync and
     a gradient read-back between replays.  This is the pattern that exposed ROCm's packet-capture replay path (stale zero-fills
     -> garbage gradients within 3 replays, see ocflow_amd/__init__.py): every replay must leave finite, sanely scaled
     gradients and a loss that follows the eager trajectory."""
@@ -309,11 +312,12 @@ def test_graph_replay_full_size_is_clean(monkeypatch):
     def soft_bce(x, t, *a, **k):  # F.binary_cross_entropy minus its device-side assert, which would take the process down
         x = x.clamp(1e-30, 1 - 6e-8)
         return -(t * torch.log(x) + (1 - t) * torch.log1p(-x)).mean()
-    monkeypatch.setattr(F, "binary_cross_entropy", soft_bce)
+    if not real_bce:
+        monkeypatch.setattr(F, "binary_cross_entropy", soft_bce)
     torch.manual_seed(42)
     env = DistEnv(device=torch.device(DEV))
     st = TrainStepper(FlowOccModel({"learning_rate": 1e-4, "model": "flowoccnet"}), env, amp_dtype=torch.bfloat16,
-                      channels_last=True, fused_optimizer=True)
+                      channels_last=True, fused_optimizer=True, master_weights=real_bce)
     batch = st.prepare(synthetic_batch(8, 436, 1024, env.device, seed=42))
     first = float(st.step(batch, 0))
     st.enable_graph(batch)
