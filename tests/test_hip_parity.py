@@ -635,6 +635,35 @@ def test_corr_backward_matrix_core_kernel(ops, shape, with_occ, sliced):
     assert lib.ocf_corr_bwd_select(3) != 0
 
 
+def test_torch_library_ops(ops):
+    """ocflow_amd/torch_ops.py: torch.ops.ocflow.cost_volume / warp are the same launches as ops.compute_cost_volume / ops.warp, pass
+    torch.library.opcheck (schema, fake kernel, autograd registration) and trace under torch.compile without graph breaks"""
+    import ocflow_amd.torch_ops  # noqa: F401
+    gen = torch.Generator().manual_seed(12)
+    f1 = torch.randn((2, 32, 12, 20), generator=gen).to(DEV).requires_grad_()
+    f2 = torch.randn((2, 32, 12, 20), generator=gen).to(DEV).requires_grad_()
+    fl = (torch.randn((2, 2, 12, 20), generator=gen) * 2).to(DEV).requires_grad_()
+    cot = torch.randn((2, 81, 12, 20), generator=gen).to(DEV)
+    out = torch.ops.ocflow.cost_volume(f1, f2, 4)
+    ref = ops.compute_cost_volume(f1, f2, 4)
+    assert torch.equal(out, ref)
+    for a, b in zip(torch.autograd.grad(out, (f1, f2), cot), torch.autograd.grad(ref, (f1, f2), cot)):
+        assert torch.equal(a, b)
+    w, wr = torch.ops.ocflow.warp(f1, fl, 1.25, False), ops.warp(f1, fl, False, 1.25)
+    assert torch.equal(w, wr)
+    ga, gb = torch.autograd.grad(w, (f1, fl), torch.ones_like(w)), torch.autograd.grad(wr, (f1, fl), torch.ones_like(wr))
+    np.testing.assert_allclose(ga[0].cpu().numpy(), gb[0].cpu().numpy(), rtol=1e-5, atol=1e-5)  # (float atomics: order differs)
+    np.testing.assert_allclose(ga[1].cpu().numpy(), gb[1].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    torch.library.opcheck(torch.ops.ocflow.cost_volume.default, (f1.detach(), f2.detach(), 4), test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(torch.ops.ocflow.warp.default, (f1.detach(), fl.detach(), 1.25, False), test_utils=("test_schema", "test_faketensor"))
+
+    def fn(a, b, flow):
+        return torch.ops.ocflow.cost_volume(a, torch.ops.ocflow.warp(b, flow, 1.25, False), 4).square().mean()
+
+    compiled = torch.compile(fn, backend="aot_eager", fullgraph=True)
+    assert abs(float(compiled(f1, f2, fl)) - float(fn(f1, f2, fl))) < 1e-6
+
+
 def test_psnr_golden(ops, golden):
     """ops.psnr (one reduction kernel over the batch) against the reference's per-image numpy psnr, incl. the identical-pair case
     (100) and a strided view of a [B,6,H,W] batch at a Sintel-sized frame against the oracle"""

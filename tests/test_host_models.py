@@ -212,3 +212,17 @@ def test_graph_env_guard_detects_late_import(monkeypatch):
     monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
     assert ocflow_amd._graph_env_guard() is False and os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "1"
+
+
+def test_torch_library_ops_are_registered_with_fake_kernels():
+    """ocflow_amd/torch_ops.py: dispatcher identities of the two core operators -- shape propagation on meta tensors needs no GPU"""
+    import torch
+    import ocflow_amd.torch_ops  # noqa: F401
+    f = torch.empty((2, 32, 12, 20), device="meta")
+    out = torch.ops.ocflow.cost_volume(f, f, 4)
+    assert out.shape == (2, 81, 12, 20) and out.device.type == "meta"
+    fl = torch.empty((2, 2, 12, 20), device="meta")
+    assert torch.ops.ocflow.warp(f, fl, 1.25, False).shape == f.shape
+    g1, g2 = torch.ops.ocflow.cost_volume_backward(f, f, out, 4)
+    assert g1.shape == f.shape and g2.shape == f.shape
+    assert "max_displacement" in str(torch.ops.ocflow.cost_volume.default._schema)
