@@ -260,14 +260,17 @@ int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, in
  *                  (optional, int64) is incremented.  `workspace`: ocf_bn_act_workspace_bytes(C) bytes of scratch (any contents); one
  *                  workspace serves consecutive launches on one stream.
  *   training == 0: y = lrelu((x - running_mean) / sqrt(running_var + eps) * gamma + beta); no statistics pass, no workspace.
- * backward (training-mode forward only): gx, dgamma [C], dbeta [C] (overwritten). */
-int ocf_bn_act_workspace_bytes(int C, int64_t* bytes);
+ * backward (training-mode forward only): gx, dgamma [C], dbeta [C] (overwritten).
+ * groups (1 or 2, training only): the batch is `groups` consecutive, equally sized statistics groups -- the result of calling the module
+ * on each part in turn (statistics per group, save_mean / save_invstd [groups][C], running buffers updated group after group, parameter
+ * gradients summed), in the same launches.  The encoder runs both images of a pair as one batch this way. */
+int ocf_bn_act_workspace_bytes(int C, int groups, int64_t* bytes);
 int ocf_bn_act_fwd(const ocf_tensor4* x, const ocf_tensor4* y, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, void* workspace, int B, int C,
-                   int H, int W, float eps, float momentum, float negative_slope, int training, int dtype, void* stream);
+                   int H, int W, float eps, float momentum, float negative_slope, int training, int groups, int dtype, void* stream);
 int ocf_bn_act_bwd(const ocf_tensor4* x, const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, const float* gamma,
                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, int B, int C, int H, int W,
-                   float negative_slope, int dtype, void* stream);
+                   float negative_slope, int groups, int dtype, void* stream);
 
 /* kernel choice of ocf_corr_bwd / ocf_corr_occ_bwd (process-wide; same results up to float summation order): 0 = automatic, 1 = the
  * vector kernel only, 2 = the matrix-core band-GEMM kernel whenever its preconditions hold (bf16, d = 4, channel-contiguous operands,

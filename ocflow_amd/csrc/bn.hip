@@ -67,6 +67,9 @@ __device__ __forceinline__ void store_partials(float (*red)[2 * V + 1], const fl
 
 template <typename T, int V>
 __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, long R, int C, int G) {
+  // blockIdx.y = statistics group (R rows each; a group is a contiguous range of the batch)
+  x += (long)blockIdx.y * R * C;
+  part += (long)blockIdx.y * gridDim.x * 2 * C;
   __shared__ float red[256][2 * V + 1];
   const int rpb = 256 / G;
   const int r = threadIdx.x / G, cg = threadIdx.x - r * G;
@@ -127,7 +130,24 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
                                                        float slope, float eps, float momentum) {
   __shared__ float s_a[MAX_C], s_b[MAX_C];
   __shared__ double s_tot[2][MAX_C];
-  if (nparts > 0) reduce_partials(part, nparts, C, s_tot);
+  // blockIdx.y = statistics group (1 or 2 groups): its own rows, partials and saved statistics.  The running buffers see the groups one
+  // after the other, exactly as two calls of the module would: block (0, 0) -- the keeper -- also totals group 1 for that.
+  __shared__ float s_m1[MAX_C], s_v1[MAX_C];
+  const int grp = blockIdx.y, ngrp = gridDim.y;
+  x += (long)grp * R * C;
+  y += (long)grp * R * C;
+  const bool keeper = nparts > 0 && blockIdx.x == 0 && grp == 0;
+  if (keeper && ngrp == 2) {
+    reduce_partials(part + (long)nparts * 2 * C, nparts, C, s_tot);
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const double n = (double)R, dm = s_tot[0][c] / n;
+      double var = s_tot[1][c] / n - dm * dm;
+      s_m1[c] = (float)dm;
+      s_v1[c] = (float)(var > 0.0 ? var : 0.0);
+    }
+    __syncthreads();
+  }
+  if (nparts > 0) reduce_partials(part + (long)grp * nparts * 2 * C, nparts, C, s_tot);
   for (int c = threadIdx.x; c < C; c += 256) {
     float m, is;
     if (nparts > 0) {
@@ -137,10 +157,22 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
       m = (float)dm;
       is = (float)(1.0 / sqrt(var + (double)eps));
       if (blockIdx.x == 0) {
-        mean[c] = m;
-        invstd[c] = is;
-        if (run_mean) run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * dm);
-        if (run_var) run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * var * (R > 1 ? n / (n - 1.0) : 1.0));
+        mean[(long)grp * C + c] = m;
+        invstd[(long)grp * C + c] = is;
+      }
+      if (keeper) {
+        const double unb = R > 1 ? n / (n - 1.0) : 1.0, mo = (double)momentum;
+        double rmv = run_mean ? (double)run_mean[c] : 0.0, rvv = run_var ? (double)run_var[c] : 0.0;
+        rmv = (1.0 - mo) * rmv + mo * dm;
+        rvv = (1.0 - mo) * rvv + mo * var * unb;
+        if (ngrp == 2) {
+          rmv = (float)rmv;  // (a separate call would have stored fp32 in between)
+          rvv = (float)rvv;
+          rmv = (1.0 - mo) * rmv + mo * (double)s_m1[c];
+          rvv = (1.0 - mo) * rvv + mo * (double)s_v1[c] * unb;
+        }
+        if (run_mean) run_mean[c] = (float)rmv;
+        if (run_var) run_var[c] = (float)rvv;
       }
     } else {
       m = run_mean[c];
@@ -150,7 +182,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
     s_a[c] = a;
     s_b[c] = beta[c] - m * a;
   }
-  if (nparts > 0 && blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (keeper && threadIdx.x == 0 && nbt) *nbt += ngrp;
   __syncthreads();
   const long n_units = R * G;
   const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
@@ -184,6 +216,12 @@ template <typename T, int V>
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ gy,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            float* __restrict__ part, long R, int C, int G, float slope) {
+  {  // blockIdx.y = statistics group
+    const long go = (long)blockIdx.y * R * C;
+    x += go; y += go; gy += go;
+    mean += (long)blockIdx.y * C; invstd += (long)blockIdx.y * C;
+    part += (long)blockIdx.y * gridDim.x * 2 * C;
+  }
   __shared__ float red[256][2 * V + 1];
   const int rpb = 256 / G;
   const int r = threadIdx.x / G, cg = threadIdx.x - r * G;
@@ -226,10 +264,27 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ part, int nparts,
                                                         float* dgamma, float* dbeta, long R, int C, int G, float slope) {
   __shared__ double s_tot[2][MAX_C];
-  reduce_partials(part, nparts, C, s_tot);
+  __shared__ float s_o[2][MAX_C];
+  // blockIdx.y = statistics group; the parameter gradients are the sums over the groups: block (0, 0) also totals group 1
+  const int grp = blockIdx.y, ngrp = gridDim.y;
+  {
+    const long go = (long)grp * R * C;
+    x += go; y += go; gy += go; gx += go;
+    mean += (long)grp * C; invstd += (long)grp * C;
+  }
+  const bool keeper = blockIdx.x == 0 && grp == 0;
+  if (keeper && ngrp == 2) {
+    reduce_partials(part + (long)nparts * 2 * C, nparts, C, s_tot);
+    for (int c = threadIdx.x; c < C; c += 256) { s_o[0][c] = (float)s_tot[0][c]; s_o[1][c] = (float)s_tot[1][c]; }
+    __syncthreads();
+  }
+  reduce_partials(part + (long)grp * nparts * 2 * C, nparts, C, s_tot);
   const float inv_n = 1.f / (float)R;
-  if (blockIdx.x == 0)
-    for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)s_tot[0][c]; dgamma[c] = (float)s_tot[1][c]; }
+  if (keeper)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dbeta[c] = (float)s_tot[0][c] + (ngrp == 2 ? s_o[0][c] : 0.f);
+      dgamma[c] = (float)s_tot[1][c] + (ngrp == 2 ? s_o[1][c] : 0.f);
+    }
   const long n_units = R * G;
   const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
   if (i0 >= n_units) return;
@@ -290,9 +345,14 @@ __device__ __forceinline__ void block_totals(float* s, float* q, float (*red)[2 
 template <typename T, int V>
 __global__ void __launch_bounds__(CB) bn_fwd_col_kernel(const T* __restrict__ x, T* __restrict__ y, float* mean, float* invstd, float* run_mean,
                                                          float* run_var, long long* nbt, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, long R, int C, float slope, float eps, float momentum) {
+                                                         const float* __restrict__ beta, long R, int C, float slope, float eps, float momentum, int ngrp) {
   __shared__ float red[CB / 64][2 * V];
   const int c0 = blockIdx.x * V;
+  const T* x0 = x;
+  T* y0 = y;
+  for (int grp = 0; grp < ngrp; grp++) {  // statistics groups one after the other (the running buffers see them in order)
+  x = x0 + (long)grp * R * C;
+  y = y0 + (long)grp * R * C;
   float s[V], q[V];
 #pragma unroll
   for (int j = 0; j < V; j++) s[j] = q[j] = 0.f;
@@ -317,15 +377,15 @@ __global__ void __launch_bounds__(CB) bn_fwd_col_kernel(const T* __restrict__ x,
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const int c = c0 + j;
     if (threadIdx.x == 0) {
-      mean[c] = (float)dm;
-      invstd[c] = is;
+      mean[(long)grp * C + c] = (float)dm;
+      invstd[(long)grp * C + c] = is;
       if (run_mean) run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * dm);
       if (run_var) run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * var * (R > 1 ? n / (n - 1.0) : 1.0));
     }
     a[j] = gamma[c] * is;
     b[j] = beta[c] - (float)dm * a[j];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt && grp == 0) *nbt += ngrp;
   for (long r0 = threadIdx.x; r0 < R; r0 += 4 * CB) {
     float f[4][V];
 #pragma unroll
@@ -341,18 +401,27 @@ __global__ void __launch_bounds__(CB) bn_fwd_col_kernel(const T* __restrict__ x,
         stv<T, V>(y + (r0 + CB * k) * C + c0, f[k]);
       }
   }
+  __syncthreads();  // (red is reused by the next group)
+  }
 }
 
 template <typename T, int V>
 __global__ void __launch_bounds__(CB) bn_bwd_col_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ gy,
                                                          T* __restrict__ gx, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, float* dgamma, float* dbeta, long R, int C,
-                                                         float slope) {
+                                                         float slope, int ngrp) {
   __shared__ float red[CB / 64][2 * V];
   const int c0 = blockIdx.x * V;
+  const T *x0 = x, *y0 = y, *g0 = gy;
+  T* gx0 = gx;
+  float sb[V], sg[V];  // parameter gradients: sums over the statistics groups
+#pragma unroll
+  for (int j = 0; j < V; j++) sb[j] = sg[j] = 0.f;
+  for (int grp = 0; grp < ngrp; grp++) {
+  x = x0 + (long)grp * R * C; y = y0 + (long)grp * R * C; gy = g0 + (long)grp * R * C; gx = gx0 + (long)grp * R * C;
   float s[V], q[V], mu[V], is[V];
 #pragma unroll
-  for (int j = 0; j < V; j++) { s[j] = q[j] = 0.f; mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
+  for (int j = 0; j < V; j++) { s[j] = q[j] = 0.f; mu[j] = mean[(long)grp * C + c0 + j]; is[j] = invstd[(long)grp * C + c0 + j]; }
   for (long r0 = threadIdx.x; r0 < R; r0 += 2 * CB) {
     float fx[2][V], fy[2][V], fg[2][V];
 #pragma unroll
@@ -376,7 +445,7 @@ __global__ void __launch_bounds__(CB) bn_bwd_col_kernel(const T* __restrict__ x,
   float k0[V], k1[V], k2[V];
 #pragma unroll
   for (int j = 0; j < V; j++) {
-    if (threadIdx.x == 0) { dbeta[c0 + j] = s[j]; dgamma[c0 + j] = q[j]; }
+    sb[j] += s[j]; sg[j] += q[j];
     k0[j] = gamma[c0 + j] * is[j];
     k1[j] = s[j] * inv_n;
     k2[j] = q[j] * inv_n;
@@ -398,6 +467,12 @@ __global__ void __launch_bounds__(CB) bn_bwd_col_kernel(const T* __restrict__ x,
         }
         stv<T, V>(gx + (r0 + CB * k) * C + c0, fx[k]);
       }
+  }
+  __syncthreads();  // (red is reused by the next group)
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < V; j++) { dbeta[c0 + j] = sb[j]; dgamma[c0 + j] = sg[j]; }
   }
 }
 
@@ -436,22 +511,23 @@ static int grid_for_units(long n_units, int G) {
 template <typename T, int V>
 static int fwd_v(const ocf_tensor4* x, const ocf_tensor4* y, const float* gamma, const float* beta, float* rm, float* rv, long long* nbt,
                  float* save_mean, float* save_invstd, void* workspace, long R, int C, float eps, float momentum, float slope, int training,
-                 hipStream_t st) {
+                 int groups, hipStream_t st) {
+  // R = rows of ONE statistics group
   const int G = C / V;
   const long n_units = R * G;
   LaunchProf lp;
   if (training && R * C <= COL_MAX_ELEMS) {
     lp.launch(true, bn_fwd_col_kernel<T, V>, dim3(G), dim3(CB), 0, st, (const T*)x->data, (T*)y->data, save_mean, save_invstd, rm, rv, nbt, gamma,
-              beta, R, C, slope, eps, momentum);
+              beta, R, C, slope, eps, momentum, groups);
     return launch_status();
   }
   if (training) {
     const int nb = stat_blocks(R, C);
-    lp.launch(false, bn_stats_kernel<T, V>, dim3(nb), dim3(256), 0, st, (const T*)x->data, (float*)workspace, R, C, G);
-    lp.launch(true, bn_apply_kernel<T, V>, dim3(grid_for_units(n_units, G)), dim3(256), 0, st, (const T*)x->data, (T*)y->data,
+    lp.launch(false, bn_stats_kernel<T, V>, dim3(nb, groups), dim3(256), 0, st, (const T*)x->data, (float*)workspace, R, C, G);
+    lp.launch(true, bn_apply_kernel<T, V>, dim3(grid_for_units(n_units, G), groups), dim3(256), 0, st, (const T*)x->data, (T*)y->data,
               (const float*)workspace, nb, save_mean, save_invstd, rm, rv, nbt, gamma, beta, R, C, G, slope, eps, momentum);
   } else {
-    lp.launch(true, bn_apply_kernel<T, V>, dim3(grid_for_units(n_units, G)), dim3(256), 0, st, (const T*)x->data, (T*)y->data,
+    lp.launch(true, bn_apply_kernel<T, V>, dim3(grid_for_units(n_units, G), groups), dim3(256), 0, st, (const T*)x->data, (T*)y->data,
               (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr, rm, rv, (long long*)nullptr, gamma, beta, R, C, G, slope, eps, 0.f);
   }
   return launch_status();
@@ -460,19 +536,19 @@ static int fwd_v(const ocf_tensor4* x, const ocf_tensor4* y, const float* gamma,
 template <typename T, int V>
 static int bwd_v(const ocf_tensor4* x, const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, const float* gamma,
                  const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, long R, int C, float slope,
-                 hipStream_t st) {
+                 int groups, hipStream_t st) {
   const int G = C / V;
   const long n_units = R * G;
   const int nb = stat_blocks(R, C);
   LaunchProf lp;
   if (R * C <= COL_MAX_ELEMS) {
     lp.launch(true, bn_bwd_col_kernel<T, V>, dim3(G), dim3(CB), 0, st, (const T*)x->data, (const T*)y->data, (const T*)gy->data, (T*)gx->data,
-              save_mean, save_invstd, gamma, dgamma, dbeta, R, C, slope);
+              save_mean, save_invstd, gamma, dgamma, dbeta, R, C, slope, groups);
     return launch_status();
   }
-  lp.launch(false, bn_bwd_stats_kernel<T, V>, dim3(nb), dim3(256), 0, st, (const T*)x->data, (const T*)y->data, (const T*)gy->data, save_mean,
+  lp.launch(false, bn_bwd_stats_kernel<T, V>, dim3(nb, groups), dim3(256), 0, st, (const T*)x->data, (const T*)y->data, (const T*)gy->data, save_mean,
             save_invstd, (float*)workspace, R, C, G, slope);
-  lp.launch(true, bn_bwd_dx_kernel<T, V>, dim3(grid_for_units(n_units, G)), dim3(256), 0, st, (const T*)x->data, (const T*)y->data,
+  lp.launch(true, bn_bwd_dx_kernel<T, V>, dim3(grid_for_units(n_units, G), groups), dim3(256), 0, st, (const T*)x->data, (const T*)y->data,
             (const T*)gy->data, (T*)gx->data, save_mean, save_invstd, gamma, (const float*)workspace, nb, dgamma, dbeta, R, C, G, slope);
   return launch_status();
 }
@@ -482,52 +558,54 @@ static int bwd_v(const ocf_tensor4* x, const ocf_tensor4* y, const ocf_tensor4* 
 
 using namespace ocf;
 
-extern "C" int ocf_bn_act_workspace_bytes(int C, int64_t* bytes) {
-  if (C <= 0 || !bytes) return OCF_EINVAL;
-  *bytes = (int64_t)bn::MAX_PARTS * 2 * C * sizeof(float);
+extern "C" int ocf_bn_act_workspace_bytes(int C, int groups, int64_t* bytes) {
+  if (C <= 0 || groups < 1 || groups > 2 || !bytes) return OCF_EINVAL;
+  *bytes = (int64_t)groups * bn::MAX_PARTS * 2 * C * sizeof(float);
   return OCF_OK;
 }
 
 extern "C" int ocf_bn_act_fwd(const ocf_tensor4* x, const ocf_tensor4* y, const float* gamma, const float* beta, float* running_mean,
                               float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, void* workspace, int B,
-                              int C, int H, int W, float eps, float momentum, float negative_slope, int training, int dtype, void* stream) {
+                              int C, int H, int W, float eps, float momentum, float negative_slope, int training, int groups, int dtype, void* stream) {
   clear_stale_error();
+  if (groups < 1 || groups > 2 || (B % (groups > 0 ? groups : 1)) != 0 || (!training && groups != 1)) return OCF_EINVAL;
   if (!x || !y || !x->data || !y->data || !gamma || !beta || B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   if (dtype != OCF_F32 && dtype != OCF_BF16) return OCF_EINVAL;
   if (training && (!save_mean || !save_invstd || !workspace)) return OCF_EINVAL;
   if (!training && (!running_mean || !running_var)) return OCF_EINVAL;
   if (!bn::dense_cl(x, B, C, H, W) || !bn::dense_cl(y, B, C, H, W)) return OCF_EUNSUPPORTED;
-  const long R = (long)B * H * W;
+  const long R = (long)(B / groups) * H * W;  // rows of one statistics group
   hipStream_t st = (hipStream_t)stream;
   long long* nbt = (long long*)num_batches_tracked;
   if (dtype == OCF_BF16) {
     const int v = bn::pick_v<bf16>(C, {x, y});
-    if (v == 8) return bn::fwd_v<bf16, 8>(x, y, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, workspace, R, C, eps, momentum, negative_slope, training, st);
-    if (v == 4) return bn::fwd_v<bf16, 4>(x, y, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, workspace, R, C, eps, momentum, negative_slope, training, st);
+    if (v == 8) return bn::fwd_v<bf16, 8>(x, y, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, workspace, R, C, eps, momentum, negative_slope, training, groups, st);
+    if (v == 4) return bn::fwd_v<bf16, 4>(x, y, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, workspace, R, C, eps, momentum, negative_slope, training, groups, st);
     return OCF_EUNSUPPORTED;
   }
   if (bn::pick_v<float>(C, {x, y}) == 4)
-    return bn::fwd_v<float, 4>(x, y, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, workspace, R, C, eps, momentum, negative_slope, training, st);
+    return bn::fwd_v<float, 4>(x, y, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, workspace, R, C, eps, momentum, negative_slope, training, groups, st);
   return OCF_EUNSUPPORTED;
 }
 
 extern "C" int ocf_bn_act_bwd(const ocf_tensor4* x, const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, const float* gamma,
                               const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, int B, int C,
-                              int H, int W, float negative_slope, int dtype, void* stream) {
+                              int H, int W, float negative_slope, int groups, int dtype, void* stream) {
   clear_stale_error();
+  if (groups < 1 || groups > 2 || B % (groups > 0 ? groups : 1) != 0) return OCF_EINVAL;
   if (!x || !y || !gy || !gx || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !workspace) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (dtype != OCF_F32 && dtype != OCF_BF16)) return OCF_EINVAL;
   if (!bn::dense_cl(x, B, C, H, W) || !bn::dense_cl(y, B, C, H, W) || !bn::dense_cl(gy, B, C, H, W) || !bn::dense_cl(gx, B, C, H, W))
     return OCF_EUNSUPPORTED;
-  const long R = (long)B * H * W;
+  const long R = (long)(B / groups) * H * W;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OCF_BF16) {
     const int v = bn::pick_v<bf16>(C, {x, y, gy, gx});
-    if (v == 8) return bn::bwd_v<bf16, 8>(x, y, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, st);
-    if (v == 4) return bn::bwd_v<bf16, 4>(x, y, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, st);
+    if (v == 8) return bn::bwd_v<bf16, 8>(x, y, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, groups, st);
+    if (v == 4) return bn::bwd_v<bf16, 4>(x, y, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, groups, st);
     return OCF_EUNSUPPORTED;
   }
   if (bn::pick_v<float>(C, {x, y, gy, gx}) == 4)
-    return bn::bwd_v<float, 4>(x, y, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, st);
+    return bn::bwd_v<float, 4>(x, y, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, groups, st);
   return OCF_EUNSUPPORTED;
 }

@@ -3,17 +3,18 @@
 configuration.  Module structure, parameter and buffer names are the reference's (state_dict compatibility)."""
 import os
 
+import torch
 import torch.nn as nn
 
 from ocflow_amd import ops
 from ._epilogue import deconv_bias
 
 
-def _bn_act(bn: nn.BatchNorm2d, act: nn.LeakyReLU, x):
+def _bn_act(bn: nn.BatchNorm2d, act: nn.LeakyReLU, x, groups: int = 1):
     # OCFLOW_UNFUSED_BN=1: the reference's own op chain (A/B switch for measurements and bisecting, not a fallback)
-    if os.environ.get("OCFLOW_UNFUSED_BN", "0") == "1":
+    if os.environ.get("OCFLOW_UNFUSED_BN", "0") == "1" and groups == 1:
         return act(bn(x))
-    return ops.batchnorm_lrelu(x, bn, act.negative_slope)
+    return ops.batchnorm_lrelu(x, bn, act.negative_slope, groups)
 
 _SLOPE = 0.1
 _WIDTHS = (3, 16, 32, 64, 96, 128, 196)
@@ -32,10 +33,10 @@ class DoubleConv(nn.Module):
         self.double_conv = nn.Sequential(*_conv_bn_act(in_channels, out_channels, 3, 2),
                                          *_conv_bn_act(out_channels, out_channels, 3, 1))
 
-    def forward(self, x):
+    def forward(self, x, groups: int = 1):
         s = self.double_conv
-        x = _bn_act(s[1], s[2], s[0](x))
-        return _bn_act(s[4], s[5], s[3](x))
+        x = _bn_act(s[1], s[2], s[0](x), groups)
+        return _bn_act(s[4], s[5], s[3](x), groups)
 
 
 class Upsample(nn.Module):
@@ -47,8 +48,8 @@ class Upsample(nn.Module):
         self.batchnorm = nn.BatchNorm2d(out_channels)
         self.leaky = nn.LeakyReLU(negative_slope=_SLOPE)
 
-    def forward(self, x, y):
-        return _bn_act(self.batchnorm, self.leaky, deconv_bias(self.deconv, x, y.size())) + y
+    def forward(self, x, y, groups: int = 1):
+        return _bn_act(self.batchnorm, self.leaky, deconv_bias(self.deconv, x, y.size()), groups) + y
 
 
 class FeaturePyramidNet(nn.Module):
@@ -60,14 +61,30 @@ class FeaturePyramidNet(nn.Module):
         for lvl in range(5, 1, -1):
             setattr(self, f"upsample{lvl}", Upsample(_WIDTHS[lvl + 1], _WIDTHS[lvl]))
 
-    def forward(self, x):
+    def forward(self, x, groups: int = 1):
         skips = []
         for lvl in range(1, 7):
-            x = getattr(self, f"layer{lvl}")(x)
+            x = getattr(self, f"layer{lvl}")(x, groups)
             skips.append(x)
-        p = _bn_act(self.pyr_top[1], self.pyr_top[2], self.pyr_top[0](skips[5]))
+        p = _bn_act(self.pyr_top[1], self.pyr_top[2], self.pyr_top[0](skips[5]), groups)
         pyramid = [p]
         for lvl in range(5, 1, -1):
-            p = getattr(self, f"upsample{lvl}")(p, skips[lvl - 1])
+            p = getattr(self, f"upsample{lvl}")(p, skips[lvl - 1], groups)
             pyramid.append(p)
         return pyramid  # [p6, p5, p4, p3, p2] with 196, 128, 96, 64, 32 channels
+
+    def forward_pair(self, x1, x2):
+        """the pyramids of both images of a pair: `(self(x1), self(x2))` (flow_net.py:100-101, flow_occ_net.py:149-150), computed as ONE
+        batch of 2B images on the GPU.  The convolutions do not couple samples; every BatchNorm runs with two statistics groups
+        (ops.batchnorm_lrelu(groups=2): per-half statistics, running buffers updated half after half, as the two calls would), so
+        the values are those of the two calls while the 17 convolutions / BatchNorm sites per image -- most of them launch-bound at
+        the coarse levels -- are launched once instead of twice.  OCFLOW_UNPAIRED_FPN=1, CPU tensors and NCHW layouts: two calls."""
+        paired = (x1.is_cuda and x1.shape == x2.shape and x1.dim() == 4 and os.environ.get("OCFLOW_UNPAIRED_FPN", "0") != "1"
+                  and os.environ.get("OCFLOW_UNFUSED_BN", "0") != "1"
+                  and (not self.training or x1.is_contiguous(memory_format=torch.channels_last) or x1.shape[1] == 3))
+        if not paired:
+            return self(x1), self(x2)
+        B = x1.shape[0]
+        pyr = self(torch.cat([x1, x2], 0), 2 if self.training else 1)
+        halves = [p.view(2, B, *p.shape[1:]).unbind(0) for p in pyr]
+        return [h[0] for h in halves], [h[1] for h in halves]

@@ -65,8 +65,7 @@ class FlowNet(nn.Module):
         return ops.warp(img, flow, align_corners=False)
 
     def forward(self, inputs):
-        pyr1 = self.feature_pyramid_network(inputs[:, 0:3])
-        pyr2 = self.feature_pyramid_network(inputs[:, 3:6])
+        pyr1, pyr2 = self.feature_pyramid_network.forward_pair(inputs[:, 0:3], inputs[:, 3:6])
         flow_up = feat_up = flow = feat = None
         for i, level in enumerate(LEVELS):
             f1, f2 = pyr1[i], pyr2[i]

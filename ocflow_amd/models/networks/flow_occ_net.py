@@ -65,8 +65,7 @@ class FlowOccNet(nn.Module):
         return ops.warp(img, flow, align_corners=False)
 
     def forward(self, inputs, training=False, mask=None):
-        pyr1 = self.feature_pyramid_network(inputs[:, 0:3])
-        pyr2 = self.feature_pyramid_network(inputs[:, 3:6])
+        pyr1, pyr2 = self.feature_pyramid_network.forward_pair(inputs[:, 0:3], inputs[:, 3:6])
         flow_up = flow_feat_up = occ_up = occ_feat_up = None
         flow = flow_feat = occ = None
         for i, level in enumerate(LEVELS):

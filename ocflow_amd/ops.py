@@ -890,9 +890,9 @@ def bias_leaky_relu(x, bias, negative_slope=0.1):
 _BN_WS = {}  # device -> scratch of the batch-norm kernels (per-block partial sums between their two passes)
 
 
-def _bn_workspace(C_, device):
+def _bn_workspace(C_, device, groups=1):
     n = C.c_int64(0)
-    _lib.check(_lib.load().ocf_bn_act_workspace_bytes(int(C_), C.byref(n)), "ocf_bn_act_workspace_bytes")
+    _lib.check(_lib.load().ocf_bn_act_workspace_bytes(int(C_), int(groups), C.byref(n)), "ocf_bn_act_workspace_bytes")
     ws = _BN_WS.get(device)
     if ws is None or ws.numel() < n.value:
         ws = torch.empty(max(n.value, 1 << 20), device=device, dtype=torch.uint8)
@@ -906,19 +906,20 @@ def _ptr(t):
 
 class _BnActFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, slope):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, slope, groups):
         B, C_, H, W = x.shape
         y = torch.empty_like(x)
-        mean = torch.empty(C_, device=x.device, dtype=torch.float32)
-        invstd = torch.empty(C_, device=x.device, dtype=torch.float32)
-        ws = _bn_workspace(C_, x.device)
+        mean = torch.empty((groups, C_), device=x.device, dtype=torch.float32)
+        invstd = torch.empty((groups, C_), device=x.device, dtype=torch.float32)
+        ws = _bn_workspace(C_, x.device, groups)
         with torch.cuda.device(x.device):
             st = _lib.load().ocf_bn_act_fwd(_t4(x), _t4(y), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
                                             _ptr(mean), _ptr(invstd), _ptr(ws), B, C_, H, W, float(eps), float(momentum), float(slope), 1,
-                                            _dtype_code(x), _stream(x))
+                                            int(groups), _dtype_code(x), _stream(x))
         _lib.check(st, "ocf_bn_act_fwd")
         ctx.save_for_backward(x, y, weight, mean, invstd)
         ctx.slope = float(slope)
+        ctx.groups = int(groups)
         return y
 
     @staticmethod
@@ -933,11 +934,12 @@ class _BnActFn(Function):
         gx = torch.empty_like(x)
         dgamma = torch.empty(C_, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C_, device=x.device, dtype=torch.float32)
-        ws = _bn_workspace(C_, x.device)
+        ws = _bn_workspace(C_, x.device, ctx.groups)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().ocf_bn_act_bwd(_t4(x), _t4(y), _t4(gy), _t4(gx), _ptr(weight), _ptr(mean), _ptr(invstd), _ptr(dgamma),
-                                                  _ptr(dbeta), _ptr(ws), B, C_, H, W, ctx.slope, _dtype_code(x), _stream(x)), "ocf_bn_act_bwd")
-        return gx, dgamma, dbeta, None, None, None, None, None, None
+                                                  _ptr(dbeta), _ptr(ws), B, C_, H, W, ctx.slope, ctx.groups, _dtype_code(x), _stream(x)),
+                       "ocf_bn_act_bwd")
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def batchnorm_lrelu_supported(x, bn) -> bool:
@@ -956,23 +958,28 @@ def batchnorm_lrelu_supported(x, bn) -> bool:
     return x.shape[0] * x.shape[2] * x.shape[3] > 1 or not bn.training
 
 
-def batchnorm_lrelu(x, bn, negative_slope=0.1):
-    """`F.leaky_relu(bn(x), negative_slope)` for an nn.BatchNorm2d `bn` -- the reference's conv -> BatchNorm2d -> LeakyReLU(0.1) blocks
+def batchnorm_lrelu(x, bn, negative_slope=0.1, groups=1):
+    """`F.leaky_relu(bn(x), negative_slope)` for an nn.BatchNorm2d `bn` (groups=2: of `bn` applied to the two halves of the batch in turn) -- the reference's conv -> BatchNorm2d -> LeakyReLU(0.1) blocks
     of the feature pyramid (models/networks/feature_pyramid_net.py:5-95).  Two HIP passes per direction instead of the framework's nine
     launches per site (statistics with a last-block fp64 reduction, normalise + activation; the running statistics and
     num_batches_tracked are updated by the statistics pass).  Same module, same parameters and buffers; layouts / modes the kernels do
     not take (NCHW, evaluation with gradients, momentum=None ...) go through the framework's own operators."""
-    if not batchnorm_lrelu_supported(x, bn):
-        return torch.nn.functional.leaky_relu(bn(x), negative_slope)
+    if groups not in (1, 2) or x.shape[0] % groups:
+        raise ValueError(f"groups must be 1 or 2 and divide the batch, got {groups} for a batch of {x.shape[0]}")
+    if not batchnorm_lrelu_supported(x, bn) or (groups == 2 and not bn.training):
+        if groups == 1:
+            return torch.nn.functional.leaky_relu(bn(x), negative_slope)
+        # `groups` consecutive parts of the batch, each normalised by its own statistics: the module called on each part in turn
+        return torch.cat([torch.nn.functional.leaky_relu(bn(part), negative_slope) for part in x.chunk(groups, 0)], 0)
     _require_hip(x)
     if bn.training:
         return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps),
-                              float(negative_slope))
+                              float(negative_slope), int(groups))
     B, C_, H, W = x.shape
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ocf_bn_act_fwd(_t4(x), _t4(y), _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), None,
-                                              None, None, None, B, C_, H, W, float(bn.eps), 0.0, float(negative_slope), 0, _dtype_code(x),
+                                              None, None, None, B, C_, H, W, float(bn.eps), 0.0, float(negative_slope), 0, 1, _dtype_code(x),
                                               _stream(x)), "ocf_bn_act_fwd")
     return y
 

@@ -728,6 +728,48 @@ def test_batchnorm_lrelu_vs_framework(ops, shape, dtype):
     assert int(bn.num_batches_tracked) == 2
 
 
+@pytest.mark.parametrize("shape", [(4, 16, 21, 45), (4, 196, 7, 16), (16, 32, 28, 64), (2, 128, 14, 32), (6, 64, 55, 128)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_lrelu_two_statistics_groups(ops, shape, dtype):
+    """ops.batchnorm_lrelu(groups=2) -- both images of a pair as one batch -- is the module applied to the two halves in turn: per-half
+    statistics, running buffers updated half after half, parameter gradients summed.  Bit-identical to two groups=1 calls of the same
+    kernels (same partial sums, same order), and within tolerance of the framework chain on the halves."""
+    import copy
+    import torch.nn as nn
+    import torch.nn.functional as F
+    B, C_, H, W = shape
+    gen = torch.Generator().manual_seed(B + C_)
+    x0 = (torch.randn(shape, generator=gen) * 1.3 - 0.2).to(dtype)
+    x0[B // 2:] += 0.7  # the halves differ in their statistics
+    cot = torch.randn(shape, generator=gen).to(dtype)
+    bn = nn.BatchNorm2d(C_).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C_, generator=gen) + 0.5); bn.bias.copy_(torch.randn(C_, generator=gen) * 0.3)
+    bn_a, bn_b = copy.deepcopy(bn), copy.deepcopy(bn)
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    x = cl(x0).requires_grad_()
+    y = ops.batchnorm_lrelu(x, bn, 0.1, groups=2)
+    gx, gw, gb = torch.autograd.grad(y, (x, bn.weight, bn.bias), cl(cot))
+    # two calls of the same kernels on the halves
+    xs = [cl(x0[:B // 2]).requires_grad_(), cl(x0[B // 2:]).requires_grad_()]
+    ys = [ops.batchnorm_lrelu(xs[0], bn_a, 0.1), ops.batchnorm_lrelu(xs[1], bn_a, 0.1)]
+    ga = [torch.autograd.grad(ys[k], (xs[k], bn_a.weight, bn_a.bias), cl(cot[k * (B // 2):(k + 1) * (B // 2)])) for k in range(2)]
+    assert torch.equal(y, torch.cat(ys, 0)) and torch.equal(gx, torch.cat([ga[0][0], ga[1][0]], 0))
+    assert torch.equal(gw, ga[0][1] + ga[1][1]) and torch.equal(gb, ga[0][2] + ga[1][2])
+    # (the second half's statistics pass through fp32 on their way to the running update: last-bit differences)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn_a.running_mean.cpu().numpy(), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_a.running_var.cpu().numpy(), rtol=1e-6, atol=1e-8)
+    assert int(bn.num_batches_tracked) == 2 == int(bn_a.num_batches_tracked)
+    # the framework chain on the halves (fp32)
+    bn_b = bn_b.cpu()
+    yr = torch.cat([F.leaky_relu(bn_b(x0[:B // 2].float()), 0.1), F.leaky_relu(bn_b(x0[B // 2:].float()), 0.1)], 0)
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2
+    close(y, yr, tol)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_b.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        ops.batchnorm_lrelu(x, bn, 0.1, groups=3)
+
+
 def test_batchnorm_lrelu_framework_path_for_other_layouts(ops):
     """layouts / modes the kernels do not take go through the framework's own operators: same values as the module chain, bit for bit"""
     import torch.nn as nn

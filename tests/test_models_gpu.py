@@ -232,6 +232,46 @@ def test_aligned_concatenation_is_the_same_block(monkeypatch, block):
     _grads_with_and_without_padding(monkeypatch, build, run)
 
 
+@pytest.mark.parametrize("mode", ["fp32_cl_train", "bf16_cl_train", "fp32_nchw_train", "fp32_cl_eval"])
+def test_feature_pyramid_pair_equals_two_calls(monkeypatch, mode):
+    """FeaturePyramidNet.forward_pair (both images as one batch of 2B, BatchNorm with two statistics groups) against the reference's two
+    calls (flow_net.py:100-101): every pyramid level of both images, every parameter gradient, the BatchNorm running buffers and the
+    batch counters.  fp32: convolution results at batch 16 and batch 8 agree to rounding; bf16: to bf16 rounding."""
+    from ocflow_amd.models.networks.feature_pyramid_net import FeaturePyramidNet
+    fp32 = mode.startswith("fp32")
+    cl = "_cl_" in mode
+    train = mode.endswith("train")
+    gen = torch.Generator().manual_seed(9)
+    x1 = torch.rand((2, 3, 128, 192), generator=gen) * 2 - 1
+    x2 = torch.rand((2, 3, 128, 192), generator=gen) * 2 - 1
+    res = []
+    for unpaired in ("1", "0"):
+        monkeypatch.setenv("OCFLOW_UNPAIRED_FPN", unpaired)
+        torch.manual_seed(0)
+        net = FeaturePyramidNet().to(DEV)
+        if cl:
+            net = net.to(memory_format=torch.channels_last)
+        net.train(train)
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        a, b = x1.to(DEV).contiguous(memory_format=fmt), x2.to(DEV).contiguous(memory_format=fmt)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not fp32):
+            p1, p2 = net.forward_pair(a, b)
+            loss = sum((t.float() ** 2).mean() for t in p1) + 0.5 * sum(t.float().abs().mean() for t in p2)
+        grads = torch.autograd.grad(loss, list(net.parameters())) if train else []
+        res.append(([t.float().cpu() for t in p1 + p2], [g.float().cpu() for g in grads],
+                    {k: v.float().cpu() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}))
+    (o0, g0, s0), (o1, g1, s1) = res
+    tol = 2e-4 if fp32 else 6e-2
+    for u, v in zip(o0, o1):
+        assert float((u - v).abs().max()) <= tol * (float(u.abs().max()) + 1e-3)
+    gmax = max([float(u.abs().max()) for u in g0] + [1e-12])
+    for u, v in zip(g0, g1):  # (the bias of a transposed convolution in front of a BatchNorm has a mathematically zero gradient: 1e-9 noise)
+        # bf16: twelve convolution + BatchNorm layers deep, different library kernels at batch 16 and 8: per cent of the gradient scale
+        assert float((u - v).abs().max()) <= (2e-3 if fp32 else 0.2) * max(float(u.abs().max()), (1e-3 if fp32 else 5e-2) * gmax)
+    for k in s0:
+        np.testing.assert_allclose(s1[k].numpy(), s0[k].numpy(), rtol=1e-4 if fp32 else 2e-2, atol=1e-5 if fp32 else 2e-3, err_msg=k)
+
+
 def _stepper(fused, graph, amp=None, batch=None, steps=6):
     """train `steps` steps of the supervised FlowOccModel step on one fixed batch; returns (losses, parameters)"""
     from ocflow_amd.models.flow_occ_model import FlowOccModel
