@@ -81,13 +81,20 @@ def _conv_nobias(conv: nn.Conv2d, x):
     Opt-in (OCFLOW_NATIVE_WGRAD=1): the first version of that kernel is parity-green and level with MIOpen's kernel + helper launches
     on the large layers (profiles/r2_*_wgrad.txt) but not yet a net win for the whole step."""
     w = _match_in_channels(conv.weight, x.shape[1]) if conv.groups == 1 else conv.weight
-    if _native_wgrad() and ops.conv3x3_wgrad_eligible(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+    mode = _native_wgrad()
+    if mode and (mode == "1" or x.shape[0] * x.shape[2] * x.shape[3] <= _SMALL_PIXELS) and \
+            ops.conv3x3_wgrad_eligible(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
         return ops.conv3x3(x, w, conv.dilation[0])
     return F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
-def _native_wgrad() -> bool:
-    return os.environ.get("OCFLOW_NATIVE_WGRAD", "0") == "1"
+_SMALL_PIXELS = 4096  # B*H*W up to which "small" mode uses the hand-written weight gradient (the two coarsest pyramid levels at B = 8)
+
+
+def _native_wgrad() -> str:
+    """OCFLOW_NATIVE_WGRAD: "0" (default) never, "1" every eligible layer, "small" only layers of at most _SMALL_PIXELS pixels"""
+    v = os.environ.get("OCFLOW_NATIVE_WGRAD", "0")
+    return "" if v == "0" else v
 
 
 def conv_lrelu(conv: nn.Conv2d, x, negative_slope: float = 0.1):
