@@ -32,12 +32,27 @@ def cat_aligned(parts, dim: int = 1):
         pad = -sum(int(t.shape[1]) for t in parts) % CHANNEL_ALIGN
         if pad:
             cl = x0.is_contiguous(memory_format=torch.channels_last)
-            if cl:  # (torch.zeros takes no memory_format: a channels_last view of an NHWC allocation)
-                z = x0.new_zeros((x0.shape[0], x0.shape[2], x0.shape[3], pad)).permute(0, 3, 1, 2)
-            else:
-                z = x0.new_zeros((x0.shape[0], pad, x0.shape[2], x0.shape[3]))
+            z = _zero_channels(x0, pad, cl)
             parts = list(parts) + [z]
     return torch.cat(list(parts), dim)
+
+
+_ZEROS = {}  # (device, dtype, B, pad, H, W, channels_last) -> read-only zero block shared by every concatenation of that shape
+
+
+def _zero_channels(x0, pad, cl):
+    """a [B, pad, H, W] block of zeros in x0's layout.  Never written, so one tensor per shape serves every step (a fill launch per
+    concatenation and step otherwise); it stays allocated for the life of the process (a few MB per pyramid level)."""
+    key = (x0.device, x0.dtype, x0.shape[0], pad, x0.shape[2], x0.shape[3], cl)
+    z = _ZEROS.get(key)
+    if z is None:
+        if cl:  # (torch.zeros takes no memory_format: a channels_last view of an NHWC allocation)
+            z = x0.new_zeros((x0.shape[0], x0.shape[2], x0.shape[3], pad)).permute(0, 3, 1, 2)
+        else:
+            z = x0.new_zeros((x0.shape[0], pad, x0.shape[2], x0.shape[3]))
+        if not torch.cuda.is_current_stream_capturing():
+            _ZEROS[key] = z  # (a tensor created during a graph capture lives in the graph's pool: not shared)
+    return z
 
 
 def _unpadded_cat() -> bool:
