@@ -847,10 +847,17 @@ class _BiasActFn(Function):
             return ((sc == 1 or C_ == 1) and pitch >= C_ and (sh == W * pitch or H == 1 or W == 1)
                     and (sb == H * W * pitch or B == 1 or (H == 1 and W == 1)))
 
+        densify = False
         if passthrough:
             y, gg = None, gy
             if not (gg.is_contiguous() or pixel_major(gg)):
                 gg = gg.contiguous(memory_format=ctx.fmt)  # reduction operand only; the gradient returned stays `gy`
+            elif ctx.fmt == torch.channels_last and not gg.is_contiguous(memory_format=torch.channels_last) and gy.dim() == 4 and C_ > 1 \
+                    and os.environ.get("OCFLOW_NO_DENSIFY", "0") != "1":
+                # a channel slice of a concatenation's gradient (the up-sampling layers feed torch.cat): the consumer of the returned
+                # gradient -- the transposed convolution's backward -- would copy it to a dense tensor first; the reduction pass
+                # reads every element anyway, so it writes that dense copy itself (slope 1: gx = gy) and one launch per site is saved
+                densify = True
         else:
             (y,) = ctx.saved_tensors
             gg = gy if gy.dtype == y.dtype else gy.to(y.dtype)
@@ -858,18 +865,27 @@ class _BiasActFn(Function):
                 gg = gg.contiguous(memory_format=torch.channels_last if _is_cl(y) else torch.contiguous_format)
                 if gg.stride() != y.stride():
                     gg = torch.empty_like(y).copy_(gg)
-        gx = None if passthrough else torch.empty_like(y)
+        if densify:
+            gx = torch.empty(gy.shape, dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
+            y = gx  # (the kernel only looks at the sign of y to pick gy or gy * slope: with slope 1 both are gy)
+        else:
+            gx = None if passthrough else torch.empty_like(y)
         gb = _take_zeros(C_, gy.device) if ctx.needs_input_grad[1] else None
-        if gb is not None or not passthrough:
+        if gb is not None or not passthrough or densify:
             if gb is None:
                 gb = _take_zeros(C_, gy.device)
             with torch.cuda.device(gy.device):
-                _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y), _t4(gg), _t4(gx), C.c_void_p(gb.data_ptr()), B, C_, H, W, ctx.slope, 1,
-                                                        _dtype_code(gg), _stream(gg)),
-                           "ocf_bias_act_bwd")
+                st = _lib.load().ocf_bias_act_bwd(_t4(y), _t4(gg), _t4(gx), C.c_void_p(gb.data_ptr()), B, C_, H, W, ctx.slope, 1,
+                                                  _dtype_code(gg), _stream(gg))
+            if densify and st == _lib.OCF_EUNSUPPORTED:  # a layout the copying form does not take: the pass-through form as before
+                densify, gx = False, None
+                with torch.cuda.device(gy.device):
+                    st = _lib.load().ocf_bias_act_bwd(_t4(None), _t4(gg), _t4(None), C.c_void_p(gb.data_ptr()), B, C_, H, W, ctx.slope, 1,
+                                                      _dtype_code(gg), _stream(gg))
+            _lib.check(st, "ocf_bias_act_bwd")
         if gb is not None and ctx.bias_dtype != torch.float32:
             gb = gb.to(ctx.bias_dtype)
-        return (gy if passthrough else gx), (gb if ctx.needs_input_grad[1] else None), None
+        return (gx if (densify or not passthrough) else gy), (gb if ctx.needs_input_grad[1] else None), None
 
 
 def bias_leaky_relu(x, bias, negative_slope=0.1):
