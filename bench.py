@@ -487,7 +487,13 @@ def main():
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager",
                        "final_loss": round(loss_val, 5),
                        "optimizer": "adam(fused)" if args.fused_adam else "adam(foreach)",
-                       "weights": "fp32 masters + bf16 compute copies" if weights_master else "fp32 (autocast casts per use)"},
+                       "weights": "fp32 masters + bf16 compute copies" if weights_master else "fp32 (autocast casts per use)",
+                       "network_execution": ("reference layers and parameters; same arithmetic, regrouped launches: "
+                                             + ("encoder of both images as one batch with two BatchNorm statistics groups"
+                                                if os.environ.get("OCFLOW_UNPAIRED_FPN", "0") != "1" else "encoder called once per image")
+                                             + "; " + ("decoder-input concatenations zero-padded to a multiple of 32 channels"
+                                                       if os.environ.get("OCFLOW_UNPADDED_CAT", "0") != "1" else "unpadded concatenations")
+                                             + " (DESIGN.md section 10)")},
             "roofline": roofline, "unsupervised": unsup, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
