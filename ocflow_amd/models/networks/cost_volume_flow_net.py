@@ -7,8 +7,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from ocflow_amd import ops
-from ._epilogue import ConvLReLU
+from ._epilogue import ConvLReLU, cat_aligned, conv_bias, deconv_bias
 
 ENC_WIDTHS = (3, 16, 32, 64, 96, 128, 196)
 DENSE_WIDTHS = (128, 128, 96, 64, 32)
@@ -98,6 +100,10 @@ class FlowNetCV(nn.Module):
         return ops.warp(img, flow, align_corners=False)
 
     def forward(self, x):
+        # OCFLOW_PAD_PWC=1: the 32-channel aligned concatenations of the FPN nets here too.  DIAGNOSTIC switch (scripts/diag_fault2.py):
+        # this is the configuration in which round 2 hit a GPU memory fault at 8 x 384 x 512; off by default, see DESIGN.md section 11.
+        pad = os.environ.get("OCFLOW_PAD_PWC", "0") == "1"
+        cat = cat_aligned if pad else torch.cat
         c1 = encode(self, x[:, :3])
         c2 = encode(self, x[:, 3:])
         up_flow = up_feat = flow = feats = None
@@ -111,8 +117,14 @@ class FlowNetCV(nn.Module):
                 feats = corr
             else:
                 # the NORMALISED c1 is what enters the decoder (:190)
-                feats = torch.cat((corr, f1, up_flow.to(corr.dtype), up_feat.to(corr.dtype)), 1)
+                feats = cat((corr, f1, up_flow.to(corr.dtype), up_feat.to(corr.dtype)), 1)
             feats = dense_block(self, lvl, feats)
+            if pad:
+                flow = conv_bias(getattr(self, f"predict_flow{lvl}"), feats)
+                if lvl > 2:
+                    up_flow = deconv_bias(getattr(self, f"deconv{lvl}"), flow)
+                    up_feat = deconv_bias(getattr(self, f"upfeat{lvl}"), feats)
+                continue
             flow = getattr(self, f"predict_flow{lvl}")(feats)
             if lvl > 2:
                 up_flow = getattr(self, f"deconv{lvl}")(flow)

@@ -450,8 +450,86 @@ def gold_inpainting():
     with open(os.path.join(HERE, "state_dict_manifest_inpainting.json"), "w") as f:
         json.dump({"inpaintingnet": manifest}, f)
 
+# ------------------------------------------- 13. FPN nets in TRAIN mode (batch-statistics BatchNorm): what the benchmark trains
+def _grad_pick(g):
+    """a gradient as stored in the fixture: whole when small, otherwise the leading [<=8, <=16, ...] block"""
+    if g.dim() >= 2:
+        return g[:8, :16]
+    return g
+
+
+TRAIN_FPN_GRADS = {
+    "flowoccnet": ("model.feature_pyramid_network.layer1.double_conv.0.weight", "model.feature_pyramid_network.layer1.double_conv.1.weight",
+                   "model.feature_pyramid_network.layer1.double_conv.1.bias", "model.feature_pyramid_network.layer6.double_conv.4.weight",
+                   "model.feature_pyramid_network.layer3.double_conv.3.weight", "model.occlusion_estimators.0.conv1.weight",
+                   "model.occlusion_estimators.4.mask_layer.weight", "model.opticalflow_estimators.4.conv1.weight",
+                   "model.opticalflow_estimators.2.upconv2.bias", "model.context_network.conv4.weight"),
+    "flownet": ("flow_pred.feature_pyramid_network.layer1.double_conv.0.weight", "flow_pred.feature_pyramid_network.layer1.double_conv.1.weight",
+                "flow_pred.feature_pyramid_network.layer2.double_conv.4.bias", "flow_pred.feature_pyramid_network.layer6.double_conv.4.weight",
+                "flow_pred.opticalflow_estimators.0.conv1.weight", "flow_pred.opticalflow_estimators.4.conv6.weight",
+                "flow_pred.opticalflow_estimators.3.upconv1.weight", "flow_pred.context_network.conv2.bias"),
+}
+TRAIN_FPN_BUFFERS = ("feature_pyramid_network.layer1.double_conv.1.running_mean", "feature_pyramid_network.layer1.double_conv.1.running_var",
+                     "feature_pyramid_network.layer6.double_conv.4.running_mean", "feature_pyramid_network.layer6.double_conv.4.running_var",
+                     "feature_pyramid_network.layer6.double_conv.4.num_batches_tracked")
+
+
+def gold_train_fpn():
+    """One TRAINING step of the two feature-pyramid models the benchmark runs (BASELINE configs[1] / the unsupervised leg), B = 2 at
+    128 x 192 so that the coarsest level keeps 2 x 3 pixels per sample: outputs, losses, parameter gradients (a BatchNorm weight and bias
+    among them) and the BatchNorm running statistics AFTER the step (the reference runs the encoder once per image, i.e. two updates
+    per forward: feature_pyramid_net.py:76-93 called at flow_occ_net.py:133-134 / flow_net.py:100-101)."""
+    arrs = {}
+    x = torch.from_numpy(smooth_field((2, 6, 128, 192), seed=101, amp=1.0)).float().clamp(-1, 1)
+    gt_flow = torch.randn((2, 2, 128, 192), generator=g(102)) * 2
+    gt_occ = (torch.rand((2, 1, 128, 192), generator=g(103)) < 0.3).float()
+    # inputs are regenerated by the test from the same seeds (tests/test_train_goldens_gpu.py); their checksums pin the regeneration
+    arrs.update(x_absmean=x.abs().mean(), gt_flow_absmean=gt_flow.abs().mean(), gt_occ_mean=gt_occ.mean())
+
+    # (a) supervised step of FlowOccModel('flowoccnet'): flow_occ_model.py:43-55
+    m = FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"})
+    rngfree_fill(m)
+    m.train()
+    seen = []
+    h = m.model.register_forward_hook(lambda mod, inp, out: seen.append(out))
+    fl_loss, oc_loss = m.general_step((x, gt_flow, gt_occ), 0, "train")
+    h.remove()
+    (fl_loss + oc_loss).backward()
+    fl, oc = seen[0]
+    arrs.update(occ_flow=fl, occ_occ=oc, occ_flow_loss=fl_loss, occ_occ_loss=oc_loss)
+    params = dict(m.named_parameters())
+    for k in TRAIN_FPN_GRADS["flowoccnet"]:
+        arrs["occ_grad__" + k] = _grad_pick(params[k].grad)
+    sd = m.state_dict()
+    for k in TRAIN_FPN_BUFFERS:
+        arrs["occ_buf__" + k] = sd["model." + k]
+
+    # (b) unsupervised occlusion-aware step of FlowStageModel('flownet'): model.py:366-409, config weights of unsupervised_config.yml
+    hp = dict(learning_rate=1e-5, model="flownet", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0,
+              with_occ=False, occ_aware=True)
+    m = ref_model.FlowStageModel(dict(hp))
+    rngfree_fill(m)
+    m.train()
+    seen = []
+    h = m.flow_pred.register_forward_hook(lambda mod, inp, out: seen.append(out))
+    res = m.general_step_occ_aware((x, gt_flow, gt_occ), 0, "train")
+    h.remove()
+    loss = hp["photo_weight"] * res[0] + hp["smooth1_weight"] * res[1] + hp["smooth2_weight"] * res[2]
+    loss.backward()
+    arrs.update(stage_flow=seen[0], stage_back_flow=seen[1], stage_scalars=torch.stack([r.detach() for r in res]), stage_loss=loss)
+    params = dict(m.named_parameters())
+    for k in TRAIN_FPN_GRADS["flownet"]:
+        arrs["stage_grad__" + k] = _grad_pick(params[k].grad)
+    sd = m.state_dict()
+    for k in TRAIN_FPN_BUFFERS:
+        arrs["stage_buf__" + k] = sd["flow_pred." + k]
+    save("train_fpn", **arrs)
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "train_fpn":
+        gold_train_fpn()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         gold_fullsize()
         sys.exit(0)
@@ -478,3 +556,4 @@ if __name__ == "__main__":
     gold_nets()
     gold_fullsize()
     gold_inpainting()
+    gold_train_fpn()
