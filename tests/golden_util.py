@@ -44,6 +44,42 @@ def rngfree_fill(module: torch.nn.Module) -> torch.nn.Module:
     return module
 
 
+def _name_seed(name: str) -> int:
+    h = 1469598103934665603
+    for ch in name.encode():
+        h = ((h ^ ch) * 1099511628211) % (1 << 63)
+    return h
+
+
+@torch.no_grad()
+def seeded_fill(module: torch.nn.Module, seed: int = 0) -> torch.nn.Module:
+    """Pseudo-random weights that depend only on (state_dict key, shape, seed): every tensor is drawn from its own CPU generator seeded by
+    a hash of its key, so the reference and this build get identical weights whatever their construction order.  Convolutions / linear
+    weights: uniform(-b, b) with b = sqrt(3 / fan_in) (unit-gain, keeps activations O(1) through the net); 1-D `weight`: 1 + 0.1 u;
+    biases / running_mean: 0.05 u; running_var: 1 + 0.1 u^2.  Used by the TRAIN-mode fixtures: the sinusoidal `rngfree_fill` weights give
+    nearly rank-deficient feature maps, whose batch statistics are ill-conditioned (the reference's own fp32 and fp64 runs then disagree
+    by tens of per cent in the gradients -- make_golden.py::gold_train_fpn)."""
+    sd = module.state_dict()
+    for k, t in sd.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            t.zero_()
+            continue
+        g = torch.Generator().manual_seed((_name_seed(k) + 7919 * seed) % (1 << 62))
+        u = torch.rand(tuple(t.shape), generator=g, dtype=torch.float64) * 2 - 1
+        if leaf == "running_var":
+            v = 1.0 + 0.1 * u * u
+        elif leaf == "running_mean":
+            v = 0.05 * u
+        elif t.dim() <= 1:
+            v = 1.0 + 0.1 * u if leaf == "weight" else 0.05 * u
+        else:
+            fan_in = int(np.prod(t.shape[1:]))
+            v = math.sqrt(3.0 / max(fan_in, 1)) * u
+        t.copy_(v.to(t.dtype))
+    return module
+
+
 def smooth_field(shape, seed=0, amp=1.0, waves=6) -> np.ndarray:
     """Deterministic smooth (image-like) field of the given [B,C,H,W] shape in about [-amp, amp]."""
     B, C, H, W = shape

@@ -2,13 +2,18 @@
 reference goldens (tests/golden/train_fpn.npz, made by make_golden.py::gold_train_fpn from /root/reference): batch-statistics BatchNorm
 through the HIP kernels with the two images of a pair as ONE batch of two statistics groups (`FeaturePyramidNet.forward_pair`), i.e. the
 regrouped launches the benchmark times -- outputs, losses, parameter gradients (BatchNorm weight / bias among them) and the running
-statistics after the step.  fp32, bar 1e-4 (north_star); reference: feature_pyramid_net.py:5-95, flow_occ_net.py:128-189,
-flow_net.py:89-131, flow_occ_model.py:43-55, models/model.py:366-409."""
+statistics after the step.  fp32; reference: feature_pyramid_net.py:5-95, flow_occ_net.py:128-189, flow_net.py:89-131,
+flow_occ_model.py:43-55, models/model.py:366-409.
+
+Bars: the fixture holds the reference evaluated in fp64 and, per quantity, `__noise` = how far the reference's OWN fp32 run is from that.
+A quantity passes within max(1e-4, 3 x noise) -- 1e-4 is the north_star bar (flow EPE, occlusion L1), the noise term only matters for
+the encoder gradients, which pass through five warped pyramid levels (noise up to 4e-3 of their scale).  Weights: golden_util.seeded_fill
+(the sinusoidal rngfree_fill weights make batch statistics ill-conditioned: see make_golden.py)."""
 import numpy as np
 import pytest
 import torch
 
-from golden_util import rngfree_fill, smooth_field
+from golden_util import seeded_fill, smooth_field
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -37,9 +42,13 @@ def _epe(a, b):
     return float(torch.sqrt(((a.detach().float().cpu() - T(b)) ** 2).sum(1)).mean())
 
 
-def _check_grads(params, g, prefix, tol=1e-4):
-    """every stored gradient within `tol` of the reference, relative to that gradient's own scale"""
-    keys = [k for k in g if k.startswith(prefix)]
+def _bar(g, key, floor=1e-4):
+    return max(floor, 3.0 * float(g[key + "__noise"])) if key + "__noise" in g else floor
+
+
+def _check_grads(params, g, prefix):
+    """every stored gradient within max(1e-4, 3 x the reference's own fp32 noise) of the reference, relative to that gradient's scale"""
+    keys = [k for k in g if k.startswith(prefix) and not k.endswith("__noise")]
     assert len(keys) >= 8
     worst = []
     for k in keys:
@@ -51,19 +60,21 @@ def _check_grads(params, g, prefix, tol=1e-4):
         got = got[:8, :16] if got.dim() >= 2 else got
         assert got.shape == ref.shape, (name, got.shape, ref.shape)
         scale = float(ref.abs().max()) + 1e-12
-        worst.append((float((got - ref).abs().max()) / scale, name))
+        worst.append((float((got - ref).abs().max()) / scale / _bar(g, k), float((got - ref).abs().max()) / scale, name))
     worst.sort(reverse=True)
-    assert worst[0][0] < tol, worst[:4]
+    print("gradients, worst error / bar:", [(round(w[0], 3), f"{w[1]:.2e}", w[2]) for w in worst[:4]])
+    assert worst[0][0] < 1.0, worst[:4]
 
 
 def _check_buffers(sd, g, prefix, root):
-    for k in [k for k in g if k.startswith(prefix)]:
+    for k in [k for k in g if k.startswith(prefix) and not k.endswith("__noise")]:
         name = root + k[len(prefix):]
         got, ref = sd[name].detach().cpu(), T(g[k])
         if ref.dtype in (torch.int64, torch.int32):
             assert int(got) == int(ref), name  # two encoder passes per forward = two updates
         else:
-            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-5, err_msg=name)
+            scale = float(ref.abs().max()) + 1e-12
+            assert float((got - ref).abs().max()) / scale < _bar(g, k), name
 
 
 @pytest.mark.parametrize("fmt", ["nchw", "channels_last"])
@@ -72,15 +83,16 @@ def test_flowoccnet_supervised_train_step_matches_reference(golden, fmt):
     g = golden("train_fpn")
     x, gt_flow, gt_occ = _inputs(g)
     mf = torch.channels_last if fmt == "channels_last" else torch.contiguous_format
-    m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"})).to(DEV).to(memory_format=mf).train()
+    m = seeded_fill(FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"}), 11).to(DEV).to(memory_format=mf).train()
     seen = []
     h = m.model.register_forward_hook(lambda mod, inp, out: seen.append(out))
     fl_loss, oc_loss = m.general_step((x.to(DEV).contiguous(memory_format=mf), gt_flow.to(DEV), gt_occ.to(DEV)), 0, "train")
     h.remove()
     (fl_loss + oc_loss).backward()
     fl, oc = seen[0]
-    assert _epe(fl, g["occ_flow"]) < 1e-4
-    assert float((oc.detach().float().cpu() - T(g["occ_occ"])).abs().mean()) < 1e-4
+    e_flow, e_occ = _epe(fl, g["occ_flow"]), float((oc.detach().float().cpu() - T(g["occ_occ"])).abs().mean())
+    print(f"flowoccnet train step [{fmt}]: flow EPE {e_flow:.2e}, occlusion L1 {e_occ:.2e}")
+    assert e_flow < _bar(g, "occ_flow") and e_occ < _bar(g, "occ_occ")
     assert abs(float(fl_loss) - float(g["occ_flow_loss"])) < 1e-4 * max(1.0, abs(float(g["occ_flow_loss"])))
     assert abs(float(oc_loss) - float(g["occ_occ_loss"])) < 1e-4 * max(1.0, abs(float(g["occ_occ_loss"])))
     _check_grads(dict(m.named_parameters()), g, "occ_grad__")
@@ -95,13 +107,15 @@ def test_flownet_occlusion_aware_train_step_matches_reference(golden, fmt):
     mf = torch.channels_last if fmt == "channels_last" else torch.contiguous_format
     hp = dict(learning_rate=1e-5, model="flownet", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0,
               with_occ=False, occ_aware=True)
-    m = rngfree_fill(FlowStageModel(hp)).to(DEV).to(memory_format=mf).train()
+    m = seeded_fill(FlowStageModel(hp), 11).to(DEV).to(memory_format=mf).train()
     seen = []
     h = m.flow_pred.register_forward_hook(lambda mod, inp, out: seen.append(out))
     batch = (x.to(DEV).contiguous(memory_format=mf), gt_flow.to(DEV), gt_occ.to(DEV))
     res = m.general_step_occ_aware(batch, 0, "train")
     h.remove()
-    assert _epe(seen[0], g["stage_flow"]) < 1e-4 and _epe(seen[1], g["stage_back_flow"]) < 1e-4
+    e_f, e_b = _epe(seen[0], g["stage_flow"]), _epe(seen[1], g["stage_back_flow"])
+    print(f"flownet occlusion-aware train step [{fmt}]: forward-flow EPE {e_f:.2e}, backward-flow EPE {e_b:.2e}")
+    assert e_f < _bar(g, "stage_flow") and e_b < _bar(g, "stage_back_flow")
     np.testing.assert_allclose(torch.stack([r.detach() for r in res]).float().cpu().numpy(), g["stage_scalars"], rtol=1e-4, atol=1e-5)
     loss = hp["photo_weight"] * res[0] + hp["smooth1_weight"] * res[1] + hp["smooth2_weight"] * res[2]
     assert abs(float(loss) - float(g["stage_loss"])) < 1e-4 * max(1.0, abs(float(g["stage_loss"])))
@@ -110,15 +124,67 @@ def test_flownet_occlusion_aware_train_step_matches_reference(golden, fmt):
     _check_buffers(m.state_dict(), g, "stage_buf__", "flow_pred.")
 
 
+@pytest.mark.parametrize("fmt", ["nchw", "channels_last"])
+def test_feature_pyramid_train_mode_matches_reference(golden, fmt):
+    """the encoder alone: `forward_pair` (one batch of two statistics groups through the HIP BatchNorm kernels in channels_last; two calls
+    in NCHW) against the reference module called on the two images in turn -- pyramids, EVERY BatchNorm parameter gradient, convolution
+    gradients and every running buffer after the step (reference noise here: 1.2e-5 at worst)"""
+    from ocflow_amd.models.networks.feature_pyramid_net import FeaturePyramidNet
+    g = golden("train_fpn")
+    x, _, _ = _inputs(g)
+    mf = torch.channels_last if fmt == "channels_last" else torch.contiguous_format
+    fpn = seeded_fill(FeaturePyramidNet(), 11).to(DEV).to(memory_format=mf).train()
+    xd = x.to(DEV)
+    p1, p2 = fpn.forward_pair(xd[:, :3].contiguous(memory_format=mf), xd[:, 3:].contiguous(memory_format=mf))
+    loss = sum((a * a).mean() + (a * b).mean() for a, b in zip(p1, p2))
+    loss.backward()
+    bar = max(1e-4, 3.0 * float(g["fpn__noise"]))
+    assert abs(float(loss) - float(g["fpn_loss"])) < bar * abs(float(g["fpn_loss"]))
+    worst = []
+    for lvl, (a, b) in zip((6, 5, 4, 3, 2), zip(p1, p2)):
+        for tag, t in (("p1", a), ("p2", b)):
+            ref = T(g[f"fpn_{tag}_l{lvl}"])
+            worst.append((float((t.detach().float().cpu()[:, :16] - ref).abs().max()) / (float(ref.abs().max()) + 1e-12), f"{tag}_l{lvl}"))
+    params = dict(fpn.named_parameters())
+    n_bn = 0
+    for k in [k for k in g if k.startswith("fpn_grad__")]:
+        name = k[len("fpn_grad__"):]
+        got, ref = params[name].grad.detach().float().cpu(), T(g[k])
+        got = got[:8, :16] if got.dim() >= 2 else got
+        n_bn += got.dim() == 1
+        worst.append((float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-12), "grad " + name))
+    sd = fpn.state_dict()
+    for k in [k for k in g if k.startswith("fpn_buf__")]:
+        name = k[len("fpn_buf__"):]
+        got, ref = sd[name].detach().cpu(), T(g[k])
+        if ref.dtype in (torch.int64, torch.int32):
+            assert int(got) == int(ref) == 2, name
+        else:
+            worst.append((float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-12), "buffer " + name))
+    assert n_bn >= 30  # weight and bias of all 17 BatchNorm layers
+    worst.sort(reverse=True)
+    print(f"encoder train mode [{fmt}]: worst relative errors", [(f"{w[0]:.2e}", w[1]) for w in worst[:4]], "bar", bar)
+    assert worst[0][0] < bar, worst[:5]
+
+
+def _cos_ratio(a, b):
+    a, b = a.flatten().double(), b.flatten().double()
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)), float(b.norm() / (a.norm() + 1e-300))
+
+
 def test_bf16_pairing_and_padding_track_their_own_fp32_run(golden):
     """the throughput configuration (bf16 autocast, channels_last, paired encoder, 32-channel aligned concatenations) against an fp32 run of
-    the SAME regrouping: outputs and the stored gradients differ only by bf16 rounding (a statistics or channel-mapping error would be O(1))."""
+    the SAME regrouping.  What is compared is what bf16 can resolve: outputs and losses of the whole model, the gradients of its last
+    layers (context network, finest estimators: short backward paths), and -- in the encoder-only run below -- every encoder gradient.
+    (Through the five warped pyramid levels a bf16 backward pass of this untrained net decorrelates: cosine 0.75-0.9 for the encoder
+    gradients at B = 2, 128 x 192, measured; a statistics-group or channel-mapping error shows up in the quantities checked here as
+    O(1).)"""
     from ocflow_amd.models.flow_occ_model import FlowOccModel
     g = golden("train_fpn")
     x, gt_flow, gt_occ = _inputs(g)
     runs = []
     for amp in (False, True):
-        m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"})).to(DEV).to(memory_format=torch.channels_last).train()
+        m = seeded_fill(FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"}), 11).to(DEV).to(memory_format=torch.channels_last).train()
         seen = []
         h = m.model.register_forward_hook(lambda mod, inp, out: seen.append(out))
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
@@ -128,18 +194,41 @@ def test_bf16_pairing_and_padding_track_their_own_fp32_run(golden):
         runs.append((seen[0][0].detach().float(), seen[0][1].detach().float(), float(fl_loss), float(oc_loss),
                      {k: p.grad.detach().float() for k, p in m.named_parameters() if p.grad is not None}))
     (f0, o0, l0, c0, g0), (f1, o1, l1, c1, g1) = runs
+    print(f"bf16 vs fp32 (same regrouping): flow mean abs diff {float((f0 - f1).abs().mean()):.3e} of {float(f0.abs().mean()):.3e}, "
+          f"occlusion {float((o0 - o1).abs().mean()):.3e}, losses {l0:.5f}/{l1:.5f} {c0:.5f}/{c1:.5f}")
     assert float((f0 - f1).abs().mean()) < 0.02 * float(f0.abs().mean()) + 0.02
     assert float((o0 - o1).abs().mean()) < 0.02
     assert abs(l0 - l1) < 0.02 * abs(l0) + 1e-3 and abs(c0 - c1) < 0.03 * abs(c0) + 1e-3
-    # gradients: direction and size.  (bf16 element errors are amplified through five warped pyramid levels; cosine similarity and the
-    # norm ratio are what a wrong statistics group or a shifted channel would break)
-    bad = []
-    for k in g0:
-        a, b = g0[k].flatten(), g1[k].flatten()
-        if float(a.norm()) < 1e-8:
-            continue
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
-        ratio = float(b.norm() / a.norm())
-        if cos < 0.9 or not (0.8 < ratio < 1.25):
-            bad.append((k, round(cos, 3), round(ratio, 3)))
-    assert len(bad) <= max(2, len(g0) // 50), bad[:10]
+    late = [k for k in g0 if k.startswith("model.context_network.") or k.startswith("model.opticalflow_estimators.4.conv6")
+            or k.startswith("model.occlusion_estimators.4.mask_layer")]
+    assert len(late) >= 16
+    stats = sorted((_cos_ratio(g0[k], g1[k]) + (k,) for k in late if float(g0[k].norm()) > 1e-8))
+    print("late-layer gradients, lowest cosines:", [(round(c, 4), round(r, 3), k) for c, r, k in stats[:3]])
+    assert stats[0][0] > 0.97 and all(0.9 < r < 1.1 for _, r, _ in stats), stats[:4]
+
+
+def test_bf16_paired_encoder_tracks_fp32(golden):
+    """encoder only, TRAIN mode: bf16 autocast through `forward_pair` (HIP BatchNorm kernels, two statistics groups) against the fp32 run of
+    the same call -- every parameter gradient keeps its direction (cosine) and size, pyramids agree to bf16 resolution.  (The fp32 run
+    itself is pinned to the reference by test_feature_pyramid_train_mode_matches_reference.)"""
+    from ocflow_amd.models.networks.feature_pyramid_net import FeaturePyramidNet
+    g = golden("train_fpn")
+    x, _, _ = _inputs(g)
+    xd = x.to(DEV)
+    a1, a2 = xd[:, :3].contiguous(memory_format=torch.channels_last), xd[:, 3:].contiguous(memory_format=torch.channels_last)
+    runs = []
+    for amp in (False, True):
+        fpn = seeded_fill(FeaturePyramidNet(), 11).to(DEV).to(memory_format=torch.channels_last).train()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            p1, p2 = fpn.forward_pair(a1, a2)
+        loss = sum((a.float() * a.float()).mean() + (a.float() * b.float()).mean() for a, b in zip(p1, p2))
+        loss.backward()
+        runs.append(([t.detach().float() for t in p1 + p2], float(loss),
+                     {k: p.grad.detach().float() for k, p in fpn.named_parameters() if p.grad is not None and not k.endswith("deconv.bias")}))
+    (pyr0, l0, g0), (pyr1, l1, g1) = runs
+    rel = max(float((a - b).abs().mean()) / (float(a.abs().mean()) + 1e-12) for a, b in zip(pyr0, pyr1))
+    stats = sorted(_cos_ratio(g0[k], g1[k]) + (k,) for k in g0)
+    print(f"bf16 paired encoder vs fp32: worst pyramid mean-abs deviation {rel:.3e}, loss {l0:.5f}/{l1:.5f}; lowest gradient cosines:",
+          [(round(c, 4), round(r, 3), k) for c, r, k in stats[:3]])
+    assert rel < 0.03 and abs(l0 - l1) < 0.01 * abs(l0)
+    assert len(stats) >= 45 and stats[0][0] > 0.98 and all(0.93 < r < 1.07 for _, r, _ in stats), stats[:4]
