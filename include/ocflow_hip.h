@@ -2,7 +2,8 @@
  *
  * Every entry point is a stream-ordered launcher: plain device pointers + explicit element
  * strides + sizes + a hipStream_t passed as void*.  No torch types, no allocation, no host
- * synchronisation, re-entrant, graph-capturable.  Return value: 0 = OCF_OK, negative = error
+ * synchronisation, RE-ENTRANT (no process-wide state: where a request can be served by several
+ * kernels the choice is a per-call `policy` argument, 0 = automatic), graph-capturable.  Return value: 0 = OCF_OK, negative = error
  * (never throws).  Each function names the reference interface (file:line under the OCFlow
  * tree) it replaces; the reference-side binding is shown in INTEGRATION.md.
  *
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCF_ABI_VERSION 1
+#define OCF_ABI_VERSION 2 /* 2: per-call kernel policies replace the process-wide ocf_*_select switches of version 1 */
 #define OCF_MAX_DISPLACEMENT 4
 
 enum ocf_dtype { OCF_F32 = 0, OCF_BF16 = 1 };
@@ -74,14 +75,24 @@ int ocf_stream_capture_id(void* stream, unsigned long long* id);
  * d <= OCF_MAX_DISPLACEMENT.  out has (2d+1)^2 channels and element type `dtype`. */
 int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                  const ocf_tensor4* out, int B, int C, int H, int W, int d, float flow_scale, int align_corners,
-                 int dtype, void* stream);
+                 int dtype, int policy /* enum ocf_corr_policy */, void* stream);
 
+/* Kernel selection of ocf_corr_fwd for bf16, PER CALL (results are the same under every policy, only the kernel differs -- for A/B
+ * measurements and for testing the kernels the automatic choice would not pick). */
+enum ocf_corr_policy {
+  OCF_CORR_POLICY_AUTO = 0,
+  OCF_CORR_POLICY_BAND_ONLY = 1, /* the band-GEMM kernels for everything                                      */
+  OCF_CORR_POLICY_NO_WAVE = 2,   /* automatic choice without the wave kernel (row / direct / band kernels)   */
+  OCF_CORR_POLICY_WAVE = 3       /* the wave kernel whenever its preconditions hold (also for C <= 64)       */
+};
 /* Diagnostics: which kernel ocf_corr_fwd launches for a request (same arguments, nothing is launched).  The parity tests assert
  * that every instantiation the benchmark times is the one they value-check. */
 enum ocf_corr_variant {
   OCF_CORR_ROWS_K1 = 1,         /* bf16 row kernel, one 32-channel block   (dense channels_last, d = 4, C <= 32)  */
   OCF_CORR_ROWS_K2 = 2,         /* bf16 row kernel, two blocks resident    (dense channels_last, d = 4, C <= 64)  */
   OCF_CORR_DIRECT = 3,          /* bf16 direct kernel: fragments straight from global memory (d = 4, 64 < C <= 128, or <= 224 for W <= 16) */
+  OCF_CORR_WAVE = 4,            /* bf16 wave kernel: one wave per (row, strip, dy), no LDS; small levels (C > 64), any output pixel pitch,
+                                   optional in-register warp of the second operand (d = 4, C <= 224)                                   */
   OCF_CORR_BAND_TH8 = 11,       /* bf16 band-GEMM kernel, C <= 32, 32x8 tiles, persistent multi-tile walk         */
   OCF_CORR_BAND_MULTI_TH4 = 12, /* bf16 band-GEMM kernel, C > 32, 4-row tiles                                      */
   OCF_CORR_BAND_MULTI_TH2 = 13, /*   ... 2-row tiles (fewer 4-row tiles than CUs)                                  */
@@ -89,18 +100,29 @@ enum ocf_corr_variant {
   OCF_CORR_VECTOR_F32 = 20      /* fp32 vector-ALU kernel                                                          */
 };
 int ocf_corr_fwd_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
-                         const ocf_tensor4* out, int B, int C, int H, int W, int d, int dtype);
-/* Kernel selection policy of ocf_corr_fwd for bf16 (process-wide; results are the same under every policy, only the kernel
- * differs -- for A/B measurements and for testing the kernels the automatic choice would not pick). */
-enum ocf_corr_policy { OCF_CORR_POLICY_AUTO = 0, OCF_CORR_POLICY_BAND_ONLY = 1 };
-int ocf_corr_fwd_select(int policy);
+                         const ocf_tensor4* out, int B, int C, int H, int W, int d, int dtype, int policy);
 
 /* gradient of the plain cost volume w.r.t. both operands (w2 materialised by the caller):
  *   g1[b,c,y,x] = 1/C sum_k gout[b,k,y,x]       * w2[b,c,y+dy,x+dx]
  *   g2[b,c,y,x] = 1/C sum_k gout[b,k,y-dy,x-dx] * f1[b,c,y-dy,x-dx]
  * replaces: autograd of correlation_layer.py:33-39 (81 x MulBackward/MeanBackward + CatBackward) */
+enum ocf_corr_bwd_policy {
+  OCF_CORR_BWD_POLICY_AUTO = 0,
+  OCF_CORR_BWD_POLICY_VECTOR = 1, /* the vector-ALU kernels only                                                                          */
+  OCF_CORR_BWD_POLICY_MFMA = 2    /* the matrix-core band-GEMM kernel whenever its preconditions hold (bf16, d = 4, channel-contiguous
+                                     operands, 8-byte aligned pixels) -- what the automatic choice does as well                            */
+};
+enum ocf_corr_bwd_variant {
+  OCF_CORR_BWD_MFMA = 1,    /* corr_bwd_mfma.hip: band GEMMs on the matrix cores */
+  OCF_CORR_BWD_TILED16 = 2, /* corr.hip LDS-tiled vector kernel, 16-byte units   */
+  OCF_CORR_BWD_TILED8 = 3,  /*   ... 8-byte units (C = 196 bf16)                 */
+  OCF_CORR_BWD_GATHER = 4   /* global-memory gather kernel (strided layouts)     */
+};
 int ocf_corr_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* gout, const ocf_tensor4* g1,
-                 const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, void* stream);
+                 const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, int policy, void* stream);
+/* which kernel (enum ocf_corr_bwd_variant) ocf_corr_bwd / ocf_corr_occ_bwd launch for a request; nothing is launched */
+int ocf_corr_bwd_variant(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* gout, const ocf_tensor4* g1,
+                         const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, int policy);
 
 /* the same with the occlusion mask of the forward (out = corr(f1, w2 * occ), occ fp32 [B,1,H,W]) folded in: `w2` is the UNMASKED
  * operand, the product w2*occ is formed while staging, g2 is the gradient w.r.t. w2 (= d/d(w2*occ) * occ) and
@@ -110,7 +132,7 @@ int ocf_corr_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4
  * replaces: autograd of `self.corr(f1, warped * occ)` flow_occ_net.py:167-168, cost_volume_flow_occ_net.py:204-206 */
 int ocf_corr_occ_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* occ, const ocf_tensor4* gout,
                      const ocf_tensor4* g1, const ocf_tensor4* g2, const ocf_tensor4* gocc, int B, int C, int H, int W, int d,
-                     int dtype, void* stream);
+                     int dtype, int policy, void* stream);
 
 /* ---- K2  backward bilinear warp (zeros padding), both align_corners variants --------------
  * out[b,c,y,x] = bilinear(img[b,c], px, py), neighbours outside the image contribute 0
@@ -125,18 +147,18 @@ int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tens
  *         kernel pair (channels_last, >= 1M (pixel, channel) pairs) overwrites it: ocf_warp_bwd_plan() says which (bit 0 of its
  *         result = "zero grad_img first"; a caller that always zeroes is always correct);
  * gflow : fp32 [B,2,H,W], written (gradient w.r.t. the UNSCALED flow, i.e. includes s). */
+/* Kernel selection of ocf_warp_bwd for channels_last operands, per call (same results up to float summation order; the SAME policy must
+ * be given to ocf_warp_bwd_plan and to ocf_warp_bwd -- both evaluate one decision function, grid limits included):
+ * AUTO = the gather kernel (per-destination-pixel lists in LDS, plain stores; sources whose taps lie within 6 pixels) + the per-source kernel
+ *     (grad_flow, float atomics for the remaining far sources) when the tensor has >= 1M (pixel, channel) pairs, else the scatter kernel;
+ * SCATTER = scatter kernel (global float atomics) always;  GATHER = gather pair whenever the layout allows -- for A/B measurements and
+ * for testing both paths at any size. */
+enum ocf_warp_bwd_policy { OCF_WARP_BWD_POLICY_AUTO = 0, OCF_WARP_BWD_POLICY_SCATTER = 1, OCF_WARP_BWD_POLICY_GATHER = 2 };
 int ocf_warp_bwd_plan(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C, int H,
-                      int W, int dtype);
+                      int W, int dtype, int policy);
 int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
                  const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners, int dtype,
-                 void* stream);
-
-/* Kernel selection of ocf_warp_bwd for channels_last operands (process-wide; same results up to float summation order):
- * 0 = automatic: the gather kernel (per-destination-pixel lists in LDS, plain stores; sources whose taps lie within 6 pixels) + the
- *     per-source kernel (grad_flow, float atomics for the remaining far sources) when the tensor has >= 1M (pixel, channel) pairs,
- *     else the scatter kernel;  1 = scatter kernel (global float atomics) always;  2 = gather pair whenever the layout allows
- * -- for A/B measurements and for testing both paths at any size. */
-int ocf_warp_bwd_select(int policy);
+                 int policy, void* stream);
 
 /* Deterministic variant: the same contributions accumulated through 64-bit fixed-point integer atomics
  * (2^-36 resolution, |sum| < 1.3e8) in a caller-provided workspace of ocf_warp_bwd_det_workspace_bytes() bytes (zeroed by the
@@ -185,12 +207,11 @@ int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const f
  * occ = 1 - clamp(range, 0, 1) (written when occ != NULL).  range/occ: contiguous fp32 [B,1,H,W];
  * range is zeroed by the launcher.
  * replaces: flow_to_warp + compute_range_map  models/model.py:223-305 (dup flow_model.py:81-163), model.py:391 */
-int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, int B, int H, int W, void* stream);
-
-/* kernel selection (process-wide, same results up to float summation order): 1 = LDS-window splat (default: 99 us at 8 x 436 x 1024),
- * 0 = per-pixel gather through LDS lists + float atomics for sources displaced by more than 8 pixels (137 us; its near-source part
- * is bit-reproducible) */
-int ocf_range_map_select(int policy);
+/* policy (per call, same results up to float summation order): AUTO / SPLAT = LDS-window splat (99 us at 8 x 436 x 1024), GATHER =
+ * per-pixel gather through LDS lists + float atomics for sources displaced by more than 8 pixels (137 us; its near-source part is
+ * bit-reproducible) */
+enum ocf_range_policy { OCF_RANGE_POLICY_AUTO = 0, OCF_RANGE_POLICY_SPLAT = 1, OCF_RANGE_POLICY_GATHER = 2 };
+int ocf_range_map(const ocf_tensor4* flow, float* range, float* occ, int B, int H, int W, int policy, void* stream);
 /* deterministic variant (fixed-point integer atomics, see ocf_warp_bwd_det); workspace: ocf_range_map_det_workspace_bytes() */
 int ocf_range_map_det_workspace_bytes(int B, int H, int W, int64_t* bytes);
 int ocf_range_map_det(const ocf_tensor4* flow, float* range, float* occ, void* workspace, int B, int H, int W, void* stream);
@@ -248,8 +269,10 @@ int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tens
  * per-layer fp32 workspace fill + bf16 cast.
  * replaces: the weight half of autograd's convolution_backward for conv() / nn.Conv2d(k=3, s=1, p=d, dilation=d) in
  *           flow_net.py:11-37, flow_occ_net.py:11-67, context_net.py:11-17, cost_volume_flow_net.py:58-112 */
+/* policy (per call; same results up to float summation order): 0 = automatic, 1 = register-staged kernel, 2 = LDS-DMA three-stage ring
+ * kernel (eight-wave workgroups, two Ci blocks per workgroup) */
 int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky, int64_t gw_skx,
-                      int B, int Ci, int Co, int H, int W, int dilation, int dtype, void* stream);
+                      int B, int Ci, int Co, int H, int W, int dilation, int dtype, int policy, void* stream);
 
 /* ---- BatchNorm2d (batch statistics) + LeakyReLU of the feature-pyramid encoder
  * replaces: nn.BatchNorm2d + nn.LeakyReLU(0.1) of the reference's `conv_bn_relu` blocks (models/networks/feature_pyramid_net.py:5-95), i.e.
@@ -271,15 +294,6 @@ int ocf_bn_act_fwd(const ocf_tensor4* x, const ocf_tensor4* y, const float* gamm
 int ocf_bn_act_bwd(const ocf_tensor4* x, const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, const float* gamma,
                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, int B, int C, int H, int W,
                    float negative_slope, int groups, int dtype, void* stream);
-
-/* kernel choice of ocf_corr_bwd / ocf_corr_occ_bwd (process-wide; same results up to float summation order): 0 = automatic, 1 = the
- * vector kernel only, 2 = the matrix-core band-GEMM kernel whenever its preconditions hold (bf16, d = 4, channel-contiguous operands,
- * 8-byte aligned pixels) */
-int ocf_corr_bwd_select(int policy);
-
-/* kernel version of ocf_conv3x3_wgrad (process-wide; same results up to float summation order): 0 = automatic, 1 = register-staged kernel,
- * 2 = LDS-DMA three-stage ring kernel (eight-wave workgroups, two Ci blocks per workgroup) */
-int ocf_conv3x3_wgrad_select(int policy);
 
 #ifdef __cplusplus
 }

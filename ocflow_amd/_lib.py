@@ -17,7 +17,14 @@ import torch  # noqa: F401  (load order, not an API dependency: the C ABI has no
 
 from . import build as _build
 
+ABI_VERSION = 2  # include/ocflow_hip.h OCF_ABI_VERSION
 OCF_F32, OCF_BF16 = 0, 1
+# per-call kernel policies (enum ocf_corr_policy, ocf_corr_bwd_policy, ocf_warp_bwd_policy, ocf_range_policy of the header)
+CORR_AUTO, CORR_BAND_ONLY, CORR_NO_WAVE, CORR_WAVE = 0, 1, 2, 3
+CORR_VARIANT_WAVE = 4  # enum ocf_corr_variant
+CORR_BWD_AUTO, CORR_BWD_VECTOR, CORR_BWD_MFMA = 0, 1, 2
+WARP_BWD_AUTO, WARP_BWD_SCATTER, WARP_BWD_GATHER = 0, 1, 2
+RANGE_AUTO, RANGE_SPLAT, RANGE_GATHER = 0, 1, 2
 OCF_OK = 0
 OCF_EUNSUPPORTED = -2
 
@@ -35,18 +42,16 @@ SIGNATURES = {
     "ocf_device_info": [C.c_char_p, _i, C.POINTER(_i)],
     "ocf_profile_next_launch": [_vp, _vp],
     "ocf_stream_capture_id": [_vp, C.POINTER(C.c_ulonglong)],
-    "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
-    "ocf_corr_fwd_variant": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i],
-    "ocf_corr_fwd_select": [_i],
-    "ocf_corr_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
-    "ocf_corr_occ_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
+    "ocf_corr_fwd_variant": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i],
+    "ocf_corr_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_corr_bwd_variant": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i],
+    "ocf_corr_occ_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_warp_fwd": [_T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
-    "ocf_warp_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
-    "ocf_warp_bwd_select": [_i],
-    "ocf_warp_bwd_plan": [_T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i],
+    "ocf_warp_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
+    "ocf_warp_bwd_plan": [_T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i],
     "ocf_warp_bwd_det_workspace_bytes": [_i, _i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_warp_bwd_det": [_T4P, _T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
-    "ocf_range_map_select": [_i],
     "ocf_range_map_det_workspace_bytes": [_i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_range_map_det": [_T4P, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ocf_photo_loss_fwd": [_T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
@@ -55,15 +60,13 @@ SIGNATURES = {
     "ocf_masked_l1_bwd": [_T4P, _T4P, _T4P, _vp, _T4P, _i, _i, _i, _i, _vp],
     "ocf_smooth_loss_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _f, _vp],
     "ocf_smooth_loss_bwd": [_T4P, _T4P, _vp, _T4P, _i, _i, _i, _i, _f, _vp],
-    "ocf_range_map": [_T4P, _vp, _vp, _i, _i, _i, _vp],
+    "ocf_range_map": [_T4P, _vp, _vp, _i, _i, _i, _i, _vp],
     "ocf_moments": [_T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_ssim_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_ssim_bwd_workspace_bytes": [_i, _i, _i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_ssim_bwd": [_T4P, _T4P, _vp, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_sqdiff": [_T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
-    "ocf_conv3x3_wgrad": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "ocf_conv3x3_wgrad_select": [_i],
-    "ocf_corr_bwd_select": [_i],
+    "ocf_conv3x3_wgrad": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_bias_act_fwd": [_T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ocf_bn_act_workspace_bytes": [_i, _i, C.POINTER(C.c_int64)],
@@ -101,12 +104,9 @@ def load():
             fn.restype = C.c_int
         lib.ocf_status_string.argtypes = [C.c_int]
         lib.ocf_status_string.restype = C.c_char_p
-        # kernel-choice knobs for A/B runs of a whole model (same results; see the *_select entries of include/ocflow_hip.h)
-        for env, fn in (("OCFLOW_WARP_BWD_POLICY", lib.ocf_warp_bwd_select), ("OCFLOW_CORR_BWD_POLICY", lib.ocf_corr_bwd_select),
-                        ("OCFLOW_RANGE_MAP_POLICY", lib.ocf_range_map_select), ("OCFLOW_WGRAD_POLICY", lib.ocf_conv3x3_wgrad_select)):
-            if os.environ.get(env):
-                if fn(int(os.environ[env])) != OCF_OK:
-                    raise RuntimeError(f"ocflow_amd: {env}={os.environ[env]} is not a valid policy")
+        if lib.ocf_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"ocflow_amd: {path} implements ABI version {lib.ocf_abi_version()}, this package binds version {ABI_VERSION} "
+                               "(stale build: python -m ocflow_amd.build --force)")
         _lib = lib
     return _lib
 

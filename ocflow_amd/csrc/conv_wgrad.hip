@@ -276,15 +276,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_v2_kernel(const char* __
   }
 }
 
-static int g_wgrad_policy = 0;  // ocf_conv3x3_wgrad_select: 0 = automatic, 1 = version 1 (register staging), 2 = version 2 (LDS-DMA ring)
-
 }  // namespace ocf
 
 extern "C" int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky,
-                                 int64_t gw_skx, int B, int Ci, int Co, int H, int W, int dilation, int dtype, void* stream) {
+                                 int64_t gw_skx, int B, int Ci, int Co, int H, int W, int dilation, int dtype, int policy, void* stream) {
   using namespace ocf;
   clear_stale_error();
   if (!x || !gy || !gw || !x->data || !gy->data) return OCF_EINVAL;
+  if (policy < 0 || policy > 2) return OCF_EINVAL;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || dilation < 1) return OCF_EINVAL;
   if (dtype != OCF_BF16 || dilation > wg::MAXD || Ci % 8 != 0 || Co % 8 != 0) return OCF_EUNSUPPORTED;
   // dense channels_last operands with 16-byte aligned pixels
@@ -295,7 +294,7 @@ extern "C" int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, fl
   if ((long)B * H * W * (long)(Ci > Co ? Ci : Co) * 2 >= (1L << 40)) return OCF_EUNSUPPORTED;
   // automatic = version 1: measured at the benchmark's layer shapes (profiles/r2_d_wgrad_v2.txt) the ring kernel is DMA-throughput and
   // LDS-read bound where version 1 is latency bound, and ends up within +-10 % of it; it stays selectable for tuning
-  const bool v2 = g_wgrad_policy == 2;
+  const bool v2 = policy == 2;
   const int cib = v2 ? (Ci + 63) / 64 : (Ci + 31) / 32, cog = (Co + 127) / 128;
   const int nrows = B * H;
   // split-K factor: every row chunk adds a full copy of dW with float atomics (~1.3 TB/s chip-wide), while fewer than ~2 workgroups
@@ -333,10 +332,4 @@ extern "C" int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, fl
   lp.launch(true, conv3x3_wgrad_kernel, dim3((unsigned)(chunks * cib), (unsigned)cog), dim3(256), 0, (hipStream_t)stream, (const char*)x->data,
             (const char*)gy->data, gw, (long)gw_so, (long)gw_si, (long)gw_sky, (long)gw_skx, B, Ci, Co, H, W, dilation, rpc);
   return launch_status();
-}
-
-extern "C" int ocf_conv3x3_wgrad_select(int policy) {
-  if (policy < 0 || policy > 2) return OCF_EINVAL;
-  ocf::g_wgrad_policy = policy;
-  return OCF_OK;
 }

@@ -629,13 +629,30 @@ static int corr_fwd_t(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_te
 #undef OCF_DISPATCH
 }
 
+// which kernel a backward request gets (enum ocf_corr_bwd_variant); shared by the launcher and by ocf_corr_bwd_variant
+template <typename T>
+static int corr_bwd_variant_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* g, const ocf_tensor4* g1, const ocf_tensor4* g2,
+                              int B, int C, int H, int W, int d, int policy) {
+  constexpr int U = Unit<T>::U;
+  if (sizeof(T) == 2 && corr_bwd_mfma_eligible(f1, w2, g, g1, g2, B, C, H, W, d, policy)) return OCF_CORR_BWD_MFMA;
+  bool vec = vec_ok<T>(f1) && vec_ok<T>(w2);
+  if (g1) vec = vec && vec_ok<T>(g1);
+  if (g2) vec = vec && vec_ok<T>(g2);
+  if (vec && C % U == 0 && g->sc == 1) return OCF_CORR_BWD_TILED16;
+  int v8 = min_vec(vec_width<T>(f1), vec_width<T>(w2));
+  if (g1) v8 = min_vec(v8, vec_width<T>(g1));
+  if (g2) v8 = min_vec(v8, vec_width<T>(g2));
+  if (v8 >= 8 && (C * (long)sizeof(T)) % 8 == 0 && g->sc == 1) return OCF_CORR_BWD_TILED8;
+  return OCF_CORR_BWD_GATHER;
+}
+
 template <typename T>
 static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* g, const ocf_tensor4* g1,
-                      const ocf_tensor4* g2, int B, int C, int H, int W, int d, hipStream_t st, const ocf_tensor4* occ = nullptr,
+                      const ocf_tensor4* g2, int B, int C, int H, int W, int d, int policy, hipStream_t st, const ocf_tensor4* occ = nullptr,
                       const ocf_tensor4* gocc = nullptr) {
   constexpr int U = Unit<T>::U;
   if (gocc && hipMemsetAsync(gocc->data, 0, sizeof(float) * (size_t)B * H * W, st) != hipSuccess) return OCF_ELAUNCH;
-  if (sizeof(T) == 2 && corr_bwd_mfma_eligible(f1, w2, g, g1, g2, B, C, H, W, d))
+  if (sizeof(T) == 2 && corr_bwd_mfma_eligible(f1, w2, g, g1, g2, B, C, H, W, d, policy))
     return corr_bwd_bf16_mfma(f1, w2, g, g1, g2, B, C, H, W, st, occ, gocc);
   bool vec = vec_ok<T>(f1) && vec_ok<T>(w2);
   if (g1) vec = vec && vec_ok<T>(g1);
@@ -673,64 +690,73 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
 
 extern "C" int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                             const ocf_tensor4* out, int B, int C, int H, int W, int d, float flow_scale, int align_corners,
-                            int dtype, void* stream) {
+                            int dtype, int policy, void* stream) {
   ocf::clear_stale_error();
   if (!f1 || !f2 || !out || !f1->data || !f2->data || !out->data) return OCF_EINVAL;
   if ((flow && !flow->data) || (occ && !occ->data)) return OCF_EINVAL;
+  if (policy < OCF_CORR_POLICY_AUTO || policy > OCF_CORR_POLICY_WAVE) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
   if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   // bf16: ONE kernel; a profiling request (ocf_profile_next_launch) is handed to the launch itself (hipExtLaunchKernelGGL takes
   // the events and stamps them with the dispatch's own begin / end times, like the profiler's kernel trace) instead of
   // bracketing it with event records, which add ~3 us of queue processing to a 10-30 us kernel
-  if (dtype == OCF_BF16) return ocf::corr_fwd_bf16_mfma(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, st);
+  if (dtype == OCF_BF16) return ocf::corr_fwd_bf16_mfma(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, policy, st);
   ocf::ScopedProfile prof(st);
   if (dtype == OCF_F32) return ocf::corr_fwd_t<float>(f1, f2, flow, occ, out, B, C, H, W, d, flow_scale, align_corners, st);
   return OCF_EINVAL;
 }
 
 extern "C" int ocf_corr_fwd_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
-                                    const ocf_tensor4* out, int B, int C, int H, int W, int d, int dtype) {
+                                    const ocf_tensor4* out, int B, int C, int H, int W, int d, int dtype, int policy) {
   if (!f1 || !f2 || !out || !f1->data || !f2->data || !out->data) return OCF_EINVAL;
+  if (policy < OCF_CORR_POLICY_AUTO || policy > OCF_CORR_POLICY_WAVE) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
   if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
   if (dtype == OCF_F32) return OCF_CORR_VECTOR_F32;
   if (dtype != OCF_BF16) return OCF_EINVAL;
-  return ocf::corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d);
-}
-
-extern "C" int ocf_corr_fwd_select(int policy) {
-  if (policy != OCF_CORR_POLICY_AUTO && policy != OCF_CORR_POLICY_BAND_ONLY) return OCF_EINVAL;
-  ocf::corr_fwd_set_policy(policy);
-  return OCF_OK;
+  return ocf::corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d, policy);
 }
 
 extern "C" int ocf_corr_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* gout, const ocf_tensor4* g1,
-                            const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, void* stream) {
+                            const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, int policy, void* stream) {
   ocf::clear_stale_error();
   if (!f1 || !w2 || !gout || !f1->data || !w2->data || !gout->data) return OCF_EINVAL;
   if ((g1 && !g1->data) || (g2 && !g2->data) || (!g1 && !g2)) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
+  if (policy < OCF_CORR_BWD_POLICY_AUTO || policy > OCF_CORR_BWD_POLICY_MFMA) return OCF_EINVAL;
   if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == OCF_F32) return ocf::corr_bwd_t<float>(f1, w2, gout, g1, g2, B, C, H, W, d, st);
-  if (dtype == OCF_BF16) return ocf::corr_bwd_t<ocf::bf16>(f1, w2, gout, g1, g2, B, C, H, W, d, st);
+  if (dtype == OCF_F32) return ocf::corr_bwd_t<float>(f1, w2, gout, g1, g2, B, C, H, W, d, policy, st);
+  if (dtype == OCF_BF16) return ocf::corr_bwd_t<ocf::bf16>(f1, w2, gout, g1, g2, B, C, H, W, d, policy, st);
+  return OCF_EINVAL;
+}
+
+extern "C" int ocf_corr_bwd_variant(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* gout, const ocf_tensor4* g1,
+                                    const ocf_tensor4* g2, int B, int C, int H, int W, int d, int dtype, int policy) {
+  if (!f1 || !w2 || !gout || !f1->data || !w2->data || !gout->data || (!g1 && !g2)) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
+  if (policy < OCF_CORR_BWD_POLICY_AUTO || policy > OCF_CORR_BWD_POLICY_MFMA) return OCF_EINVAL;
+  if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
+  if (dtype == OCF_F32) return ocf::corr_bwd_variant_t<float>(f1, w2, gout, g1, g2, B, C, H, W, d, policy);
+  if (dtype == OCF_BF16) return ocf::corr_bwd_variant_t<ocf::bf16>(f1, w2, gout, g1, g2, B, C, H, W, d, policy);
   return OCF_EINVAL;
 }
 
 /* occlusion-aware backward: see include/ocflow_hip.h */
 extern "C" int ocf_corr_occ_bwd(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* occ, const ocf_tensor4* gout,
                                 const ocf_tensor4* g1, const ocf_tensor4* g2, const ocf_tensor4* gocc, int B, int C, int H, int W, int d,
-                                int dtype, void* stream) {
+                                int dtype, int policy, void* stream) {
   ocf::clear_stale_error();
   if (!f1 || !w2 || !occ || !gout || !f1->data || !w2->data || !occ->data || !gout->data) return OCF_EINVAL;
+  if (policy < OCF_CORR_BWD_POLICY_AUTO || policy > OCF_CORR_BWD_POLICY_MFMA) return OCF_EINVAL;
   if ((g1 && !g1->data) || (g2 && !g2->data) || (gocc && !gocc->data) || (!g1 && !g2)) return OCF_EINVAL;
   if (gocc && !g2) return OCF_EINVAL;  // the occlusion gradient is a by-product of the g2 pass
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 0) return OCF_EINVAL;
   if (d < 1 || d > OCF_MAX_DISPLACEMENT) return OCF_EUNSUPPORTED;
   if (gocc && !(gocc->sw == 1 && gocc->sh == W && gocc->sb == (long)H * W)) return OCF_EUNSUPPORTED;  // dense fp32 [B,1,H,W]
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == OCF_F32) return ocf::corr_bwd_t<float>(f1, w2, gout, g1, g2, B, C, H, W, d, st, occ, gocc);
-  if (dtype == OCF_BF16) return ocf::corr_bwd_t<ocf::bf16>(f1, w2, gout, g1, g2, B, C, H, W, d, st, occ, gocc);
+  if (dtype == OCF_F32) return ocf::corr_bwd_t<float>(f1, w2, gout, g1, g2, B, C, H, W, d, policy, st, occ, gocc);
+  if (dtype == OCF_BF16) return ocf::corr_bwd_t<ocf::bf16>(f1, w2, gout, g1, g2, B, C, H, W, d, policy, st, occ, gocc);
   return OCF_EINVAL;
 }

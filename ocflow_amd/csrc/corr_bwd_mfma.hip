@@ -327,17 +327,13 @@ __global__ __launch_bounds__(256, G2 ? 2 : 3) void corr_bwd_mfma(T4 other, T4 g,
   }
 }
 
-static int g_corr_bwd_policy = 0;  // ocf_corr_bwd_select: 0 = automatic, 1 = vector kernel only, 2 = matrix-core kernel whenever eligible
-
-void corr_bwd_set_policy(int policy) { g_corr_bwd_policy = policy; }
-
 static bool px8(const ocf_tensor4* t) {  // channel-contiguous, pixels and rows 8-byte aligned, forward strides
   return t->sc == 1 && t->sw > 0 && t->sh > 0 && t->sb > 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sb % 4 == 0 && (uintptr_t)t->data % 8 == 0;
 }
 
 bool corr_bwd_mfma_eligible(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_tensor4* g, const ocf_tensor4* g1, const ocf_tensor4* g2,
-                            int B, int C, int H, int W, int d) {
-  if (g_corr_bwd_policy == 1 || d != bm::D || C % 4 != 0) return false;
+                            int B, int C, int H, int W, int d, int policy) {
+  if (policy == OCF_CORR_BWD_POLICY_VECTOR || d != bm::D || C % 4 != 0) return false;
   if (!px8(f1) || !px8(w2) || (g1 && !px8(g1)) || (g2 && !px8(g2))) return false;
   if (!(g->sc == 1 && g->sw >= bm::NK && g->sh > 0 && g->sb > 0)) return false;
   // byte offsets inside one image are 32-bit in the kernel
@@ -365,9 +361,3 @@ int corr_bwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_t
 }
 
 }  // namespace ocf
-
-extern "C" int ocf_corr_bwd_select(int policy) {
-  if (policy < 0 || policy > 2) return OCF_EINVAL;
-  ocf::corr_bwd_set_policy(policy);
-  return OCF_OK;
-}

@@ -470,22 +470,25 @@ static int launch_mfma_d(const T4& f1, const T4& f2, const T4& flow, const T4& o
   }
 }
 
-static int g_corr_policy = 0;  // ocf_corr_fwd_select: 0 = automatic, 1 = band-GEMM kernels only
-void corr_fwd_set_policy(int p) { g_corr_policy = p; }
-
 int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
-                          const ocf_tensor4* out, int B, int C, int H, int W, int d) {
-  if (g_corr_policy == 0) {
-    const int v = corr_rows_variant(f1, f2, flow, out, C, H, W, d);
-    if (v) return v;
-  }
+                          const ocf_tensor4* out, int B, int C, int H, int W, int d, int policy) {
+  if (policy == OCF_CORR_POLICY_BAND_ONLY) return band_variant(B, C, H, W);
+  const bool wave_ok = policy != OCF_CORR_POLICY_NO_WAVE && corr_wave_eligible(f1, f2, flow, occ, out, B, C, H, W, d);
+  if (policy == OCF_CORR_POLICY_WAVE && wave_ok) return OCF_CORR_WAVE;
+  const int v = corr_rows_variant(f1, f2, flow, out, C, H, W, d);  // (0 with a flow, or when the output is not a dense cost volume)
+  if (v == OCF_CORR_DIRECT && wave_ok) return OCF_CORR_WAVE;       // small levels: independent waves instead of nine-wave workgroups
+  if (v) return v;
+  // no row kernel for this request: the wave kernel takes the small levels with the warp gathered in registers, and cost volumes
+  // written into a wider buffer (any pixel pitch) that the band kernel would write element by element
+  if (wave_ok && (C > 64 || !flow)) return OCF_CORR_WAVE;
   return band_variant(B, C, H, W);
 }
 
 int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
-                       const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st) {
-  if (corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d) <= OCF_CORR_DIRECT)
-    return corr_fwd_bf16_rows(f1, f2, occ, out, B, C, H, W, st);
+                       const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, int policy, hipStream_t st) {
+  const int variant = corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d, policy);
+  if (variant == OCF_CORR_WAVE) return corr_fwd_bf16_wave(f1, f2, flow, occ, out, B, C, H, W, fs, ac, st);
+  if (variant <= OCF_CORR_DIRECT) return corr_fwd_bf16_rows(f1, f2, occ, out, B, C, H, W, st);
   auto span = [&](const ocf_tensor4* t, long c) { return (labs(t->sh) * H + labs(t->sw) * W + labs(t->sc) * c) * 2L; };
   if (span(f1, C) >= (1L << 31) || span(f2, C) >= (1L << 31)) return OCF_EUNSUPPORTED;
   int vec = min_vec(vec_width<bf16>(f1), vec_width<bf16>(f2));

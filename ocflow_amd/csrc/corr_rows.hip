@@ -26,6 +26,7 @@
 #include <hip/hip_ext.h>
 #include "ocf_common.h"
 #include "corr_internal.h"
+#include "corr_frag.h"
 
 namespace ocf {
 namespace rw {
@@ -294,20 +295,6 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
 // f2 rows are re-read by the nine dy waves of nine neighbouring rows -- from L2, and the whole level is a few MB.
 // VEC = 16: 16-byte aligned pixels (C % 8 == 0); VEC = 8: 8-byte aligned (C = 196: 392-byte pixels, the last unit is a half unit).
 // ---------------------------------------------------------------------------------------------------------------------------------
-// raw fragment load (clamped address, always executed) and the mask applied to it AFTER the whole burst has been issued
-template <int VEC>
-__device__ __forceinline__ u32x4 load_frag_raw(const char* p, int c0, int C) {
-  if (VEC == 16) return *(const u32x4*)p;
-  const u32x2 lo = *(const u32x2*)p;
-  const u32x2 hi = *(const u32x2*)(p + ((c0 + 4 < C) ? 8 : 0));
-  return u32x4{lo[0], lo[1], hi[0], hi[1]};
-}
-template <int VEC>
-__device__ __forceinline__ u32x4 mask_frag(u32x4 v, bool ok, int c0, int C) {
-  const unsigned m = ok ? 0xffffffffu : 0u, mh = (ok && (VEC == 16 || c0 + 4 < C)) ? 0xffffffffu : 0u;
-  return u32x4{v[0] & m, v[1] & m, v[2] & mh, v[3] & mh};
-}
-
 // (waves per SIMD: a nine-wave workgroup puts three waves on one SIMD)
 template <int KB, int STRIPS, int VEC, int MODE>
 __global__ __launch_bounds__(64 * rw::N) void corr_fwd_direct(T4 f1, T4 f2, T4 occ, T4 out, int B, int C, int H, int W, int tiles_x) {

@@ -226,7 +226,6 @@ __global__ __launch_bounds__(256) void warp_bwd_cl_kernel(T4 img, T4 flow, T4 go
   }
 }
 
-static int g_warp_bwd_policy = 0;  // ocf_warp_bwd_select: 0 = gather + per-source kernels where they pay, 1 = scatter kernel only, 2 = gather whenever eligible
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Backward, channels_last, without the global float-atomic bound (warp_bwd_cl_kernel runs at the chip-wide atomic rate: 4 atomics per
@@ -470,19 +469,26 @@ static int warp_fwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
 // below ~1M (pixel, channel) pairs the single scatter kernel is faster -- 8.1 vs 14.7 us at 8 x 196 x 7 x 16)
 template <typename T>
 static bool warp_bwd_use_gather(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C,
-                                int H, int W) {
+                                int H, int W, int policy) {
   const long npix = (long)B * H * W;
   const bool cl = img->sc == 1 && gout->sc == 1 && gimg && gimg->sc == 1 && C >= 4;
   const bool gf_dense = !gflow || (gflow->sw == 1 && gflow->sh == W && gflow->sc == (long)H * W && gflow->sb == 2L * H * W);
-  if (!cl || !gf_dense || npix * C >= (1L << 40) || g_warp_bwd_policy == 1 || (g_warp_bwd_policy == 0 && npix * C < (1L << 20))) return false;
+  if (!cl || !gf_dense || npix * C >= (1L << 40) || policy == OCF_WARP_BWD_POLICY_SCATTER ||
+      (policy == OCF_WARP_BWD_POLICY_AUTO && npix * C < (1L << 20)))
+    return false;
   const int vec = min_vec(vec_width<T>(img), vec_width<T>(gout));
   const int upp = (C + Unit<T>::U - 1) / Unit<T>::U;
-  return vec >= 8 && upp <= 64 && C % (vec / (int)sizeof(T)) == 0;
+  if (!(vec >= 8 && upp <= 64 && C % (vec / (int)sizeof(T)) == 0)) return false;
+  // the grid limits of the two launches belong to the SAME decision (ocf_warp_bwd_plan and the launcher must agree on who zeroes grad_img)
+  const long tiles = (long)B * ((W + WT_W - 1) / WT_W) * ((H + WT_H - 1) / WT_H);
+  int upp_pad = 1;
+  while (upp_pad < upp) upp_pad *= 2;
+  return tiles <= 0x7fffffffL && (npix * upp_pad + 255) / 256 <= 0x7fffffffL;
 }
 
 template <typename T>
 static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
-                      const ocf_tensor4* gflow, int B, int C, int H, int W, float fs, int ac, hipStream_t st) {
+                      const ocf_tensor4* gflow, int B, int C, int H, int W, float fs, int ac, int policy, hipStream_t st) {
   const long npix = (long)B * H * W;
   const WarpGeom wg(H, W, ac);
   // channels_last fast path: unit channel stride everywhere and a dense fp32 grad_flow the launcher can zero
@@ -495,7 +501,7 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
     const long blocks = (total + 255) / 256;
     const int vec = min_vec(vec_width<T>(img), vec_width<T>(gout));
     const int upp = (C + Unit<T>::U - 1) / Unit<T>::U;
-    if (warp_bwd_use_gather<T>(img, gout, gimg, gflow, B, C, H, W)) {
+    if (warp_bwd_use_gather<T>(img, gout, gimg, gflow, B, C, H, W, policy)) {
       // gather kernel for the near sources (plain stores: writes the whole of grad_img, no zero-fill needed), then the per-source
       // kernel: grad_flow (plain stores) + float atomics for the far sources
       const int tx = (W + WT_W - 1) / WT_W, ty = (H + WT_H - 1) / WT_H;
@@ -503,7 +509,7 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
       int upp_pad = 1;
       while (upp_pad < upp) upp_pad *= 2;
       const long totalb = npix * upp_pad;
-      if (tiles <= 0x7fffffffL && (totalb + 255) / 256 <= 0x7fffffffL) {
+      {
         LaunchProf lp;
         if (vec == 16)
           lp.launch(false, warp_bwd_gather_kernel<T, 16>, dim3((unsigned)tiles, (unsigned)((C + 31) / 32)), dim3(256), 0, st, mk(flow), mk(gout),
@@ -549,33 +555,29 @@ extern "C" int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, con
   return OCF_EINVAL;
 }
 
-extern "C" int ocf_warp_bwd_select(int policy) {
-  if (policy < 0 || policy > 2) return OCF_EINVAL;
-  ocf::g_warp_bwd_policy = policy;
-  return OCF_OK;
-}
-
 extern "C" int ocf_warp_bwd_plan(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C,
-                                 int H, int W, int dtype) {
+                                 int H, int W, int dtype, int policy) {
   if (!img || !gout || !img->data || !gout->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  if (policy < OCF_WARP_BWD_POLICY_AUTO || policy > OCF_WARP_BWD_POLICY_GATHER) return OCF_EINVAL;
   bool gather = false;
-  if (dtype == OCF_F32) gather = ocf::warp_bwd_use_gather<float>(img, gout, gimg, gflow, B, C, H, W);
-  else if (dtype == OCF_BF16) gather = ocf::warp_bwd_use_gather<ocf::bf16>(img, gout, gimg, gflow, B, C, H, W);
+  if (dtype == OCF_F32) gather = ocf::warp_bwd_use_gather<float>(img, gout, gimg, gflow, B, C, H, W, policy);
+  else if (dtype == OCF_BF16) gather = ocf::warp_bwd_use_gather<ocf::bf16>(img, gout, gimg, gflow, B, C, H, W, policy);
   else return OCF_EINVAL;
   return gather ? 0 : 1;  // bit 0: grad_img must be zeroed by the caller (scatter kernel: float atomics)
 }
 
 extern "C" int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
                             const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners,
-                            int dtype, void* stream) {
+                            int dtype, int policy, void* stream) {
   ocf::clear_stale_error();
   if (!img || !flow || !gout || !img->data || !flow->data || !gout->data) return OCF_EINVAL;
   if ((gimg && !gimg->data) || (gflow && !gflow->data) || (!gimg && !gflow)) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  if (policy < OCF_WARP_BWD_POLICY_AUTO || policy > OCF_WARP_BWD_POLICY_GATHER) return OCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == OCF_F32) return ocf::warp_bwd_t<float>(img, flow, gout, gimg, gflow, B, C, H, W, flow_scale, align_corners, st);
+  if (dtype == OCF_F32) return ocf::warp_bwd_t<float>(img, flow, gout, gimg, gflow, B, C, H, W, flow_scale, align_corners, policy, st);
   if (dtype == OCF_BF16)
-    return ocf::warp_bwd_t<ocf::bf16>(img, flow, gout, gimg, gflow, B, C, H, W, flow_scale, align_corners, st);
+    return ocf::warp_bwd_t<ocf::bf16>(img, flow, gout, gimg, gflow, B, C, H, W, flow_scale, align_corners, policy, st);
   return OCF_EINVAL;
 }

@@ -127,7 +127,9 @@ def _conv_module(conv: nn.Conv2d, x):
 
 
 def _unfused() -> bool:
-    return os.environ.get("OCFLOW_UNFUSED_EPILOGUE", "0") == "1"
+    # under torch.compile / make_fx the reference's own op chain is traced (the compiler fuses bias + activation itself; the in-place
+    # ctypes launch cannot be traced) -- the correlation / warp / loss operators trace as torch.ops.ocflow.* (ocflow_amd/torch_ops.py)
+    return os.environ.get("OCFLOW_UNFUSED_EPILOGUE", "0") == "1" or torch.compiler.is_compiling()
 
 
 def conv_bias(conv: nn.Conv2d, x):

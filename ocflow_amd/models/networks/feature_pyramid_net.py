@@ -12,7 +12,7 @@ from ._epilogue import deconv_bias
 
 def _bn_act(bn: nn.BatchNorm2d, act: nn.LeakyReLU, x, groups: int = 1):
     # OCFLOW_UNFUSED_BN=1: the reference's own op chain (A/B switch for measurements and bisecting, not a fallback)
-    if os.environ.get("OCFLOW_UNFUSED_BN", "0") == "1" and groups == 1:
+    if (os.environ.get("OCFLOW_UNFUSED_BN", "0") == "1" or torch.compiler.is_compiling()) and groups == 1:
         return act(bn(x))
     return ops.batchnorm_lrelu(x, bn, act.negative_slope, groups)
 
@@ -80,6 +80,7 @@ class FeaturePyramidNet(nn.Module):
         the values are those of the two calls while the 17 convolutions / BatchNorm sites per image -- most of them launch-bound at
         the coarse levels -- are launched once instead of twice.  OCFLOW_UNPAIRED_FPN=1, CPU tensors and NCHW layouts: two calls."""
         paired = (x1.is_cuda and x1.shape == x2.shape and x1.dim() == 4 and os.environ.get("OCFLOW_UNPAIRED_FPN", "0") != "1"
+                  and not torch.compiler.is_compiling()
                   and os.environ.get("OCFLOW_UNFUSED_BN", "0") != "1"
                   and (not self.training or x1.is_contiguous(memory_format=torch.channels_last) or x1.shape[1] == 3))
         if not paired:

@@ -28,10 +28,54 @@ __all__ = [
 ]
 
 MAX_DISPLACEMENT = 4
-_FUSED_WARP = os.environ.get("OCFLOW_FUSED_WARP", "0") == "1"
+# OCFLOW_FUSED_WARP: "auto" (default) = ONE launch (warp gathered inside the correlation kernel, the warped tensor never exists in HBM)
+# whenever nothing downstream needs the warped tensor -- no gradient is being recorded -- and the request is served by a kernel with
+# the in-register gather (ocf_corr_fwd_variant == OCF_CORR_WAVE); "1" = always one launch; "0" = always warp kernel + correlation kernel
+_FUSED_WARP = os.environ.get("OCFLOW_FUSED_WARP", "auto")
 
 _KERNEL_TIMER = None
 _DETERMINISTIC = os.environ.get("OCFLOW_DETERMINISTIC", "0") == "1"
+
+
+class KernelPolicy:
+    """Which kernel serves a request that several can serve (same results): the value of each field is handed to the C ABI PER CALL
+    (include/ocflow_hip.h: enum ocf_corr_policy / ocf_corr_bwd_policy / ocf_warp_bwd_policy / ocf_range_policy; 0 = automatic).  The
+    library itself keeps no state; this object is the host-side default, initialised from OCFLOW_{CORR_FWD,CORR_BWD,WARP_BWD,
+    RANGE_MAP,WGRAD}_POLICY for whole-model A/B runs, and `kernel_policy(...)` scopes an override for tests and measurements."""
+    __slots__ = ("corr_fwd", "corr_bwd", "warp_bwd", "range_map", "wgrad")
+
+    def __init__(self):
+        env = os.environ.get
+        self.corr_fwd = int(env("OCFLOW_CORR_FWD_POLICY", "0"))
+        self.corr_bwd = int(env("OCFLOW_CORR_BWD_POLICY", "0"))
+        self.warp_bwd = int(env("OCFLOW_WARP_BWD_POLICY", "0"))
+        self.range_map = int(env("OCFLOW_RANGE_MAP_POLICY", "0"))
+        self.wgrad = int(env("OCFLOW_WGRAD_POLICY", "0"))
+
+
+POLICY = KernelPolicy()
+
+
+class kernel_policy:
+    """`with ops.kernel_policy(corr_fwd=_lib.CORR_BAND_ONLY): ...` -- the launches issued inside the block (forward AND the backward
+    passes recorded inside it) carry these policies; the previous values come back on exit.  Host-side convenience only."""
+
+    def __init__(self, **kw):
+        for k in kw:
+            if k not in KernelPolicy.__slots__:
+                raise TypeError(f"unknown kernel policy field {k!r}")
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: getattr(POLICY, k) for k in self.kw}
+        for k, v in self.kw.items():
+            setattr(POLICY, k, int(v))
+        return POLICY
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            setattr(POLICY, k, v)
+        return False
 
 
 def set_deterministic(flag: bool = True):
@@ -149,7 +193,7 @@ def _warp_fwd_raw(img, flow, flow_scale, align_corners):
     return out
 
 
-def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flow):
+def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flow, policy=None):
     B, C_, H, W = img.shape
     if gout.dtype != img.dtype:
         gout = gout.to(img.dtype)
@@ -166,14 +210,17 @@ def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flo
         return gimg, gflow
     gimg = _empty_like_layout(img, img.shape, torch.float32) if need_img else None
     gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32) if need_flow else None
-    # the scatter kernel accumulates into grad_img with float atomics (zero it first); the gather kernels overwrite it
-    if gimg is not None and _lib.load().ocf_warp_bwd_plan(_t4(img), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W, _dtype_code(img)) != 0:
+    # the scatter kernel accumulates into grad_img with float atomics (zero it first); the gather kernels overwrite it.  Plan and
+    # launch receive the SAME policy value and evaluate one decision function in the library.
+    policy = POLICY.warp_bwd if policy is None else policy
+    if gimg is not None and _lib.load().ocf_warp_bwd_plan(_t4(img), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W, _dtype_code(img),
+                                                          policy) != 0:
         gimg.zero_()
 
     def launch():
         with torch.cuda.device(img.device):
             _lib.check(_lib.load().ocf_warp_bwd(_t4(img), _t4(flow), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W,
-                                                float(flow_scale), int(bool(align_corners)), _dtype_code(img), _stream(img)),
+                                                float(flow_scale), int(bool(align_corners)), _dtype_code(img), policy, _stream(img)),
                        "ocf_warp_bwd")
 
     # read gout + img (es each), flow 8; write (atomics) fp32 grad_img 4C, grad_flow 8
@@ -184,35 +231,130 @@ def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flo
 
 
 # --------------------------------------------------------------------------------------------- cost volume
+def _fuse_warp(f1, f2, flow, occ, out, d, needs_grad) -> bool:
+    """one fused launch (True) or warp kernel + correlation kernel (False) for a correlation with a flow: see _FUSED_WARP"""
+    if _FUSED_WARP == "1":
+        return True
+    if _FUSED_WARP == "0" or needs_grad or f1.dtype != torch.bfloat16:
+        return False  # backward consumes the warped tensor: kept from the forward instead of being recomputed
+    B, C_, H, W = f1.shape
+    v = _lib.load().ocf_corr_fwd_variant(_t4(f1), _t4(f2), _t4(flow), _t4(occ), _t4(out), B, C_, H, W, d, _dtype_code(f1), POLICY.corr_fwd)
+    return v == _lib.CORR_VARIANT_WAVE
+
+
+def _corr_warp_fwd_raw(f1, f2, flow, occ, d, flow_scale, align_corners, out, needs_grad):
+    """-> (cost volume, warped second operand or None).  Stateless launch sequence shared by the autograd Function below and by the
+    registered operator torch.ops.ocflow.corr_warp (torch_ops.py)."""
+    B, C_, H, W = f1.shape
+    n = 2 * d + 1
+    if out is None:
+        out = _empty_like_layout(f1, (B, n * n, H, W))
+    # with a flow: ocf_corr_fwd can gather the warped operand inside the correlation kernel (no warped tensor in HBM; same
+    # values: the fused kernels round the gathered operand to the feature dtype before the contraction, exactly what the
+    # materialised tensor holds).  A training forward keeps the two-launch form -- backward consumes the warped tensor, which
+    # is then kept instead of being recomputed; no-grad forwards (evaluation, the second forward of the occlusion-aware step)
+    # take the single launch where a gather kernel serves the shape (_fuse_warp).
+    w2 = None
+    if flow is not None and not _fuse_warp(f1, f2, flow, occ, out, d, needs_grad):
+        w2 = _warp_fwd_raw(f2, flow, flow_scale, align_corners)
+    op2, opflow = (f2, flow) if w2 is None else (w2, None)
+    policy = POLICY.corr_fwd
+
+    def launch():
+        with torch.cuda.device(f1.device):
+            _lib.check(_lib.load().ocf_corr_fwd(_t4(f1), _t4(op2), _t4(opflow), _t4(occ), _t4(out), B, C_, H, W, d,
+                                                float(flow_scale), int(bool(align_corners)), _dtype_code(f1), policy,
+                                                _stream(f1)), "ocf_corr_fwd")
+
+    if _KERNEL_TIMER is not None:
+        nbytes, flops = corr_fwd_algorithmic(B, C_, H, W, d, f1.element_size(), opflow is not None, occ is not None)
+        name = "corr_warp_fwd" if opflow is not None else "corr_fwd"  # (the fused K1+K2 launch is accounted separately: SURVEY 8d4)
+        _KERNEL_TIMER.launch(name, {"bytes": nbytes, "flops": flops, "shape": f"B{B}xC{C_}x{H}x{W}"}, launch)
+    else:
+        launch()
+    return out, w2
+
+
+def _corr_warp_bwd_raw(f1, f2, flow, occ, w2_saved, gout, d, fs, ac, needs, bwd_policy, warp_bwd_policy):
+    """gradients (g1, g2, gflow, gocc) of corr_warp; `needs` = which of (f1, f2, flow, occ) want one.  Stateless: every tensor the
+    kernels read is an argument (the saved warped operand `w2_saved`, or None to recompute it)."""
+    B, C_, H, W = f1.shape
+    need1, need2, needf, needo = needs
+    if gout.dtype != f1.dtype:
+        gout = gout.to(f1.dtype)
+    # autograd hands the cost-volume gradient over as a channel slice of the decoder-input gradient (cat backward): 81
+    # contiguous values per pixel at the concat buffer's pixel pitch.  The backward kernels read per-pixel tap windows at any
+    # pixel pitch, so that view is consumed as is; only a gradient whose taps are not contiguous per pixel (NCHW) is brought to
+    # channels_last first.
+    if _is_cl(f1) and gout.stride(1) != 1:
+        gout = gout.contiguous(memory_format=torch.channels_last)
+    # second operand of the plain correlation (kept by the two-launch forward; recomputed after a fused forward)
+    if w2_saved is not None:
+        w2 = w2_saved
+    else:
+        w2 = _warp_fwd_raw(f2, flow, fs, ac) if flow is not None else f2
+    need_w2 = need2 or needf or needo
+    g1 = _empty_like_layout(f1, f1.shape) if need1 else None
+    gw = gocc = None
+    fused_occ = False
+    if occ is not None and (need1 or need_w2):
+        # occlusion folded into the kernels: w2*occ is formed while staging, gw comes back already multiplied by occ
+        # and the occlusion gradient is a by-product of the same pass (6 elementwise launches per level otherwise)
+        gw = _empty_like_layout(w2, w2.shape) if need_w2 else None
+        gocc = torch.empty((B, 1, H, W), device=f1.device, dtype=torch.float32) if (needo and need_w2) else None
+        occ32 = _f32(occ)
+        es = f1.element_size()
+
+        def launch_occ():
+            with torch.cuda.device(f1.device):
+                return _lib.load().ocf_corr_occ_bwd(_t4(f1), _t4(w2), _t4(occ32), _t4(gout), _t4(g1), _t4(gw), _t4(gocc), B, C_, H, W,
+                                                    d, _dtype_code(f1), bwd_policy, _stream(f1))
+
+        # read grad_out n*es, f1, w2 (C*es each), occ 4; write g1, g2 (C*es each), gocc 4
+        st = _launch("corr_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ * es + (2 * d + 1) ** 2 * es + 8),
+                                               2 * 2 * C_ * (2 * d + 1) ** 2 * B * H * W), launch_occ)
+        if st == _lib.OCF_EUNSUPPORTED:
+            gw = gocc = None  # layout the tiled kernels do not take: compose it from the plain launches below
+        else:
+            _lib.check(st, "ocf_corr_occ_bwd")
+            fused_occ = True
+            if gocc is not None and occ.dtype != torch.float32:
+                gocc = gocc.to(occ.dtype)
+    if not fused_occ:
+        w2o = w2 * occ.to(w2.dtype) if occ is not None else w2
+        gw = _empty_like_layout(w2o, w2o.shape) if need_w2 else None
+        if need1 or need_w2:
+            es = f1.element_size()
+
+            def launch_plain():
+                with torch.cuda.device(f1.device):
+                    _lib.check(_lib.load().ocf_corr_bwd(_t4(f1), _t4(w2o), _t4(gout), _t4(g1), _t4(gw), B, C_, H, W, d,
+                                                        _dtype_code(f1), bwd_policy, _stream(f1)), "ocf_corr_bwd")
+
+            _launch("corr_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ * es + (2 * d + 1) ** 2 * es),
+                                              2 * 2 * C_ * (2 * d + 1) ** 2 * B * H * W), launch_plain)
+        if need_w2 and occ is not None:
+            if needo:
+                gocc = (gw.float() * w2.float()).sum(dim=1, keepdim=True)
+            gw = gw * occ.to(gw.dtype)
+    g2 = gflow = None
+    if need_w2:
+        if flow is not None:
+            if need2 or needf:
+                g2, gflow = _warp_bwd_raw(f2, flow, gw, fs, ac, need2, needf, warp_bwd_policy)
+        else:
+            g2 = gw if need2 else None
+    return g1, g2, gflow, gocc
+
+
 class _CorrWarpFn(Function):
     @staticmethod
-    def forward(ctx, f1, f2, flow, occ, d, flow_scale, align_corners):
-        B, C_, H, W = f1.shape
-        n = 2 * d + 1
-        out = _empty_like_layout(f1, (B, n * n, H, W))
-        # with a flow: ocf_corr_fwd can gather the warped operand inside the correlation kernel (no warped tensor in HBM), but
-        # since the lane-per-unit warp kernel the two-launch form is faster at every pyramid level (level 2: 12.8 + 29.0 us vs
-        # 53.7 us fused; top level 4.9 + 14.0 vs 37.5) and backward needs the warped tensor anyway -- it is kept instead of
-        # being recomputed.  OCFLOW_FUSED_WARP=1 selects the single fused launch (same values: the fused kernel rounds the
-        # gathered operand to the feature dtype before the contraction, exactly what the materialised tensor holds).
-        w2 = None
-        if flow is not None and not _FUSED_WARP:
-            w2 = _warp_fwd_raw(f2, flow, flow_scale, align_corners)
-        op2, opflow = (f2, flow) if w2 is None else (w2, None)
-
-        def launch():
-            with torch.cuda.device(f1.device):
-                _lib.check(_lib.load().ocf_corr_fwd(_t4(f1), _t4(op2), _t4(opflow), _t4(occ), _t4(out), B, C_, H, W, d,
-                                                    float(flow_scale), int(bool(align_corners)), _dtype_code(f1),
-                                                    _stream(f1)), "ocf_corr_fwd")
-
-        if _KERNEL_TIMER is not None:
-            nbytes, flops = corr_fwd_algorithmic(B, C_, H, W, d, f1.element_size(), opflow is not None, occ is not None)
-            _KERNEL_TIMER.launch("corr_fwd", {"bytes": nbytes, "flops": flops, "shape": f"B{B}xC{C_}x{H}x{W}"}, launch)
-        else:
-            launch()
+    def forward(ctx, f1, f2, flow, occ, d, flow_scale, align_corners, out):
+        out, w2 = _corr_warp_fwd_raw(f1, f2, flow, occ, d, flow_scale, align_corners, out, any(ctx.needs_input_grad[:4]))
         ctx.save_for_backward(f1, f2, flow, occ, w2)
         ctx.cfg = (d, float(flow_scale), bool(align_corners))
+        ctx.bwd_policy = POLICY.corr_bwd
+        ctx.warp_bwd_policy = POLICY.warp_bwd
         return out
 
     @staticmethod
@@ -220,82 +362,23 @@ class _CorrWarpFn(Function):
     def backward(ctx, gout):
         f1, f2, flow, occ, w2_saved = ctx.saved_tensors
         d, fs, ac = ctx.cfg
-        B, C_, H, W = f1.shape
-        need1, need2, needf, needo = ctx.needs_input_grad[:4]
-        if gout.dtype != f1.dtype:
-            gout = gout.to(f1.dtype)
-        # autograd hands the cost-volume gradient over as a channel slice of the decoder-input gradient (cat backward): 81
-        # contiguous values per pixel at the concat buffer's pixel pitch.  The tiled backward kernels stage per-pixel tap
-        # windows with unaligned 8-byte loads, so that view is consumed as is; only a gradient whose taps are not contiguous
-        # per pixel (NCHW) is brought to channels_last first.
-        if _is_cl(f1) and gout.stride(1) != 1:
-            gout = gout.contiguous(memory_format=torch.channels_last)
-        # second operand of the plain correlation (kept by the two-launch forward; recomputed after a fused forward)
-        if w2_saved is not None:
-            w2 = w2_saved
-        else:
-            w2 = _warp_fwd_raw(f2, flow, fs, ac) if flow is not None else f2
-        need_w2 = need2 or needf or needo
-        g1 = _empty_like_layout(f1, f1.shape) if need1 else None
-        gw = gocc = None
-        fused_occ = False
-        if occ is not None and (need1 or need_w2):
-            # occlusion folded into the tiled kernels: w2*occ is formed while staging, gw comes back already multiplied by occ
-            # and the occlusion gradient is a by-product of the same pass (6 elementwise launches per level otherwise)
-            gw = _empty_like_layout(w2, w2.shape) if need_w2 else None
-            gocc = torch.empty((B, 1, H, W), device=f1.device, dtype=torch.float32) if (needo and need_w2) else None
-            occ32 = _f32(occ)
-            es = f1.element_size()
-
-            def launch_occ():
-                with torch.cuda.device(f1.device):
-                    return _lib.load().ocf_corr_occ_bwd(_t4(f1), _t4(w2), _t4(occ32), _t4(gout), _t4(g1), _t4(gw), _t4(gocc), B, C_, H, W,
-                                                        d, _dtype_code(f1), _stream(f1))
-
-            # read grad_out n*es, f1, w2 (C*es each), occ 4; write g1, g2 (C*es each), gocc 4
-            st = _launch("corr_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ * es + (2 * d + 1) ** 2 * es + 8),
-                                                   2 * 2 * C_ * (2 * d + 1) ** 2 * B * H * W), launch_occ)
-            if st == _lib.OCF_EUNSUPPORTED:
-                gw = gocc = None  # layout the tiled kernels do not take: compose it from the plain launches below
-            else:
-                _lib.check(st, "ocf_corr_occ_bwd")
-                fused_occ = True
-                if gocc is not None and occ.dtype != torch.float32:
-                    gocc = gocc.to(occ.dtype)
-        if not fused_occ:
-            w2o = w2 * occ.to(w2.dtype) if occ is not None else w2
-            gw = _empty_like_layout(w2o, w2o.shape) if need_w2 else None
-            if need1 or need_w2:
-                es = f1.element_size()
-
-                def launch_plain():
-                    with torch.cuda.device(f1.device):
-                        _lib.check(_lib.load().ocf_corr_bwd(_t4(f1), _t4(w2o), _t4(gout), _t4(g1), _t4(gw), B, C_, H, W, d,
-                                                            _dtype_code(f1), _stream(f1)), "ocf_corr_bwd")
-
-                _launch("corr_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ * es + (2 * d + 1) ** 2 * es),
-                                                  2 * 2 * C_ * (2 * d + 1) ** 2 * B * H * W), launch_plain)
-            if need_w2 and occ is not None:
-                if needo:
-                    gocc = (gw.float() * w2.float()).sum(dim=1, keepdim=True)
-                gw = gw * occ.to(gw.dtype)
-        g2 = gflow = None
-        if need_w2:
-            if flow is not None:
-                if need2 or needf:
-                    g2, gflow = _warp_bwd_raw(f2, flow, gw, fs, ac, need2, needf)
-            else:
-                g2 = gw if need2 else None
-        return g1, g2, gflow, gocc, None, None, None
+        g1, g2, gflow, gocc = _corr_warp_bwd_raw(f1, f2, flow, occ, w2_saved, gout, d, fs, ac, ctx.needs_input_grad[:4], ctx.bwd_policy,
+                                                 ctx.warp_bwd_policy)
+        return g1, g2, gflow, gocc, None, None, None, None
 
 
-def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flow_scale=1.0, align_corners=False):
+def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flow_scale=1.0, align_corners=False, out=None):
     """Cost volume of features1 against  warp(features2, flow*flow_scale) [* occ].
 
-    With a flow this is TWO launches by default -- ocf_warp_fwd materialises the warped operand (backward and the occlusion
-    estimators need it as a tensor anyway), then ocf_corr_fwd with the mask applied to the band outputs; measured faster than the
-    single launch at every pyramid level.  OCFLOW_FUSED_WARP=1 selects the single launch that gathers the
-    search window through the warp straight into LDS (the warped tensor then never exists in HBM; same values).
+    With a flow: a forward that records a gradient is TWO launches -- ocf_warp_fwd materialises the warped operand (backward consumes
+    it), then ocf_corr_fwd with the mask applied to the band outputs; a no-grad forward is ONE launch where a kernel with the
+    in-register gather serves the shape (the warped tensor then never exists in HBM; same values bit for bit).  OCFLOW_FUSED_WARP=0 / 1
+    force either form.
+
+    `out`: optional pre-allocated [B, (2d+1)^2, H, W] tensor of the features' dtype with unit channel stride and ANY pixel pitch -- e.g.
+    the first 81 channels of the decoder-input buffer (flow_occ_net.py:171-176 concatenates the cost volume in front of the features):
+    the kernel writes there and the concatenation copy disappears.  Forward only (no gradient may be recorded: a view of a wider
+    buffer cannot carry this operator's backward; the differentiable form assembles the whole buffer in one autograd node).
 
     Replaces the per-level chain  warp -> [* occ] -> correlation  of flow_net.py:110-112 and
     cost_volume_flow_occ_net.py:204-206 (with flow=None, occ given: flow_occ_net.py:167-168)."""
@@ -320,7 +403,17 @@ def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flo
     if f1.numel() == 0:  # empty batch / empty map: what the reference's pad-and-shift loop returns, without a launch
         n = 2 * d + 1
         return (f1.sum() + f2.sum()) * 0 + f1.new_zeros((B, n * n, H, W))
-    return _CorrWarpFn.apply(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners)
+    if out is not None:
+        n = 2 * d + 1
+        if out.shape != (B, n * n, H, W) or out.dtype != f1.dtype or out.device != f1.device or out.stride(1) != 1:
+            raise ValueError(f"out must be a [{B},{n * n},{H},{W}] {f1.dtype} tensor with unit channel stride on {f1.device}")
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (f1, f2, flow, occ, out)):
+            raise RuntimeError("corr_warp(out=...) is a forward-only form: call it under torch.no_grad() or on detached tensors")
+        return _corr_warp_fwd_raw(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners, out, False)[0]
+    if _tracing() and out is None:
+        from . import torch_ops  # noqa: F401
+        return torch.ops.ocflow.corr_warp(f1, f2, _f32(flow), _f32(occ), d, float(flow_scale), bool(align_corners))[0]
+    return _CorrWarpFn.apply(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners, out)
 
 
 def compute_cost_volume(features1, features2, max_displacement=4):
@@ -336,6 +429,7 @@ class _WarpFn(Function):
     def forward(ctx, img, flow, flow_scale, align_corners):
         ctx.save_for_backward(img, flow)
         ctx.cfg = (float(flow_scale), bool(align_corners))
+        ctx.bwd_policy = POLICY.warp_bwd
         return _warp_fwd_raw(img, flow, flow_scale, align_corners)
 
     @staticmethod
@@ -343,7 +437,7 @@ class _WarpFn(Function):
     def backward(ctx, gout):
         img, flow = ctx.saved_tensors
         fs, ac = ctx.cfg
-        gimg, gflow = _warp_bwd_raw(img, flow, gout, fs, ac, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gimg, gflow = _warp_bwd_raw(img, flow, gout, fs, ac, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bwd_policy)
         return gimg, gflow, None, None
 
 
@@ -361,6 +455,9 @@ def warp(img, flow, align_corners=False, flow_scale=1.0):
     (x,) = _features(img)
     if x.numel() == 0:  # empty batch: grid_sample of nothing
         return x * 1
+    if _tracing():
+        from . import torch_ops  # noqa: F401
+        return torch.ops.ocflow.warp(x, _f32(flow), float(flow_scale), bool(align_corners))
     return _WarpFn.apply(x, _f32(flow), flow_scale, align_corners)
 
 
@@ -430,19 +527,43 @@ def robust_l1(x, alpha=0.001):
     return (x ** 2 + alpha ** 2) ** 0.5
 
 
+def _photo_fwd_raw(img1, img2, flow, occ):
+    """fp64 [2]: sum e * (1 - occ), sum (1 - occ)   (ocf_photo_loss_fwd)"""
+    B, C_, H, W = img1.shape
+    sums = torch.empty(2, device=img1.device, dtype=torch.float64)
+
+    def launch():
+        with torch.cuda.device(img1.device):
+            _lib.check(_lib.load().ocf_photo_loss_fwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(sums.data_ptr()),
+                                                      B, C_, H, W, _stream(img1)), "ocf_photo_loss_fwd")
+
+    px_bytes = 8 * C_ + (8 if flow is not None else 0) + (4 if occ is not None else 0)  # 36 for RGB + flow + mask
+    _launch("photo_fwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * px_bytes), launch)
+    return sums
+
+
+def _photo_bwd_raw(img1, img2, flow, occ, scale, want_flow, want_pred):
+    """(grad_flow [B,2,H,W] | None, dLoss/dP [B,C,H,W] | None) for dLoss/d sums[0] = `scale` (device fp32 scalar)"""
+    B, C_, H, W = img1.shape
+    scale = scale.float().reshape(1).contiguous()
+    gflow = torch.empty((B, 2, H, W), device=img1.device, dtype=torch.float32) if (flow is not None and want_flow) else None
+    gpred = torch.empty((B, C_, H, W), device=img1.device, dtype=torch.float32) if (flow is None and want_pred) else None
+    if gflow is not None or gpred is not None:
+        def launch():
+            with torch.cuda.device(img1.device):
+                _lib.check(_lib.load().ocf_photo_loss_bwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(scale.data_ptr()),
+                                                          _t4(gflow), _t4(gpred), B, C_, H, W, _stream(img1)),
+                           "ocf_photo_loss_bwd")
+
+        px_bytes = 8 * C_ + (16 if flow is not None else 4 * C_) + (4 if occ is not None else 0)  # 44 for RGB + flow + mask
+        _launch("photo_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * px_bytes), launch)
+    return gflow, gpred
+
+
 class _PhotoFn(Function):
     @staticmethod
     def forward(ctx, img1, img2, flow, occ):
-        B, C_, H, W = img1.shape
-        sums = torch.empty(2, device=img1.device, dtype=torch.float64)
-
-        def launch():
-            with torch.cuda.device(img1.device):
-                _lib.check(_lib.load().ocf_photo_loss_fwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(sums.data_ptr()),
-                                                          B, C_, H, W, _stream(img1)), "ocf_photo_loss_fwd")
-
-        px_bytes = 8 * C_ + (8 if flow is not None else 0) + (4 if occ is not None else 0)  # 36 for RGB + flow + mask
-        _launch("photo_fwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * px_bytes), launch)
+        sums = _photo_fwd_raw(img1, img2, flow, occ)
         ctx.save_for_backward(img1, img2, flow, occ)
         num, den = sums[0].float(), sums[1].float()
         ctx.mark_non_differentiable(den)
@@ -460,21 +581,16 @@ class _PhotoFn(Function):
         if flow is not None and (n1 or n2):
             raise NotImplementedError("warp_photometric_error: image gradients through the fused warp are not "
                                       "implemented; use ops.warp + ops.photometric_error")
-        scale = gnum.float().reshape(1).contiguous()
-        gflow = torch.empty((B, 2, H, W), device=img1.device, dtype=torch.float32) if (flow is not None and nf) else None
-        gpred = torch.empty((B, C_, H, W), device=img1.device, dtype=torch.float32) if (flow is None and (n1 or n2)) else None
-        if gflow is not None or gpred is not None:
-            def launch():
-                with torch.cuda.device(img1.device):
-                    _lib.check(_lib.load().ocf_photo_loss_bwd(_t4(img1), _t4(img2), _t4(flow), _t4(occ), C.c_void_p(scale.data_ptr()),
-                                                              _t4(gflow), _t4(gpred), B, C_, H, W, _stream(img1)),
-                               "ocf_photo_loss_bwd")
-
-            px_bytes = 8 * C_ + (16 if flow is not None else 4 * C_) + (4 if occ is not None else 0)  # 44 for RGB + flow + mask
-            _launch("photo_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * px_bytes), launch)
+        gflow, gpred = _photo_bwd_raw(img1, img2, flow, occ, gnum, nf, n1 or n2)
         g1 = -gpred if (gpred is not None and n1) else None
         g2 = gpred if (gpred is not None and n2) else None
         return g1, g2, gflow, None
+
+
+def _tracing() -> bool:
+    """inside torch.compile / make_fx: the operators go through their dispatcher identities (torch.ops.ocflow.*, torch_ops.py) -- a
+    ctypes launch cannot be traced; eager calls keep the direct path (no dispatcher overhead per launch)"""
+    return torch.compiler.is_compiling()
 
 
 def _photo(img1, img2, flow, occ):
@@ -485,7 +601,12 @@ def _photo(img1, img2, flow, occ):
     _require_hip(img1, img2, flow, occ)
     if occ is not None:
         _check4(occ, "occ", 1)
-    num, den = _PhotoFn.apply(_f32(img1), _f32(img2), _f32(flow), _f32(occ))
+    if _tracing():
+        from . import torch_ops  # noqa: F401  (registers torch.ops.ocflow.*)
+        sums = torch.ops.ocflow.photo_loss(_f32(img1), _f32(img2), _f32(flow), _f32(occ))
+        num, den = sums[0], sums[1].detach()
+    else:
+        num, den = _PhotoFn.apply(_f32(img1), _f32(img2), _f32(flow), _f32(occ))
     if occ is not None:
         return num / (den * img1.shape[1] + 1e-16)
     return num / float(img1.numel())
@@ -558,18 +679,39 @@ def gradient(img, stride=1):
     return img[:, :, :, stride:] - img[:, :, :, :-stride], img[:, :, stride:, :] - img[:, :, :-stride, :]
 
 
+def _smooth_fwd_raw(img, flow, alpha):
+    """fp64 [4]: the four weighted Charbonnier sums of ocf_smooth_loss_fwd"""
+    B, C_, H, W = img.shape
+    sums = torch.empty(4, device=img.device, dtype=torch.float64)
+
+    def launch():
+        with torch.cuda.device(img.device):
+            _lib.check(_lib.load().ocf_smooth_loss_fwd(_t4(img), _t4(flow), C.c_void_p(sums.data_ptr()), B, C_, H, W,
+                                                       float(alpha), _stream(img)), "ocf_smooth_loss_fwd")
+
+    _launch("smooth_fwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ + 8)), launch)
+    return sums
+
+
+def _smooth_bwd_raw(img, flow, coef, alpha):
+    """grad_flow for dLoss/d sums = `coef` (device fp32 [4])"""
+    B, C_, H, W = img.shape
+    coef = coef.float().contiguous()
+    gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32)
+
+    def launch():
+        with torch.cuda.device(img.device):
+            _lib.check(_lib.load().ocf_smooth_loss_bwd(_t4(img), _t4(flow), C.c_void_p(coef.data_ptr()), _t4(gflow), B, C_, H, W,
+                                                       float(alpha), _stream(img)), "ocf_smooth_loss_bwd")
+
+    _launch("smooth_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ + 16)), launch)
+    return gflow
+
+
 class _SmoothFn(Function):
     @staticmethod
     def forward(ctx, img, flow, alpha):
-        B, C_, H, W = img.shape
-        sums = torch.empty(4, device=img.device, dtype=torch.float64)
-
-        def launch():
-            with torch.cuda.device(img.device):
-                _lib.check(_lib.load().ocf_smooth_loss_fwd(_t4(img), _t4(flow), C.c_void_p(sums.data_ptr()), B, C_, H, W,
-                                                           float(alpha), _stream(img)), "ocf_smooth_loss_fwd")
-
-        _launch("smooth_fwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ + 8)), launch)
+        sums = _smooth_fwd_raw(img, flow, alpha)
         ctx.save_for_backward(img, flow)
         ctx.alpha = float(alpha)
         return sums.float()
@@ -580,17 +722,7 @@ class _SmoothFn(Function):
         img, flow = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("smoothness loss: gradient w.r.t. the image is not implemented")
-        B, C_, H, W = img.shape
-        coef = gsums.float().contiguous()
-        gflow = torch.empty((B, 2, H, W), device=img.device, dtype=torch.float32)
-
-        def launch():
-            with torch.cuda.device(img.device):
-                _lib.check(_lib.load().ocf_smooth_loss_bwd(_t4(img), _t4(flow), C.c_void_p(coef.data_ptr()), _t4(gflow), B, C_, H, W,
-                                                           ctx.alpha, _stream(img)), "ocf_smooth_loss_bwd")
-
-        _launch("smooth_bwd", lambda: _meta(f"B{B}xC{C_}x{H}x{W}", B * H * W * (4 * C_ + 16)), launch)
-        return None, gflow, None
+        return None, _smooth_bwd_raw(img, flow, gsums, ctx.alpha), None
 
 
 def smoothness_losses(img, flow, alpha=100.0):
@@ -601,7 +733,11 @@ def smoothness_losses(img, flow, alpha=100.0):
         raise ValueError("smoothness: img and flow must share B,H,W")
     _require_hip(img, flow)
     B, _, H, W = img.shape
-    s = _SmoothFn.apply(_f32(img), _f32(flow), alpha)
+    if _tracing():
+        from . import torch_ops  # noqa: F401
+        s = torch.ops.ocflow.smooth_loss(_f32(img), _f32(flow), float(alpha))
+    else:
+        s = _SmoothFn.apply(_f32(img), _f32(flow), alpha)
     nan = float("nan")  # torch.mean over an empty tensor is nan in the reference too
     n = [B * 2 * H * (W - 1), B * 2 * (H - 1) * W, B * 2 * H * (W - 2), B * 2 * (H - 2) * W]
     inv = [1.0 / v if v > 0 else nan for v in n]
@@ -625,6 +761,14 @@ def _range_map(flow, want_occ):
     _check4(flow, "flow", 2)
     _require_hip(flow)
     f = _f32(flow.detach())
+    if _tracing():
+        from . import torch_ops  # noqa: F401
+        rng, occ = torch.ops.ocflow.range_map(f, bool(want_occ))
+        return rng, (occ if want_occ else None)
+    return _range_map_raw(f, want_occ)
+
+
+def _range_map_raw(f, want_occ):
     B, _, H, W = f.shape
     rng = torch.empty((B, 1, H, W), device=f.device, dtype=torch.float32)
     occ = torch.empty_like(rng) if want_occ else None
@@ -637,7 +781,8 @@ def _range_map(flow, want_occ):
                        "ocf_range_map_det")
         else:
             _launch("range_map", lambda: _meta(f"B{B}x{H}x{W}", B * H * W * 16),
-                    lambda: _lib.check(_lib.load().ocf_range_map(_t4(f), C.c_void_p(rng.data_ptr()), occ_p, B, H, W, _stream(f)), "ocf_range_map"))
+                    lambda: _lib.check(_lib.load().ocf_range_map(_t4(f), C.c_void_p(rng.data_ptr()), occ_p, B, H, W, POLICY.range_map, _stream(f)),
+                                       "ocf_range_map"))
     return rng, occ
 
 
@@ -744,7 +889,7 @@ def conv3x3_wgrad(x, gy, dilation=1, out=None):
     so, si, sky, skx = out.stride()
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ocf_conv3x3_wgrad(_t4(x), _t4(gy), C.c_void_p(out.data_ptr()), so, si, sky, skx, B, Ci, Co, H, W, int(dilation),
-                                                 _dtype_code(x), _stream(x)), "ocf_conv3x3_wgrad")
+                                                 _dtype_code(x), POLICY.wgrad, _stream(x)), "ocf_conv3x3_wgrad")
     return out
 
 

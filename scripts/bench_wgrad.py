@@ -39,15 +39,12 @@ for B, Ci, Co, H, W, d in SHAPES:
     got = ops.conv3x3_wgrad(x, gy, d)
     err = float((got - ref).abs().max() / ref.abs().max())
     acc = torch.zeros((Co, Ci, 3, 3), device=dev).contiguous(memory_format=torch.channels_last)
-    from ocflow_amd import _lib
-    L = _lib.load()
-    L.ocf_conv3x3_wgrad_select(2)
-    got2 = ops.conv3x3_wgrad(x, gy, d)
-    err2 = float((got2 - ref).abs().max() / ref.abs().max())
-    t_v2 = timeit(lambda: ops.conv3x3_wgrad(x, gy, d, out=acc))
-    L.ocf_conv3x3_wgrad_select(1)
-    t_ours = timeit(lambda: ops.conv3x3_wgrad(x, gy, d, out=acc))
-    L.ocf_conv3x3_wgrad_select(0)
+    with ops.kernel_policy(wgrad=2):
+        got2 = ops.conv3x3_wgrad(x, gy, d)
+        err2 = float((got2 - ref).abs().max() / ref.abs().max())
+        t_v2 = timeit(lambda: ops.conv3x3_wgrad(x, gy, d, out=acc))
+    with ops.kernel_policy(wgrad=1):
+        t_ours = timeit(lambda: ops.conv3x3_wgrad(x, gy, d, out=acc))
     t_mi = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, [False, True, False]))
     flops = 2.0 * B * H * W * Ci * Co * 9
     print(f"B{B} {Ci:3d}->{Co:3d} {H}x{W} d{d:2d} | v2 {t_v2:7.1f} us ({flops / t_v2 / 1e6:6.1f} TF/s, err {err2:.1e}) | v1 {t_ours:7.1f} us ({flops / t_ours / 1e6:6.1f} TF/s) | MIOpen (kernel + helpers) {t_mi:7.1f} us | "

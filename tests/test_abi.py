@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in include/ocflow_hip.h but not exported"
-    assert lib.ocf_abi_version() == 1
+    assert lib.ocf_abi_version() == 2
     assert set(_lib.SIGNATURES) | {"ocf_status_string"} == set(declared_functions())
     assert lib.ocf_status_string(0) == b"ok" and lib.ocf_status_string(-2) == b"unsupported configuration"
 
@@ -49,12 +49,24 @@ def test_argument_validation_without_device():
     lib = _lib.load()
     t = _lib.Tensor4(0, 0, 0, 0, 0)
     good = _lib.Tensor4(16, 1, 1, 1, 1)
-    assert lib.ocf_corr_fwd(None, None, None, None, None, 1, 1, 1, 1, 4, 1.0, 0, 0, None) == -1
-    assert lib.ocf_corr_fwd(C.byref(t), C.byref(t), None, None, C.byref(t), 1, 1, 1, 1, 4, 1.0, 0, 0, None) == -1  # null data
-    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 9, 1.0, 0, 0, None) == -2  # d > 4
-    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 0, 1, 1, 1, 4, 1.0, 0, 0, None) == -1
+    assert lib.ocf_corr_fwd(None, None, None, None, None, 1, 1, 1, 1, 4, 1.0, 0, 0, 0, None) == -1
+    assert lib.ocf_corr_fwd(C.byref(t), C.byref(t), None, None, C.byref(t), 1, 1, 1, 1, 4, 1.0, 0, 0, 0, None) == -1  # null data
+    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 9, 1.0, 0, 0, 0, None) == -2  # d > 4
+    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 0, 1, 1, 1, 4, 1.0, 0, 0, 0, None) == -1
+    # kernel policies are per-call arguments (ABI version 2: the library holds no selection state); values outside their enum are rejected
+    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 4, 1.0, 0, 0, 9, None) == -1
+    assert lib.ocf_corr_fwd_variant(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 4, 1, 9) == -1
+    assert lib.ocf_corr_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 4, 0, 3, None) == -1
+    assert lib.ocf_corr_bwd_variant(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 4, 0, 3) == -1
+    assert lib.ocf_warp_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 1.0, 0, 0, 3, None) == -1
+    assert lib.ocf_warp_bwd_plan(C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 0, 3) == -1
+    assert lib.ocf_range_map(C.byref(good), C.c_void_p(16), None, 1, 1, 1, 3, None) == -1
+    for gone in ("ocf_corr_fwd_select", "ocf_corr_bwd_select", "ocf_warp_bwd_select", "ocf_range_map_select", "ocf_conv3x3_wgrad_select"):
+        assert not hasattr(lib, gone), gone
+    # the variant queries need no device: a strided fp32 request is the vector kernel, bf16 NCHW operands fall to the gather backward
+    assert lib.ocf_corr_fwd_variant(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 4, 0, 0) == 20
     assert lib.ocf_warp_fwd(None, None, None, 1, 1, 1, 1, 1.0, 0, 0, None) == -1
-    assert lib.ocf_range_map(None, None, None, 1, 1, 1, None) == -1
+    assert lib.ocf_range_map(None, None, None, 1, 1, 1, 0, None) == -1
     assert lib.ocf_photo_loss_fwd(None, None, None, None, None, 1, 3, 1, 1, None) == -1
     # the widened entry points (conv epilogue, occlusion-aware correlation backward, capture id)
     assert lib.ocf_bias_act_fwd(None, None, 1, 1, 1, 1, 0.1, 0, None) == -1
@@ -62,11 +74,11 @@ def test_argument_validation_without_device():
     assert lib.ocf_bias_act_bwd(None, None, None, None, 1, 1, 1, 1, 0.1, 0, 0, None) == -1
     # a pass-through backward (no input-gradient tensor) only exists for the plain bias epilogue (slope 1)
     assert lib.ocf_bias_act_bwd(None, C.byref(good), None, C.c_void_p(16), 1, 1, 1, 1, 0.1, 0, 0, None) == -1
-    assert lib.ocf_corr_occ_bwd(None, None, None, None, None, None, None, 1, 1, 1, 1, 4, 0, None) == -1
+    assert lib.ocf_corr_occ_bwd(None, None, None, None, None, None, None, 1, 1, 1, 1, 4, 0, 0, None) == -1
     assert lib.ocf_corr_occ_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, C.byref(good),
-                                1, 1, 1, 1, 4, 0, None) == -1  # d/docc is a by-product of the g2 pass
+                                1, 1, 1, 1, 4, 0, 0, None) == -1  # d/docc is a by-product of the g2 pass
     assert lib.ocf_corr_occ_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), C.byref(good), C.byref(good), None,
-                                1, 1, 1, 1, 9, 0, None) == -2
+                                1, 1, 1, 1, 9, 0, 0, None) == -2
     assert lib.ocf_stream_capture_id(None, None) == -1
 
 

@@ -1,9 +1,10 @@
 """GPU parity ON THE TIMED PATH: the exact shapes `bench.py` runs (8 pairs per GPU at 436x1024 => the five FPN pyramid levels
 B=8 x (C, h, w) below, and 8 x 3 x 436 x 1024 for the loss kernels), HIP kernels through the C ABI against the CPU oracle on the
 same seeded inputs.  Each correlation test also asserts WHICH kernel instantiation ran (ocf_corr_fwd_variant), under the automatic
-policy and with the band-GEMM kernels forced, so that every variant the benchmark can time is value-checked at its own shape:
-row kernel K1 / K2, direct kernel (3 / 4 / 7 channel blocks), band TH=8 with the persistent multi-tile walk (896 tiles > 512
-workgroups), band MULTI TH=4 / TH=2 / TH=1.
+policy, without the wave kernel and with the band-GEMM kernels forced (per-call policies of ABI version 2), so that every variant the
+benchmark can time is value-checked at its own shape: row kernel K1 / K2, wave kernel (3 / 4 / 7 channel blocks, one and two strips),
+direct kernel (3 / 4 / 7 channel blocks), band TH=8 with the persistent multi-tile walk (896 tiles > 512 workgroups), band MULTI
+TH=4 / TH=2 / TH=1.
 
 bf16 bar: inputs are bf16-rounded once, the oracle runs in fp32 on those values; the HIP result differs from it by the output's own
 bf16 rounding (<= 2^-8 relative) plus fp32 summation order => rtol 8e-3 (two bf16 ulps), atol 1e-3 of the value scale."""
@@ -67,20 +68,21 @@ def level_inputs(level, seed=0):
     return f1, f2, flow, occ
 
 
-# variant the automatic policy / the forced band policy must pick at B = 8 on a 256-CU MI355X
+# variant the automatic policy / the automatic policy without the wave kernel / the forced band policy must pick at B = 8 on a 256-CU MI355X
 EXPECTED = {
-    2: ("OCF_CORR_ROWS_K1", "OCF_CORR_BAND_TH8"),
-    3: ("OCF_CORR_ROWS_K2", "OCF_CORR_BAND_MULTI_TH4"),
-    4: ("OCF_CORR_DIRECT", "OCF_CORR_BAND_MULTI_TH2"),
-    5: ("OCF_CORR_DIRECT", "OCF_CORR_BAND_MULTI_TH1"),
-    6: ("OCF_CORR_DIRECT", "OCF_CORR_BAND_MULTI_TH1"),
+    2: ("OCF_CORR_ROWS_K1", "OCF_CORR_ROWS_K1", "OCF_CORR_BAND_TH8"),
+    3: ("OCF_CORR_ROWS_K2", "OCF_CORR_ROWS_K2", "OCF_CORR_BAND_MULTI_TH4"),
+    4: ("OCF_CORR_WAVE", "OCF_CORR_DIRECT", "OCF_CORR_BAND_MULTI_TH2"),
+    5: ("OCF_CORR_WAVE", "OCF_CORR_DIRECT", "OCF_CORR_BAND_MULTI_TH1"),
+    6: ("OCF_CORR_WAVE", "OCF_CORR_DIRECT", "OCF_CORR_BAND_MULTI_TH1"),
 }
-VARIANT_CODE = {"OCF_CORR_ROWS_K1": 1, "OCF_CORR_ROWS_K2": 2, "OCF_CORR_DIRECT": 3, "OCF_CORR_BAND_TH8": 11, "OCF_CORR_BAND_MULTI_TH4": 12,
-                "OCF_CORR_BAND_MULTI_TH2": 13, "OCF_CORR_BAND_MULTI_TH1": 14}
+VARIANT_CODE = {"OCF_CORR_ROWS_K1": 1, "OCF_CORR_ROWS_K2": 2, "OCF_CORR_DIRECT": 3, "OCF_CORR_WAVE": 4, "OCF_CORR_BAND_TH8": 11,
+                "OCF_CORR_BAND_MULTI_TH4": 12, "OCF_CORR_BAND_MULTI_TH2": 13, "OCF_CORR_BAND_MULTI_TH1": 14}
+POLICY_CODE = {"auto": 0, "no_wave": 2, "band": 1, "wave": 3}
 
 
 @pytest.mark.parametrize("level", [2, 3, 4, 5, 6])
-@pytest.mark.parametrize("policy", ["auto", "band"])
+@pytest.mark.parametrize("policy", ["auto", "no_wave", "band"])
 @pytest.mark.parametrize("with_occ", [True, False])
 def test_corr_forward_at_bench_shapes(ops, lib, level, policy, with_occ):
     """flow_occ_net.py:155-168 at the benchmark's shapes: warp(f2, flow * 20/2^level) -> * occ -> cost volume"""
@@ -89,15 +91,12 @@ def test_corr_forward_at_bench_shapes(ops, lib, level, policy, with_occ):
     fs = 20.0 / 2 ** level
     L = lib.load()
     a, b2, fl, oc = cl(f1), cl(f2), flow.to(DEV), occ.to(DEV) if with_occ else None
-    try:
-        assert L.ocf_corr_fwd_select(1 if policy == "band" else 0) == 0
+    with ops.kernel_policy(corr_fwd=POLICY_CODE[policy]):
         w2 = ops.warp(b2, fl, False, flow_scale=fs) if level != 6 else b2  # level 6 is not warped (flow_occ_net.py:151)
         out = ops.corr_warp(a, w2, None, oc, 4)
-        got_variant = L.ocf_corr_fwd_variant(_t4(lib, a), _t4(lib, w2), None, _t4(lib, oc) if with_occ else None, _t4(lib, out), B, Cc, h, w,
-                                             4, lib.OCF_BF16)
-    finally:
-        L.ocf_corr_fwd_select(0)
-    assert got_variant == VARIANT_CODE[EXPECTED[level][1 if policy == "band" else 0]], got_variant
+    got_variant = L.ocf_corr_fwd_variant(_t4(lib, a), _t4(lib, w2), None, _t4(lib, oc) if with_occ else None, _t4(lib, out), B, Cc, h, w,
+                                         4, lib.OCF_BF16, POLICY_CODE[policy])
+    assert got_variant == VARIANT_CODE[EXPECTED[level][("auto", "no_wave", "band").index(policy)]], got_variant
     assert out.dtype == torch.bfloat16 and out.shape == (B, 81, h, w) and out.stride(1) == 1
     if level != 6:
         assert_close(w2, O.warp(f2.float(), flow * fs, False), 8e-3, 4e-3, "warp forward")
@@ -111,16 +110,72 @@ def test_corr_forward_at_bench_shapes(ops, lib, level, policy, with_occ):
 def test_row_kernel_equals_band_kernel_bitwise(ops, lib, level):
     """same products, same fp32 accumulation order inside the MFMA, same scaling order: the two kernels agree bit for bit"""
     f1, f2, _, occ = level_inputs(level, seed=3)
-    L = lib.load()
     a, b2, oc = cl(f1), cl(f2), occ.to(DEV)
-    try:
-        L.ocf_corr_fwd_select(1)
+    with ops.kernel_policy(corr_fwd=POLICY_CODE["band"]):
         band = ops.corr_warp(a, b2, None, oc, 4)
         band_plain = ops.corr_warp(a, b2, None, None, 4)
+    for policy in ("auto", "no_wave", "wave"):  # row / wave / direct kernels: all bit-identical to the band kernel
+        with ops.kernel_policy(corr_fwd=POLICY_CODE[policy]):
+            assert torch.equal(ops.corr_warp(a, b2, None, oc, 4), band), policy
+            assert torch.equal(ops.corr_warp(a, b2, None, None, 4), band_plain), policy
+
+
+@pytest.mark.parametrize("level", [2, 3, 4, 5, 6])
+def test_cost_volume_written_into_the_decoder_input_buffer(ops, lib, level):
+    """`out=`: the cost volume lands in the first 81 channels of a 128-channel channels_last buffer (the decoder input of
+    flow_occ_net.py:171-176: [cost volume | features | flow | flow features | alignment]) -- the wave kernel takes any pixel pitch.
+    Same bits as the dense result, the rest of the buffer untouched."""
+    f1, f2, _, occ = level_inputs(level, seed=5)
+    Cc, h, w = LEVELS[level]
+    a, b2, oc = cl(f1), cl(f2), occ.to(DEV)
+    dense = ops.corr_warp(a, b2, None, oc, 4)
+    buf = torch.full((B, 128, h, w), 7.0, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    v = lib.load().ocf_corr_fwd_variant(_t4(lib, a), _t4(lib, b2), None, _t4(lib, oc), _t4(lib, buf[:, :81]), B, Cc, h, w, 4, lib.OCF_BF16, 0)
+    assert v == VARIANT_CODE["OCF_CORR_WAVE"], v
+    res = ops.corr_warp(a, b2, None, oc, 4, out=buf[:, :81])
+    assert res.data_ptr() == buf.data_ptr() and torch.equal(res, dense)
+    assert float((buf[:, 81:].float() - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("level", [4, 5])
+@pytest.mark.parametrize("with_occ", [True, False])
+def test_fused_warp_correlation_equals_two_launches(ops, lib, level, with_occ, monkeypatch):
+    """K1+K2 as ONE launch at the small levels (flow_net.py:110-112 / the no-grad second forward of models/model.py:381-388): the wave kernel
+    gathers warp(f2, flow * 20/2^level) in registers -- bit-identical to ocf_warp_fwd followed by the correlation kernel, and chosen
+    automatically when no gradient is recorded"""
+    f1, f2, flow, occ = level_inputs(level, seed=6)
+    Cc, h, w = LEVELS[level]
+    fs = 20.0 / 2 ** level
+    flow[:, :, :2] *= 30.0  # sources far outside the image
+    a, b2, fl, oc = cl(f1), cl(f2), flow.to(DEV), occ.to(DEV) if with_occ else None
+    monkeypatch.setattr(ops, "_FUSED_WARP", "0")
+    two = ops.corr_warp(a, b2, fl, oc, 4, fs, False)
+    monkeypatch.setattr(ops, "_FUSED_WARP", "auto")
+    out = torch.empty_like(two)
+    v = lib.load().ocf_corr_fwd_variant(_t4(lib, a), _t4(lib, b2), _t4(lib, fl), _t4(lib, oc) if with_occ else None, _t4(lib, out), B, Cc, h, w,
+                                        4, lib.OCF_BF16, 0)
+    assert v == VARIANT_CODE["OCF_CORR_WAVE"], v
+    timer_calls = []
+
+    class Spy:
+        def launch(self, name, meta, fn):
+            timer_calls.append(name)
+            return fn()
+
+    ops.set_kernel_timer(Spy())
+    try:
+        with torch.no_grad():
+            one = ops.corr_warp(a, b2, fl, oc, 4, fs, False)
+        assert timer_calls == ["corr_warp_fwd"], timer_calls  # a single launch, no warp kernel
+        timer_calls.clear()
+        x = a.clone().requires_grad_()
+        ops.corr_warp(x, b2, fl, oc, 4, fs, False)
+        assert timer_calls == ["warp_fwd", "corr_fwd"], timer_calls  # a recorded forward keeps the warped tensor for backward
     finally:
-        L.ocf_corr_fwd_select(0)
-    assert torch.equal(ops.corr_warp(a, b2, None, oc, 4), band)
-    assert torch.equal(ops.corr_warp(a, b2, None, None, 4), band_plain)
+        ops.set_kernel_timer(None)
+    assert torch.equal(one, two)
+    w2 = O.warp(f2.float(), flow * fs, False).bfloat16().float()
+    assert_close(one, O.compute_cost_volume(f1.float(), w2 * occ if with_occ else w2, 4), 8e-3, 2e-3, f"fused level {level}")
 
 
 @pytest.mark.parametrize("shape", [(1, 32, 5, 40), (2, 24, 9, 33), (1, 64, 7, 70), (3, 40, 13, 31), (1, 8, 1, 8), (2, 32, 4, 64), (1, 56, 3, 100),
@@ -139,8 +194,13 @@ def test_row_kernel_edge_tiles(ops, lib, shape, with_occ):
     out = ops.corr_warp(a, b2, None, oc, 4)
     if (w * 81 * 2) % 16 == 0:  # rows of the dense output start on 16-byte boundaries: the row kernel's precondition
         v = lib.load().ocf_corr_fwd_variant(_t4(lib, a), _t4(lib, b2), None, _t4(lib, oc) if with_occ else None, _t4(lib, out), Bb, Cc, h, w, 4,
-                                            lib.OCF_BF16)
-        assert v in (1, 2, 3), v
+                                            lib.OCF_BF16, 0)
+        assert v in (1, 2, 3, 4), v
+        if v == 4:  # the direct kernel the wave kernel replaced is still value-checked at these edge shapes
+            with ops.kernel_policy(corr_fwd=POLICY_CODE["no_wave"]):
+                assert torch.equal(ops.corr_warp(a, b2, None, oc, 4), out)
+    with ops.kernel_policy(corr_fwd=POLICY_CODE["wave"]):  # and the wave kernel at every edge shape (C <= 64 included, odd widths: any pitch)
+        assert torch.equal(ops.corr_warp(a, b2, None, oc, 4), out)
     ref = O.compute_cost_volume(f1.float(), f2.float() * occ if with_occ else f2.float(), 4)
     assert_close(out, ref, 8e-3, 1e-3)
 
@@ -238,17 +298,16 @@ def test_range_map_full_batch_vs_oracle(ops):
     flow = torch.nn.functional.interpolate(torch.randn((B, 2, 28, 64), generator=gen) * 6, size=(436, 1024), mode="bilinear")
     flow[:, :, :3, :] *= 20.0  # far out of the window / out of the image
     from ocflow_amd import _lib
-    for det, policy in ((False, 1), (False, 0), (True, 1)):  # splat kernel, gather + far kernels, fixed-point deterministic kernel
+    for det, policy in ((False, _lib.RANGE_SPLAT), (False, _lib.RANGE_GATHER), (True, _lib.RANGE_AUTO)):  # splat kernel, gather + far kernels, fixed-point deterministic kernel
         ops.set_deterministic(det)
-        _lib.load().ocf_range_map_select(policy)
         try:
-            rm = ops.compute_range_map(flow.to(DEV))
-            oc = ops.occlusion_from_flow(flow.to(DEV))
-            if det:
-                assert torch.equal(rm, ops.compute_range_map(flow.to(DEV)))
+            with ops.kernel_policy(range_map=policy):
+                rm = ops.compute_range_map(flow.to(DEV))
+                oc = ops.occlusion_from_flow(flow.to(DEV))
+                if det:
+                    assert torch.equal(rm, ops.compute_range_map(flow.to(DEV)))
         finally:
             ops.set_deterministic(False)
-            _lib.load().ocf_range_map_select(1)
         ref = O.compute_range_map(flow)
         assert_close(rm, ref, 1e-4, 1e-6, "range map")
         assert_close(oc, O.occlusion_from_range(ref), 1e-4, 1e-5, "occlusion")
@@ -258,7 +317,7 @@ def test_range_map_full_batch_vs_oracle(ops):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ac", [False, True])
 def test_warp_backward_gather_kernels_small_shapes(ops, lib, shape, dtype, ac):
-    """the gather + per-source kernel pair forced on (ocf_warp_bwd_select(2)) at shapes the automatic policy would give to the scatter
+    """the gather + per-source kernel pair forced on (policy OCF_WARP_BWD_POLICY_GATHER) at shapes the automatic policy would give to the scatter
     kernel: partial tiles, channel counts that are not a multiple of 32 (40, 196: 8-byte aligned pixels), fp32, both sampling
     conventions, flows with many FAR sources (|displacement| > 6 px: the float-atomic path inside the per-source kernel) and sources
     that leave the image -- against autograd of the oracle's grid_sample warp, and bit-identical grad_img on a second run"""
@@ -269,13 +328,9 @@ def test_warp_backward_gather_kernels_small_shapes(ops, lib, shape, dtype, ac):
     cot = torch.randn(shape, generator=gen).to(dtype)
     a, f = img.float().requires_grad_(), flow.clone().requires_grad_()
     gir, gfr = torch.autograd.grad(O.warp(a, f, ac), (a, f), cot.float())
-    L = lib.load()
-    try:
-        assert L.ocf_warp_bwd_select(2) == 0
+    with ops.kernel_policy(warp_bwd=lib.WARP_BWD_GATHER):
         x, fl = cl(img).requires_grad_(), flow.to(DEV).requires_grad_()
         gi, gf = torch.autograd.grad(ops.warp(x, fl, ac), (x, fl), cl(cot))
-    finally:
-        L.ocf_warp_bwd_select(0)
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert_close(gi, gir, tol * 5, tol, "grad img")
     assert_close(gf, gfr, tol * 5, tol, "grad flow", outliers=2e-3)

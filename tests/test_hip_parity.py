@@ -80,7 +80,7 @@ def test_corr_vs_oracle(ops, shape, d, dtype, cl):
 @pytest.mark.parametrize("fused", [False, True])
 def test_corr_warp_fused(ops, ac, with_occ, cl, fused, monkeypatch):
     """corr_warp with a flow, both forms: warp kernel + correlation kernel (default) and the single fused launch"""
-    monkeypatch.setattr(ops, "_FUSED_WARP", fused)
+    monkeypatch.setattr(ops, "_FUSED_WARP", "1" if fused else "0")
     gen = torch.Generator().manual_seed(5)
     B, C, H, W = 2, 24, 19, 37
     f1 = torch.randn((B, C, H, W), generator=gen).requires_grad_()
@@ -114,7 +114,7 @@ def test_corr_bf16_matrix_core_modes(ops, shape, d, mode, layout, monkeypatch):
     x every layout (dense channels_last fast path, NCHW, strided channel slice) x single / multi channel block / partial last
     block (C=196, C=40) / d < 4, against the oracle on the same bf16-rounded inputs.  Tolerance 2e-2: bf16 output rounding
     (+ the warp's bf16 rounding of the gathered features in the fused mode)."""
-    monkeypatch.setattr(ops, "_FUSED_WARP", True)  # this test is about the kernel's staging modes: keep the warp inside it
+    monkeypatch.setattr(ops, "_FUSED_WARP", "1")  # this test is about the kernels' staging modes: keep the warp inside them
     gen = torch.Generator().manual_seed((hash((shape, d, mode)) & 0xffff) + 1)
     B, C, H, W = shape
     f1 = torch.randn(shape, generator=gen).bfloat16()
@@ -143,7 +143,7 @@ def test_corr_bf16_matrix_core_modes(ops, shape, d, mode, layout, monkeypatch):
     if flow is not None and layout != "nchw":
         # the default two-launch form (warp kernel, then the correlation kernel) produces the same cost volume bit for bit:
         # both round the gathered operand to bf16 before the contraction
-        monkeypatch.setattr(ops, "_FUSED_WARP", False)
+        monkeypatch.setattr(ops, "_FUSED_WARP", "0")
         out2 = ops.corr_warp(lay(f1), lay(f2), flow.to(DEV), None if occ is None else occ.to(DEV), d, 1.25, False)
         assert torch.equal(out2, out)
 
@@ -161,12 +161,22 @@ def test_corr_bf16_output_into_concat_buffer(ops):
     buf = torch.zeros((2, 81 + 32 + 4, 16, 48), device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     dst = buf[:, 0:81]
     T4 = lambda t: C.byref(_lib.Tensor4(t.data_ptr(), *t.stride()))
-    st = _lib.load().ocf_corr_fwd(T4(a), T4(b), None, None, T4(dst), 2, 32, 16, 48, 4, 1.0, 0, _lib.OCF_BF16,
-                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    assert st == 0
-    torch.cuda.synchronize()
-    close(buf[:, 0:81], ref, 2e-2)
-    assert float(buf[:, 81:].abs().max()) == 0.0  # neighbours in the buffer untouched
+    for policy in (_lib.CORR_AUTO, _lib.CORR_BAND_ONLY):  # the wave kernel (any pixel pitch) and the band kernel's generic epilogue
+        buf.zero_()
+        st = _lib.load().ocf_corr_fwd(T4(a), T4(b), None, None, T4(dst), 2, 32, 16, 48, 4, 1.0, 0, _lib.OCF_BF16, policy,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert st == 0
+        torch.cuda.synchronize()
+        close(buf[:, 0:81], ref, 2e-2)
+        assert float(buf[:, 81:].abs().max()) == 0.0  # neighbours in the buffer untouched
+    assert _lib.load().ocf_corr_fwd_variant(T4(a), T4(b), None, None, T4(dst), 2, 32, 16, 48, 4, _lib.OCF_BF16, 0) == _lib.CORR_VARIANT_WAVE
+    # the operator surface: out= writes there (forward only: refused while a gradient is being recorded)
+    buf.zero_()
+    res = ops.corr_warp(a, b, None, None, 4, out=buf[:, 0:81])
+    assert res.data_ptr() == buf.data_ptr() and float(buf[:, 81:].abs().max()) == 0.0
+    close(res, ref, 2e-2)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        ops.corr_warp(a.clone().requires_grad_(), b, None, None, 4, out=buf[:, 0:81])
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 21, 45), (1, 64, 12, 40), (1, 128, 14, 32), (1, 196, 7, 16)])
@@ -596,8 +606,8 @@ def test_corr_backward_odd_shapes(ops, shape, d, dtype, with_occ):
 @pytest.mark.parametrize("with_occ", [False, True])
 @pytest.mark.parametrize("sliced", [False, True])
 def test_corr_backward_matrix_core_kernel(ops, shape, with_occ, sliced):
-    """the band-GEMM backward (corr_bwd_mfma.hip), forced with ocf_corr_bwd_select(2) at shapes the automatic policy leaves to the vector
-    kernel: edge tiles in both directions, 1-pixel-wide / 1-pixel-high maps, channel counts that are not a multiple of the 32-channel
+    """the band-GEMM backward (corr_bwd_mfma.hip, policy OCF_CORR_BWD_POLICY_MFMA = what the automatic policy picks whenever the layout
+    allows) against the vector kernel (OCF_CORR_BWD_POLICY_VECTOR): edge tiles in both directions, 1-pixel-wide / 1-pixel-high maps, channel counts that are not a multiple of the 32-channel
     block (196, 100, 36), the gradient arriving as a 2-byte aligned channel slice (first and last pixels of the tensor: the clamped
     and shifted operand windows), occlusion (d/docc by-product).  Against fp32 autograd of the oracle, and against the vector kernel
     (same products, different summation order: within one bf16 rounding of the gradient scale)."""
@@ -618,21 +628,17 @@ def test_corr_backward_matrix_core_kernel(ops, shape, with_occ, sliced):
     cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
 
     def run(policy):
-        assert lib.ocf_corr_bwd_select(policy) == 0
-        try:
+        with ops.kernel_policy(corr_bwd=policy):
             x, y = cl(f1).requires_grad_(), cl(f2).requires_grad_()
             oc = occ.to(DEV).requires_grad_() if with_occ else None
             out = torch.cat([ops.corr_warp(x, y, None, oc, 4), cl(extra)], 1)
             return torch.autograd.grad(out, (x, y, oc) if with_occ else (x, y), cl(cot))
-        finally:
-            lib.ocf_corr_bwd_select(0)
 
-    got, vec = run(2), run(1)
+    got, vec = run(_lib.CORR_BWD_MFMA), run(_lib.CORR_BWD_VECTOR)
     for g_, v_, w_ in zip(got, vec, want):
         scale = float(w_.abs().max()) + 1e-12
         np.testing.assert_allclose(g_.float().cpu().numpy(), w_.numpy(), rtol=0.1, atol=2e-2 * scale)
         np.testing.assert_allclose(g_.float().cpu().numpy(), v_.float().cpu().numpy(), rtol=0, atol=1e-2 * scale)
-    assert lib.ocf_corr_bwd_select(3) != 0
 
 
 def test_torch_library_ops(ops):
@@ -662,6 +668,101 @@ def test_torch_library_ops(ops):
 
     compiled = torch.compile(fn, backend="aot_eager", fullgraph=True)
     assert abs(float(compiled(f1, f2, fl)) - float(fn(f1, f2, fl))) < 1e-6
+
+
+def test_torch_library_loss_and_fused_ops(ops):
+    """the other registered operators (SURVEY 7 step 3): ocflow::corr_warp (flow and occlusion optional), ocflow::photo_loss,
+    ocflow::smooth_loss, ocflow::range_map -- same values and gradients as the reference-named entry points, opcheck (schema + fake
+    kernels), and ocflow::cost_volume's backward is a stateless operator on the saved tensors (no forward re-run)"""
+    import ocflow_amd.torch_ops  # noqa: F401
+    gen = torch.Generator().manual_seed(13)
+    B, C_, H, W = 2, 32, 12, 20
+    f1 = torch.randn((B, C_, H, W), generator=gen).to(DEV).requires_grad_()
+    f2 = torch.randn((B, C_, H, W), generator=gen).to(DEV).requires_grad_()
+    fl = (torch.randn((B, 2, H, W), generator=gen) * 2).to(DEV).requires_grad_()
+    oc = torch.rand((B, 1, H, W), generator=gen).to(DEV).requires_grad_()
+    cot = torch.randn((B, 81, H, W), generator=gen).to(DEV)
+    for flow, occ in ((fl, oc), (fl, None), (None, oc), (None, None)):
+        out, _ = torch.ops.ocflow.corr_warp(f1, f2, flow, occ, 4, 1.25, False)
+        ref = ops.corr_warp(f1, f2, flow, occ, 4, 1.25, False)
+        assert torch.equal(out, ref)
+        ins = [t for t in (f1, f2, flow, occ) if t is not None]
+        for a, b in zip(torch.autograd.grad(out, ins, cot), torch.autograd.grad(ref, ins, cot)):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5)  # (warp backward: float atomics)
+        torch.library.opcheck(torch.ops.ocflow.corr_warp.default, (f1.detach(), f2.detach(), None if flow is None else flow.detach(),
+                                                                   None if occ is None else occ.detach(), 4, 1.25, False),
+                              test_utils=("test_schema", "test_faketensor"))
+    g1, g2 = torch.ops.ocflow.cost_volume_backward(f1.detach(), f2.detach(), cot, 4)
+    r1, r2 = torch.autograd.grad(ops.compute_cost_volume(f1, f2, 4), (f1, f2), cot)
+    assert torch.equal(g1, r1) and torch.equal(g2, r2)
+    img = (torch.rand((B, 6, H, W), generator=gen) * 2 - 1).to(DEV)
+    img1, img2 = img[:, :3], img[:, 3:]
+    mask = (torch.rand((B, 1, H, W), generator=gen) < 0.3).float().to(DEV)
+    for flow, occ in ((fl, mask), (fl, None)):
+        s = torch.ops.ocflow.photo_loss(img1, img2, flow, occ)
+        ref = ops.warp_photometric_error(img1, img2, flow, occ)
+        got = s[0] / (s[1] * 3 + 1e-16) if occ is not None else s[0] / float(img1.numel())
+        assert abs(float(got) - float(ref)) < 1e-6
+        (ga,), (gb,) = torch.autograd.grad(got, (flow,)), torch.autograd.grad(ref, (flow,))
+        np.testing.assert_allclose(ga.cpu().numpy(), gb.cpu().numpy(), rtol=1e-5, atol=1e-8)
+        torch.library.opcheck(torch.ops.ocflow.photo_loss.default, (img1, img2, flow.detach(), occ), test_utils=("test_schema", "test_faketensor"))
+    s = torch.ops.ocflow.smooth_loss(img1, fl, 100.0)
+    r = ops._SmoothFn.apply(img1.float(), fl, 100.0)
+    assert torch.equal(s, r)
+    w = torch.tensor([0.3, 0.2, 0.4, 0.1], device=DEV)
+    np.testing.assert_allclose(torch.autograd.grad((s * w).sum(), fl)[0].cpu().numpy(), torch.autograd.grad((r * w).sum(), fl)[0].cpu().numpy(),
+                               rtol=1e-6, atol=1e-9)
+    torch.library.opcheck(torch.ops.ocflow.smooth_loss.default, (img1, fl.detach(), 100.0), test_utils=("test_schema", "test_faketensor"))
+    rng, occl = torch.ops.ocflow.range_map(fl.detach(), True)
+    np.testing.assert_allclose(rng.cpu().numpy(), ops.compute_range_map(fl).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(occl.cpu().numpy(), ops.occlusion_from_flow(fl).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    torch.library.opcheck(torch.ops.ocflow.range_map.default, (fl.detach(), True), test_utils=("test_schema", "test_faketensor"))
+
+
+def test_compiled_flowoccnet_level_and_loss_on_registered_ops(ops):
+    """torch.compile(fullgraph=True) of one whole level of FlowOccNet (flow_occ_net.py:151-180: warp -> occlusion estimator -> mask ->
+    cost volume -> flow estimator) plus the unsupervised loss side (image warp + photometric + smoothness + range-map occlusion): under
+    the tracer the reference-named entry points dispatch to torch.ops.ocflow.*, so the graph has no break; values and gradients equal
+    the eager run"""
+    import ocflow_amd.torch_ops  # noqa: F401
+    from ocflow_amd.models.networks._epilogue import cat_aligned
+    from ocflow_amd.models.networks.flow_net import FLOW_IN_CHANNELS, LEVELS, OpticalFlowEstimator
+    from ocflow_amd.models.networks.flow_occ_net import OCC_IN_CHANNELS, OcclusionEstimator
+    i = LEVELS.index(4)
+    torch.manual_seed(5)
+    occ_est = OcclusionEstimator(OCC_IN_CHANNELS[i], level=4).to(DEV)
+    flow_est = OpticalFlowEstimator(FLOW_IN_CHANNELS[i], level=4).to(DEV)
+    gen = torch.Generator().manual_seed(14)
+    B, C_, H, W = 2, 96, 16, 24
+    f1 = torch.randn((B, C_, H, W), generator=gen).to(DEV)
+    f2 = torch.randn((B, C_, H, W), generator=gen).to(DEV)
+    flow_up = (torch.randn((B, 2, H, W), generator=gen) * 0.5).to(DEV)
+    extras = [torch.randn((B, 1, H, W), generator=gen).to(DEV) for _ in range(2)] + [torch.randn((B, 2, H, W), generator=gen).to(DEV)]
+    imgs = (torch.rand((B, 6, 2 * H, 2 * W), generator=gen) * 2 - 1).to(DEV)
+
+    def level(f1, f2, flow_up, occ_feat_up, occ_up, flow_feat_up, imgs):
+        warped2 = ops.warp(f2, flow_up, False, flow_scale=20.0 / 16)
+        occ, occ_up2, occ_feat_up2 = occ_est(cat_aligned([f1, warped2, occ_feat_up, occ_up]), 2 * H, 2 * W)
+        corr = ops.corr_warp(f1, warped2, None, occ, 4)
+        flow, flow_up2, _ = flow_est(cat_aligned([corr, f1, flow_up, flow_feat_up]), 2 * H, 2 * W)
+        with torch.no_grad():
+            mask = ops.occlusion_from_flow(-flow_up2)
+        photo = ops.warp_photometric_error(imgs[:, :3], imgs[:, 3:], flow_up2, mask)
+        s1, s2 = ops.smoothness_losses(imgs[:, :3], flow_up2)
+        return 4.0 * photo + 0.5 * s1 + 0.1 * s2 + occ_up2.mean()
+
+    params = list(occ_est.parameters()) + list(flow_est.parameters())
+    args = (f1, f2, flow_up, *extras, imgs)
+    eager = level(*args)
+    g_eager = torch.autograd.grad(eager, params, allow_unused=True)
+    compiled = torch.compile(level, backend="aot_eager", fullgraph=True)
+    out = compiled(*args)
+    assert abs(float(out) - float(eager)) < 1e-5 * max(1.0, abs(float(eager)))
+    g_comp = torch.autograd.grad(out, params, allow_unused=True)
+    for a, b in zip(g_comp, g_eager):
+        assert (a is None) == (b is None)
+        if a is not None:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-3, atol=2e-4 * float(b.abs().max()) + 1e-9)
 
 
 def test_psnr_golden(ops, golden):
@@ -802,16 +903,12 @@ def test_conv3x3_wgrad_vs_fp32_reference(ops, shape, d, version):
     ref = torch.ops.aten.convolution_backward(gy.float(), x.float(), w, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, [False, True, False])[1]
     from ocflow_amd import _lib
     lib = _lib.load()
-    assert lib.ocf_conv3x3_wgrad_select(version) == 0
-    try:
+    with ops.kernel_policy(wgrad=version):
         got = ops.conv3x3_wgrad(x, gy, d)
         assert got.dtype == torch.float32 and got.shape == ref.shape
         np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
         again = ops.conv3x3_wgrad(x, gy, d, out=got.clone())  # accumulates
         np.testing.assert_allclose(again.cpu().numpy(), 2 * ref.cpu().numpy(), rtol=2e-4, atol=4e-4 * float(ref.abs().max()))
-    finally:
-        lib.ocf_conv3x3_wgrad_select(0)
-    assert lib.ocf_conv3x3_wgrad_select(3) != 0
 
 
 def test_conv3x3_autograd_path_matches_framework(ops):

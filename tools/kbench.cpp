@@ -57,46 +57,63 @@ int main(int argc, char** argv) {
     CK(hipMemset(out, 0, no * es));
     ocf_tensor4 t1 = mkt(f1, B, C, H, W, cl), t2 = mkt(f2, B, C, H, W, cl), to = mkt(out, B, 81, H, W, cl), tg1 = mkt(g1, B, C, H, W, cl), tg2 = mkt(g2, B, C, H, W, cl);
     ocf_tensor4 tf = mkt(flow, B, 2, H, W, false), tc = mkt(occ, B, 1, H, W, false), tgi = mkt(gimg, B, C, H, W, cl), tgf = mkt(gflow, B, 2, H, W, false);
-    // A/B of the kernel selection policies (same results, different kernels) + a bitwise cross-check of the two outputs
-    const int var_auto = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt);
-    ocf_corr_fwd_select(OCF_CORR_POLICY_BAND_ONLY);
-    const int var_band = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt);
-    float a_band = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, nullptr, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
-    float b_band = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
+    // A/B of the per-call kernel policies (same results, different kernels) + a bitwise cross-check of the outputs
+    const int var_auto = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt, OCF_CORR_POLICY_AUTO);
+    const int var_nowave = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt, OCF_CORR_POLICY_NO_WAVE);
+    const int var_band = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt, OCF_CORR_POLICY_BAND_ONLY);
+    auto fwd = [&](const ocf_tensor4* occp, int policy, const ocf_tensor4* outp) {
+      return time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, occp, outp, B, C, H, W, 4, 1.f, 0, dt, policy, st); }, st);
+    };
+    const float a_band = fwd(nullptr, OCF_CORR_POLICY_BAND_ONLY, &to), b_band = fwd(&tc, OCF_CORR_POLICY_BAND_ONLY, &to);
     std::vector<unsigned char> ref(no * es), got(no * es);
     CK(hipStreamSynchronize(st)); CK(hipMemcpy(ref.data(), out, no * es, hipMemcpyDeviceToHost));
-    ocf_corr_fwd_select(OCF_CORR_POLICY_AUTO);
-    float a = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, nullptr, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
-    float b = time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, 1.f, 0, dt, st); }, st);
+    const float a_nw = fwd(nullptr, OCF_CORR_POLICY_NO_WAVE, &to), b_nw = fwd(&tc, OCF_CORR_POLICY_NO_WAVE, &to);
+    const float a_wv = fwd(nullptr, OCF_CORR_POLICY_WAVE, &to), b_wv = fwd(&tc, OCF_CORR_POLICY_WAVE, &to);
+    const float a = fwd(nullptr, OCF_CORR_POLICY_AUTO, &to), b = fwd(&tc, OCF_CORR_POLICY_AUTO, &to);
     CK(hipStreamSynchronize(st)); CK(hipMemcpy(got.data(), out, no * es, hipMemcpyDeviceToHost));
     size_t ndiff = 0;
     for (size_t i = 0; i < no * es; i++) ndiff += ref[i] != got[i];
-    printf("  variant auto %d (corr %.1f us, +occ %.1f us) | band-only %d (corr %.1f us, +occ %.1f us) | bytes differing between the two +occ outputs: %zu\n",
-           var_auto, a, b, var_band, a_band, b_band, ndiff);
-    float c = time_us([&] { ocf_corr_fwd(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, 1.25f, 0, dt, st); }, st);
+    printf("  corr fwd (plain / +occ us): auto[%d] %.1f / %.1f | no-wave[%d] %.1f / %.1f | wave-forced %.1f / %.1f | band[%d] %.1f / %.1f | bytes differing auto vs band (+occ): %zu\n",
+           var_auto, a, b, var_nowave, a_nw, b_nw, a_wv, b_wv, var_band, a_band, b_band, ndiff);
+    // cost volume written into a 128-channel buffer (the decoder input): pixel pitch 256 bytes
+    void* wide; CK(hipMalloc(&wide, np * 128 * es));
+    ocf_tensor4 tw = mkt(wide, B, 128, H, W, cl);
+    const float b_wide = fwd(&tc, OCF_CORR_POLICY_AUTO, &tw);
+    const int var_wide = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &tw, B, C, H, W, 4, dt, OCF_CORR_POLICY_AUTO);
+    // K1+K2 in one launch (flow given) vs the warp kernel alone
+    const int var_fused = ocf_corr_fwd_variant(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, dt, OCF_CORR_POLICY_AUTO);
+    float c = time_us([&] { ocf_corr_fwd(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, 1.25f, 0, dt, OCF_CORR_POLICY_AUTO, st); }, st);
     float d = time_us([&] { ocf_warp_fwd(&t2, &tf, &tg1, B, C, H, W, 1.25f, 0, dt, st); }, st);
-    ocf_tensor4 tgo = mkt(gflow, B, 1, H, W, false);  // d/docc written into the gflow scratch buffer
-    // corr backward: vector kernel vs matrix-core kernel (max abs difference of the two g1 / g2 / d occ results, relative to the max)
+    printf("  +occ into a 128-channel buffer: variant %d %.1f us | fused warp+corr(+occ): variant %d %.1f us vs warp %.1f + corr %.1f = %.1f us\n", var_wide,
+           b_wide, var_fused, c, d, b, d + b);
+    // corr backward: vector kernel vs matrix-core kernel (max abs difference of the two g1 / g2 / d occ results, relative to the max); the
+    // gradient dense, and as the 81-channel slice of a 128-channel tensor (what autograd hands over inside the model)
+    ocf_tensor4 tgo_w = tw; tgo_w.data = wide;
+    float e = 0, eg1 = 0, eg2 = 0, e2 = 0;
     {
       ocf_tensor4 tgo1 = mkt(gflow, B, 1, H, W, false);
       const size_t ng = np * C;
       std::vector<unsigned short> r1(ng), r2(ng), m1(ng), m2(ng);
       std::vector<float> ro(np), mo(np);
-      ocf_corr_bwd_select(1);
-      float v1 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, nullptr, B, C, H, W, 4, dt, st); }, st, 50);
-      float v2 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, nullptr, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
-      float vo = time_us([&] { ocf_corr_occ_bwd(&t1, &t2, &tc, &to, &tg1, &tg2, &tgo1, B, C, H, W, 4, dt, st); }, st, 50);
+      auto bwd = [&](const ocf_tensor4* gop, const ocf_tensor4* pg1, const ocf_tensor4* pg2, int policy) {
+        return time_us([&] { ocf_corr_bwd(&t1, &t2, gop, pg1, pg2, B, C, H, W, 4, dt, policy, st); }, st, 50);
+      };
+      auto bwdo = [&](const ocf_tensor4* gop, int policy) {
+        return time_us([&] { ocf_corr_occ_bwd(&t1, &t2, &tc, gop, &tg1, &tg2, &tgo1, B, C, H, W, 4, dt, policy, st); }, st, 50);
+      };
+      const float v1 = bwd(&to, &tg1, nullptr, OCF_CORR_BWD_POLICY_VECTOR), v2 = bwd(&to, nullptr, &tg2, OCF_CORR_BWD_POLICY_VECTOR);
+      const float vo = bwdo(&to, OCF_CORR_BWD_POLICY_VECTOR);
       CK(hipStreamSynchronize(st));
       CK(hipMemcpy(r1.data(), g1, ng * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(r2.data(), g2, ng * 2, hipMemcpyDeviceToHost));
       CK(hipMemcpy(ro.data(), gflow, np * 4, hipMemcpyDeviceToHost));
-      ocf_corr_bwd_select(2);
-      float w1 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, nullptr, B, C, H, W, 4, dt, st); }, st, 50);
-      float w2t = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, nullptr, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
-      float wo = time_us([&] { ocf_corr_occ_bwd(&t1, &t2, &tc, &to, &tg1, &tg2, &tgo1, B, C, H, W, 4, dt, st); }, st, 50);
+      eg1 = bwd(&to, &tg1, nullptr, OCF_CORR_BWD_POLICY_AUTO); eg2 = bwd(&to, nullptr, &tg2, OCF_CORR_BWD_POLICY_AUTO);
+      e = bwd(&to, &tg1, &tg2, OCF_CORR_BWD_POLICY_AUTO);
+      e2 = bwdo(&to, OCF_CORR_BWD_POLICY_AUTO);
       CK(hipStreamSynchronize(st));
       CK(hipMemcpy(m1.data(), g1, ng * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(m2.data(), g2, ng * 2, hipMemcpyDeviceToHost));
       CK(hipMemcpy(mo.data(), gflow, np * 4, hipMemcpyDeviceToHost));
-      ocf_corr_bwd_select(0);
+      const float p1 = bwd(&tgo_w, &tg1, nullptr, OCF_CORR_BWD_POLICY_AUTO), p2 = bwd(&tgo_w, nullptr, &tg2, OCF_CORR_BWD_POLICY_AUTO);
+      const float po = bwdo(&tgo_w, OCF_CORR_BWD_POLICY_AUTO);
       auto bf = [](unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
       double d1 = 0, d2 = 0, dm = 0, mx1 = 0, mx2 = 0, mxo = 0;
       for (size_t i = 0; i < ng; i++) {
@@ -104,17 +121,13 @@ int main(int argc, char** argv) {
         d2 = std::max(d2, (double)fabsf(bf(r2[i]) - bf(m2[i]))); mx2 = std::max(mx2, (double)fabsf(bf(r2[i])));
       }
       for (size_t i = 0; i < np; i++) { dm = std::max(dm, (double)fabsf(ro[i] - mo[i])); mxo = std::max(mxo, (double)fabsf(ro[i])); }
-      printf("  corr_bwd: vector g1 %.1f g2 %.1f +occ(both) %.1f us | mfma g1 %.1f g2 %.1f +occ(both) %.1f us | max diff / max: g1(occ) %.2e g2(occ) %.2e docc %.2e\n",
-             v1, v2, vo, w1, w2t, wo, d1 / (mx1 + 1e-30), d2 / (mx2 + 1e-30), dm / (mxo + 1e-30));
+      printf("  corr_bwd[variant %d]: vector g1 %.1f g2 %.1f +occ(both) %.1f us | auto g1 %.1f g2 %.1f both %.1f +occ(both) %.1f us | grad_out at a 256-byte pitch: g1 %.1f g2 %.1f +occ(both) %.1f us | max diff / max: g1(occ) %.2e g2(occ) %.2e docc %.2e\n",
+             ocf_corr_bwd_variant(&t1, &t2, &to, &tg1, &tg2, B, C, H, W, 4, dt, 0), v1, v2, vo, eg1, eg2, e, e2, p1, p2, po, d1 / (mx1 + 1e-30),
+             d2 / (mx2 + 1e-30), dm / (mxo + 1e-30));
     }
-    float e = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
-    float eg1 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, &tg1, nullptr, B, C, H, W, 4, dt, st); }, st, 50);
-    float eg2 = time_us([&] { ocf_corr_bwd(&t1, &t2, &to, nullptr, &tg2, B, C, H, W, 4, dt, st); }, st, 50);
-    float e2 = time_us([&] { ocf_corr_occ_bwd(&t1, &t2, &tc, &to, &tg1, &tg2, &tgo, B, C, H, W, 4, dt, st); }, st, 50);
-    ocf_warp_bwd_select(1);
-    float f_scatter = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, st); }, st, 50);
-    ocf_warp_bwd_select(0);
-    float f = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, st); }, st, 50);
+    CK(hipFree(wide));
+    float f_scatter = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, OCF_WARP_BWD_POLICY_SCATTER, st); }, st, 50);
+    float f = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, OCF_WARP_BWD_POLICY_AUTO, st); }, st, 50);
     printf("  warp_bwd: destination-tile + far scatter %.1f us | scatter only (+ grad_img memset outside) %.1f us\n", f, f_scatter);
     double px = (double)np, bytes_plain = px * (2.0 * C * es + 81.0 * es);
     printf("%3dx%3dx%4d | corr %7.1f us %6.0f GB/s | +occ %7.1f us %6.0f | fused %7.1f us %6.0f | warp %6.1f us %6.0f | corr_bwd %7.1f us %6.0f (g1 %5.1f g2 %5.1f) | +occ %7.1f us | warp_bwd %7.1f us %6.0f\n",
@@ -149,10 +162,8 @@ int main(int argc, char** argv) {
     float b = time_us([&] { ocf_photo_loss_bwd(&t1, &t2, &tf, &to, coef, &tg, nullptr, B, C, H, W, st); }, st, 50);
     float c = time_us([&] { ocf_smooth_loss_fwd(&t1, &tf, sums, B, C, H, W, 100.f, st); }, st, 50);
     float d = time_us([&] { ocf_smooth_loss_bwd(&t1, &tf, coef, &tg, B, C, H, W, 100.f, st); }, st, 50);
-    ocf_range_map_select(1);
-    float e_old = time_us([&] { ocf_range_map(&tf, rng, oc, B, H, W, st); }, st, 50);
-    ocf_range_map_select(0);
-    float e = time_us([&] { ocf_range_map(&tf, rng, oc, B, H, W, st); }, st, 50);
+    float e_old = time_us([&] { ocf_range_map(&tf, rng, oc, B, H, W, OCF_RANGE_POLICY_SPLAT, st); }, st, 50);
+    float e = time_us([&] { ocf_range_map(&tf, rng, oc, B, H, W, OCF_RANGE_POLICY_GATHER, st); }, st, 50);
     printf("range map: gather + far %.1f us | LDS-window splat %.1f us\n", e, e_old);
     float f = time_us([&] { ocf_ssim_fwd(&t1, &t2, sums, B, C, H, W, 11, st); }, st, 20);
     float ms16 = time_us([&] { CK(hipMemsetAsync(sums, 0, 16, st)); }, st, 200);
