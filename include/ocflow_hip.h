@@ -153,12 +153,22 @@ int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tens
  *     (grad_flow, float atomics for the remaining far sources) when the tensor has >= 1M (pixel, channel) pairs, else the scatter kernel;
  * SCATTER = scatter kernel (global float atomics) always;  GATHER = gather pair whenever the layout allows -- for A/B measurements and
  * for testing both paths at any size. */
-enum ocf_warp_bwd_policy { OCF_WARP_BWD_POLICY_AUTO = 0, OCF_WARP_BWD_POLICY_SCATTER = 1, OCF_WARP_BWD_POLICY_GATHER = 2 };
+enum ocf_warp_bwd_policy {
+  OCF_WARP_BWD_POLICY_AUTO = 0,
+  OCF_WARP_BWD_POLICY_SCATTER = 1,
+  OCF_WARP_BWD_POLICY_GATHER = 2, /* window gather (near sources) + float atomics for far sources, no workspace          */
+  OCF_WARP_BWD_POLICY_BINNED = 3  /* binned gather (needs `workspace`; falls back to the window form when it is NULL)  */
+};
+/* Scratch of the BINNED gather of ocf_warp_bwd (any contents, caller-allocated, at least this many bytes): a binning pass lists, per 32 x 8
+ * destination tile, the sources whose bilinear taps land in it; the gather kernel walks that list instead of a fixed +-6 pixel window, so
+ * sources with ANY displacement are gathered with plain stores (the window form sent 25-44 % of the sources of an untrained model through
+ * float atomics).  With a workspace the automatic policy uses this form wherever it used the window form. */
+int ocf_warp_bwd_workspace_bytes(int B, int C, int H, int W, int64_t* bytes);
 int ocf_warp_bwd_plan(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C, int H,
                       int W, int dtype, int policy);
 int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
                  const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners, int dtype,
-                 int policy, void* stream);
+                 int policy, void* workspace /* may be NULL */, void* stream);
 
 /* Deterministic variant: the same contributions accumulated through 64-bit fixed-point integer atomics
  * (2^-36 resolution, |sum| < 1.3e8) in a caller-provided workspace of ocf_warp_bwd_det_workspace_bytes() bytes (zeroed by the
@@ -220,6 +230,24 @@ int ocf_range_map_det(const ocf_tensor4* flow, float* range, float* occ, void* w
  * sums[2*b+0] = sum over (C,H,W) of f[b],  sums[2*b+1] = sum of squares  (fp64, B pairs)
  * replaces: torch.var_mean(dim=(1,2,3)) in models/networks/correlation_layer.py:59-64 */
 int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int H, int W, int dtype, void* stream);
+
+/* ---- K3  normalize_features as kernels --------------------------------------
+ * `sums`: fp64 [S][B][2], the ocf_moments results of the S maps of the call (the reference normalises the two feature maps of a level
+ * together: ONE mean and ONE variance for both maps and the whole batch).  With m1 = sum / n, m2 = sumsq / n, n = C*H*W:
+ *   mu = mean_{s,b} m1[s][b],  var = mean_{s,b} (m2[s][b] - m1[s][b]^2),  inv_std = 1 / sqrt(var + 1e-16)
+ * forward (per map):  y = (x - mu) * inv_std
+ * backward: ocf_norm_bwd_sums accumulates bsums[0] += sum g, bsums[1] += sum g * (x - mu) (call it for every map; zero_first != 0 on the
+ *   first), then per map  gx = g * inv_std + dmu + 2 dvar / (S B n) * (x - m1[which][b]),  dmu = -inv_std * bsums[0] / (S B n),
+ *   dvar = -0.5 * bsums[1] * inv_std^3   -- the exact gradient through mu and var, as autograd of the reference computes it.
+ * x / y / gy / gx: dense NCHW-contiguous or channels_last tensors of `dtype` with identical strides, 16-byte aligned, C*H*W*elem % 16 == 0
+ * (anything else: OCF_EUNSUPPORTED, the caller composes it from ocf_moments and elementwise ops).
+ * replaces: normalize_features  models/networks/correlation_layer.py:59-82 (2 x var_mean, stack, mean, sub, div) and its autograd */
+int ocf_norm_fwd(const ocf_tensor4* x, const ocf_tensor4* y, const double* sums, int S, int which, int B, int C, int H, int W, int dtype,
+                 void* stream);
+int ocf_norm_bwd_sums(const ocf_tensor4* x, const ocf_tensor4* gy, const double* sums, double* bsums, int zero_first, int S, int B, int C, int H,
+                      int W, int dtype, void* stream);
+int ocf_norm_bwd(const ocf_tensor4* x, const ocf_tensor4* gy, const ocf_tensor4* gx, const double* sums, const double* bsums, int S, int which,
+                 int B, int C, int H, int W, int dtype, void* stream);
 
 /* ---- SSIM metric (first "next" row) --------------------------------------------
  * Gaussian window (sigma 1.5) of `window_size` <= 16 taps, zero padding window_size/2 (even windows give an (H+1)x(W+1) map),

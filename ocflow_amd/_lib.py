@@ -23,7 +23,7 @@ OCF_F32, OCF_BF16 = 0, 1
 CORR_AUTO, CORR_BAND_ONLY, CORR_NO_WAVE, CORR_WAVE = 0, 1, 2, 3
 CORR_VARIANT_WAVE = 4  # enum ocf_corr_variant
 CORR_BWD_AUTO, CORR_BWD_VECTOR, CORR_BWD_MFMA = 0, 1, 2
-WARP_BWD_AUTO, WARP_BWD_SCATTER, WARP_BWD_GATHER = 0, 1, 2
+WARP_BWD_AUTO, WARP_BWD_SCATTER, WARP_BWD_GATHER, WARP_BWD_BINNED = 0, 1, 2, 3
 RANGE_AUTO, RANGE_SPLAT, RANGE_GATHER = 0, 1, 2
 OCF_OK = 0
 OCF_EUNSUPPORTED = -2
@@ -48,7 +48,8 @@ SIGNATURES = {
     "ocf_corr_bwd_variant": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i],
     "ocf_corr_occ_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_warp_fwd": [_T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _vp],
-    "ocf_warp_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
+    "ocf_warp_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp],
+    "ocf_warp_bwd_workspace_bytes": [_i, _i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_warp_bwd_plan": [_T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i],
     "ocf_warp_bwd_det_workspace_bytes": [_i, _i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_warp_bwd_det": [_T4P, _T4P, _T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
@@ -62,6 +63,9 @@ SIGNATURES = {
     "ocf_smooth_loss_bwd": [_T4P, _T4P, _vp, _T4P, _i, _i, _i, _i, _f, _vp],
     "ocf_range_map": [_T4P, _vp, _vp, _i, _i, _i, _i, _vp],
     "ocf_moments": [_T4P, _vp, _i, _i, _i, _i, _i, _vp],
+    "ocf_norm_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_norm_bwd_sums": [_T4P, _T4P, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_norm_bwd": [_T4P, _T4P, _T4P, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_ssim_fwd": [_T4P, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_ssim_bwd_workspace_bytes": [_i, _i, _i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_ssim_bwd": [_T4P, _T4P, _vp, _T4P, _vp, _i, _i, _i, _i, _i, _vp],

@@ -29,6 +29,10 @@ constexpr int FP1 = 96;  // g1: bytes per staged halo pixel (64 of data).  A tra
 constexpr int FP2 = 72;  // g2: the 4 pixels of a read are 4 apart (permuted k): 72 dwords apart = bank octets 0, 8, 16, 24
 constexpr int WT = TH * N;   // taps of the window kept per halo pixel in the g2 pass (4 tap rows)
 constexpr int GP = 80;       // bytes per halo pixel of that window (72 of data; 8-byte aligned chunks)
+// g1 with the gradient delivered through LDS (GL = true): the 81 taps of the tile's own 4 x 32 pixels, 168 bytes per pixel (21 eight-byte
+// chunks, 162 of data), a front pad for the windows that start up to 15 taps before a pixel and a tail pad for those that end after it
+constexpr int GIP = 168, GI_CH = GIP / 8, GI_FRONT = 32, GI_TAIL = 48;
+constexpr int GI_BYTES = GI_FRONT + TH * TW * GIP + GI_TAIL;
 }  // namespace bm
 
 typedef short s4v_ __attribute__((ext_vector_type(4)));
@@ -45,22 +49,22 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool G2>
-__global__ __launch_bounds__(256, G2 ? 2 : 3) void corr_bwd_mfma(T4 other, T4 g, T4 dst, T4 occ, T4 w2own, T4 gocc, int B, int C, int H,
-                                                                int W, int tiles_x, int tiles_y, int ablate) {
-  using namespace bm;
-#ifndef OCF_TUNING_BUILD
-  ablate = 0;  // phase-skipping switches of the tuning build (scripts/ablate_corr_bwd.sh)
-#endif
-  constexpr int FP = G2 ? FP2 : FP1;
-  __shared__ __attribute__((aligned(16))) char s_f[HR * HWP * FP];
-  __shared__ __attribute__((aligned(16))) char s_g[G2 ? HR * HWP * GP + 64 : 16];
+// GL (g1 only): the gradient operand goes global -> LDS in coalesced 8-byte chunks (consecutive lanes = consecutive chunks of a pixel) and
+// the fragments are assembled from aligned LDS reads, instead of one unaligned 16-byte global load per lane and fragment.  Inside the
+// model the gradient is an 81-channel slice at a 256-byte pixel pitch: there the per-lane loads of the direct form run at half their
+// dense-tensor speed (52 vs 26 us at 8 x 32 x 109 x 256, tools/kbench), while the chunked staging the g2 pass has always used does not
+// care about the pitch (24 us either way).
+namespace bm {
+constexpr int SF1 = HR * HWP * FP1, SF2 = HR * HWP * FP2, SG2 = HR * HWP * GP + 64;  // LDS regions: other operand (g1 / g2 layout), g2 windows
+}
 
+// one pass (G2 = false: g1, G2 = true: g2) of one tile; s_f / s_g: this pass's LDS regions (SF1 (+ GI_BYTES with GL) / SF2 + SG2 bytes)
+template <bool G2, bool GL>
+__device__ __forceinline__ void corr_bwd_pass(char* s_f, char* s_g, T4 other, T4 g, T4 dst, T4 occ, T4 w2own, T4 gocc, int B, int C, int H, int W,
+                                              int tiles_x, int tiles_y, int ablate) {
+  using namespace bm;
+  constexpr int FP = G2 ? FP2 : FP1;
   const int tid = threadIdx.x, lane = tid & 63;
-  if (ablate & 16) {  // dispatch floor: the grid with its LDS allocation and nothing else
-    if (tid == 0) s_f[0] = 1;
-    return;
-  }
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, G = lane >> 4, q = i >> 2, p = i & 3;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -85,8 +89,35 @@ __global__ __launch_bounds__(256, G2 ? 2 : 3) void corr_bwd_mfma(T4 other, T4 g,
   // window shifted back.
   u32x4 bfr[G2 ? 1 : 2][G2 ? 1 : N], msk = {0u, 0u, 0u, 0u};
   int dlt[G2 ? 1 : 2][G2 ? 1 : N];  // edge workgroups: bytes each window was moved
-  const bool edge = !G2 && ((b == 0 && ty0 == 0 && tx0 == 0) || (b == B - 1 && ty0 + TH >= H && tx0 + TW >= W));
-  if (!G2) {
+  const bool edge = !G2 && !GL && ((b == 0 && ty0 == 0 && tx0 == 0) || (b == B - 1 && ty0 + TH >= H && tx0 + TW >= W));
+  // ---- g1, GL: the tile's own gradient pixels, 21 eight-byte chunks each (the last one holds 2 bytes of data: loaded as a halfword so
+  // that nothing past the pixel's 81 taps is ever read) -- 2688 chunks, 10.5 per thread; values are committed to LDS with the other
+  // operand's below, after every global load of the tile has been issued
+  constexpr int GIN = GL ? (TH * TW * GI_CH + 255) / 256 : 1;
+  u32x2 gi[GIN];
+  if (!G2 && GL) {
+#pragma unroll
+    for (int k = 0; k < GIN; k++) {
+      const int it = tid + 256 * k;
+      const int px = it / GI_CH, ch = it - px * GI_CH;
+      const int pr = px >> 5, pc = px & 31;  // (TW == 32)
+      const int gy = ty0 + pr, gx = tx0 + pc;
+      const bool ok = it < TH * TW * GI_CH && gy < H && gx < W;
+      const char* src = gbase + ((ok ? gy : 0) * gsh + (ok ? gx : 0) * gsw) * 2 + ch * 8;
+      u32x2 v;
+      if (ch == GI_CH - 1) { v = u32x2{(unsigned)*(const unsigned short*)src, 0u}; }
+      else { v = ((const U8B*)src)->v; }
+      const unsigned m = ok ? 0xffffffffu : 0u;
+      gi[k] = u32x2{v[0] & m, v[1] & m};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int t0 = 8 * G + 2 * r - i, t1 = t0 + 1;
+      msk[r] = ((t0 >= 0 && t0 <= 8) ? 0xffffu : 0u) | ((t1 >= 0 && t1 <= 8) ? 0xffff0000u : 0u);
+    }
+    if (y >= H || G == 3) msk = u32x4{0u, 0u, 0u, 0u};
+  }
+  if (!G2 && !GL) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int t0 = 8 * G + 2 * r - i, t1 = t0 + 1;
@@ -201,6 +232,13 @@ __global__ __launch_bounds__(256, G2 ? 2 : 3) void corr_bwd_mfma(T4 other, T4 g,
           bfr[s][dyi] = __builtin_bit_cast(u32x4, x128);
         }
     }
+    if (!G2 && GL) {
+#pragma unroll
+      for (int k = 0; k < GIN; k++) {
+        const int it = tid + 256 * k;
+        if (it < TH * TW * GI_CH) *(u32x2*)(s_g + GI_FRONT + it * 8) = gi[k];  // chunk `it` of the tile: pixel-major, 21 chunks per pixel
+      }
+    }
     if (G2) {  // (stored only now: every global load of the tile is in flight before the first wait)
 #pragma unroll
       for (int r = 0; r < HR; r++) *(u32x2*)(s_g + r * (HWP * GP) + wpA * GP + wcA * 8) = va[r];
@@ -241,7 +279,24 @@ __global__ __launch_bounds__(256, G2 ? 2 : 3) void corr_bwd_mfma(T4 other, T4 g,
         const int h0 = 16 * s + 8 * G + q, h1 = h0 + 4;
         const int p0 = h0 < HWP ? h0 : HWP - 1, p1 = h1 < HWP ? h1 : HWP - 1;
         const bool xin = tx0 + 16 * s + i < W;
-        const bf16x8 bq = __builtin_bit_cast(bf16x8, bfr[s][dyi] & (xin ? msk : u32x4{0u, 0u, 0u, 0u}));
+        u32x4 raw;
+        if (GL) {
+          // taps 8G - i + 9 dyi + 0..7 of pixel (w, 16 s + i): 16 bytes at a 2-byte aligned LDS address = three aligned 8-byte reads
+          // and a funnel shift (lanes of group 3 are outside the band: masked, any address)
+          const int addr = GI_FRONT + (w * TW + 16 * s + i) * GIP + ((G < 3 ? 8 * G - i : 0) + N * dyi) * 2;
+          const char* a8 = s_g + (addr & ~7);
+          const u32x2 d0 = *(const u32x2*)a8, d1 = *(const u32x2*)(a8 + 8), d2 = *(const u32x2*)(a8 + 16);
+          const bool up = (addr & 4) != 0;
+          const unsigned q0 = up ? d0[1] : d0[0], q1 = up ? d1[0] : d0[1], q2 = up ? d1[1] : d1[0], q3 = up ? d2[0] : d1[1],
+                         q4 = up ? d2[1] : d2[0];
+          const bool half = (addr & 2) != 0;
+          raw = half ? u32x4{__builtin_amdgcn_alignbyte(q1, q0, 2), __builtin_amdgcn_alignbyte(q2, q1, 2), __builtin_amdgcn_alignbyte(q3, q2, 2),
+                             __builtin_amdgcn_alignbyte(q4, q3, 2)}
+                     : u32x4{q0, q1, q2, q3};
+        } else {
+          raw = bfr[s][dyi];
+        }
+        const bf16x8 bq = __builtin_bit_cast(bf16x8, raw & (xin ? msk : u32x4{0u, 0u, 0u, 0u}));
 #pragma unroll
         for (int nb = 0; nb < 2; nb++) {
           const bf16x8 a = tr_pair(frow + p0 * FP + nb * 32, frow + p1 * FP + nb * 32);
@@ -327,6 +382,39 @@ __global__ __launch_bounds__(256, G2 ? 2 : 3) void corr_bwd_mfma(T4 other, T4 g,
   }
 }
 
+template <bool G2, bool GL = false>
+__global__ __launch_bounds__(256, (G2 || GL) ? 2 : 3) void corr_bwd_mfma(T4 other, T4 g, T4 dst, T4 occ, T4 w2own, T4 gocc, int B, int C, int H,
+                                                                int W, int tiles_x, int tiles_y, int ablate) {
+  using namespace bm;
+#ifndef OCF_TUNING_BUILD
+  ablate = 0;  // phase-skipping switches of the tuning build (scripts/ablate_corr_bwd.sh)
+#endif
+  __shared__ __attribute__((aligned(16))) char s_f[G2 ? SF2 : SF1];
+  __shared__ __attribute__((aligned(16))) char s_g[G2 ? SG2 : (GL ? GI_BYTES : 16)];
+  if (ablate & 16) {  // dispatch floor: the grid with its LDS allocation and nothing else
+    if (threadIdx.x == 0) s_f[0] = 1;
+    return;
+  }
+  corr_bwd_pass<G2, GL>(s_f, s_g, other, g, dst, occ, w2own, gocc, B, C, H, W, tiles_x, tiles_y, ablate);
+}
+
+// BOTH gradients of a tile in ONE launch (round 3): the g1 pass, a barrier, the g2 pass, sharing one 73 KB LDS allocation (two
+// workgroups per CU).  What it buys over the two launches: one dispatch per level instead of two (five levels per step), and the second
+// read of the tile's gradient rows -- g2 re-stages them as the halo windows of the SAME workgroup a few microseconds after g1 read them
+// -- is an L2 hit instead of a second trip to HBM (rocprofv3 round 2: 188.8 MB of traffic for 96.9 MB of algorithmic bytes at
+// 8 x 32 x 109 x 256, the gradient being fetched by both launches at its 256-byte in-model pitch).
+template <bool GL>
+__global__ __launch_bounds__(256, 2) void corr_bwd_mfma_both(T4 f1, T4 w2, T4 g, T4 g1, T4 g2, T4 occ, T4 gocc, int B, int C, int H, int W, int tiles_x,
+                                                            int tiles_y) {
+  using namespace bm;
+  constexpr int BYTES = (SF1 + (GL ? GI_BYTES : 16)) > (SF2 + SG2) ? (SF1 + (GL ? GI_BYTES : 16)) : (SF2 + SG2);
+  __shared__ __attribute__((aligned(16))) char smem[BYTES];
+  const T4 none = {nullptr, 0, 0, 0, 0};
+  corr_bwd_pass<false, GL>(smem, smem + SF1, w2, g, g1, occ, none, none, B, C, H, W, tiles_x, tiles_y, 0);
+  __syncthreads();  // every fragment read of the g1 pass is done before the g2 pass re-uses the allocation
+  corr_bwd_pass<true, false>(smem, smem + SF2, f1, g, g2, occ, w2, gocc, B, C, H, W, tiles_x, tiles_y, 0);
+}
+
 static bool px8(const ocf_tensor4* t) {  // channel-contiguous, pixels and rows 8-byte aligned, forward strides
   return t->sc == 1 && t->sw > 0 && t->sh > 0 && t->sb > 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sb % 4 == 0 && (uintptr_t)t->data % 8 == 0;
 }
@@ -354,9 +442,30 @@ int corr_bwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_t
   constexpr int ablate = 0;
 #endif
   LaunchProf lp;
-  if (g1) lp.launch(!g2, corr_bwd_mfma<false>, grid, block, 0, st, mk(w2), mk(g), mk(g1), mk(occ), mk((const ocf_tensor4*)nullptr),
-                    mk((const ocf_tensor4*)nullptr), B, C, H, W, tx, ty, ablate);
-  if (g2) lp.launch(true, corr_bwd_mfma<true>, grid, block, 0, st, mk(f1), mk(g), mk(g2), mk(occ), mk(w2), mk(gocc), B, C, H, W, tx, ty, ablate);
+  // the gradient through LDS when it arrives as a slice of a wider tensor (pixel pitch != 81 elements): see the note above the kernel
+  bool g1_lds = g->sw != NK;
+#ifdef OCF_TUNING_BUILD
+  if (const char* e = getenv("OCF_BWD_G1_LDS")) g1_lds = atoi(e) != 0;
+#endif
+  bool both = g1 && g2;
+#ifdef OCF_TUNING_BUILD
+  if (const char* e = getenv("OCF_BWD_FUSED")) both = both && atoi(e) != 0;
+#endif
+  if (both) {
+    const dim3 grid1((unsigned)(B * tx * ty), (unsigned)((C + 31) / 32));
+    if (g1_lds)
+      lp.launch(true, corr_bwd_mfma_both<true>, grid1, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
+    else
+      lp.launch(true, corr_bwd_mfma_both<false>, grid1, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
+    return launch_status();
+  }
+  if (g1 && g1_lds)
+    lp.launch(!g2, corr_bwd_mfma<false, true>, grid, block, 0, st, mk(w2), mk(g), mk(g1), mk(occ), mk((const ocf_tensor4*)nullptr),
+              mk((const ocf_tensor4*)nullptr), B, C, H, W, tx, ty, ablate);
+  else if (g1)
+    lp.launch(!g2, corr_bwd_mfma<false, false>, grid, block, 0, st, mk(w2), mk(g), mk(g1), mk(occ), mk((const ocf_tensor4*)nullptr),
+              mk((const ocf_tensor4*)nullptr), B, C, H, W, tx, ty, ablate);
+  if (g2) lp.launch(true, corr_bwd_mfma<true, false>, grid, block, 0, st, mk(f1), mk(g), mk(g2), mk(occ), mk(w2), mk(gocc), B, C, H, W, tx, ty, ablate);
   return launch_status();
 }
 

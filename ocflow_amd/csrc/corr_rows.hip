@@ -38,8 +38,12 @@ constexpr int OCC_W = ROWPX;            // occlusion halo pitch (floats); the th
 constexpr int TRASH_BYTES = 320;        // where the band stores of lanes without a valid tap go (2 bytes per lane + the dy immediate <= 144)
 constexpr int LDS_GRANULE = 1280, LDS_PER_CU = 160 * 1024;  // measured: three 53,888-byte workgroups do NOT share a CU, three of 52,992 do
 
-template <int KB, int TH, int WPR> struct G {
-  static constexpr int HH = TH + 2 * D;
+// P "passes": one staged halo tile serves P consecutive groups of TH rows (the band image and the waves are those of a TH-row tile).  At
+// the C = 64 level (KB = 2) a 2-row tile stages 10 halo rows for 2 rows of output -- 51 KB through LDS per 64 pixels, and rocprof showed
+// that launch skeleton-bound; two passes over a 12-row halo stage 61 KB per 128 pixels, still fit two workgroups per CU (74 KB), and the
+// level's 448 tiles are resident at once instead of being walked two per workgroup.
+template <int KB, int TH, int WPR, int P = 1> struct G {
+  static constexpr int HH = TH * P + 2 * D;
   static constexpr int PLANE = HH * ROWPX * NUM + (KB > 1 ? 4 : 0);  // 16-byte slots per 32-channel block; with two blocks an odd
                                                                      // multiple of 64 bytes: a pixel's blocks land on different bank halves
   static constexpr int NW = TH * WPR, NT = 64 * NW;
@@ -59,14 +63,14 @@ __device__ __forceinline__ int slot(int row, int x, int u) { return (row * ROWPX
 // load whose only use sits behind a condition -- hipcc sinks such a load into a branch and then waits for EVERY outstanding load)
 __device__ u32x4 g_zero16[2];  // zero-initialised; deliberately NOT const (a constant-address-space pointer would turn the selected loads into flat_load)
 
-template <int KB, int TH, int WPR, int MODE>
+template <int KB, int TH, int WPR, int MODE, int P = 1>
 __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(T4 f1, T4 f2, T4 occ, T4 out, int B, int C, int H, int W, int tiles_x,
                                                                    int tiles_y, int ablate) {
 #ifndef OCF_TUNING_BUILD
   ablate = 0;  // phase-skipping switches (wrong results) exist only in the tuning build tools/kbench makes for itself
 #endif
   using namespace rw;
-  using GG = G<KB, TH, WPR>;
+  using GG = G<KB, TH, WPR, P>;
   typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
   extern __shared__ u32x4 smem[];
   u32x4* s_f2 = smem;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
   const int xcd = blockIdx.x & 7, slots = gridDim.x >> 3;
   int ti = blockIdx.x >> 3;
 
-  u32x4 st[GG::ROWS_PER_WAVE][GG::SWEEPS], an[KB][2];
+  u32x4 st[GG::ROWS_PER_WAVE][GG::SWEEPS], an[P][KB][2];
   unsigned ocr[OCC_PER];
   // ---- issue every global load of tile (b, ty0, tx0): f2 halo rows (one wave per row, lanes sweep the 16-byte units in memory
   // order), this wave's f1 fragments (lane (i = l&15, kg = l>>4): channels 8kg..8kg+7 of pixel i of a strip), the occlusion halo
@@ -112,15 +116,18 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
         st[rr][k] = *(const u32x4*)(ok ? f2b + (long)(gy * f2sh + gx * f2sw + c0) * 2 : zp);
       }
     }
-    const int gy1 = ty0 + ry;
 #pragma unroll
-    for (int kb = 0; kb < KB; kb++)
+    for (int ps = 0; ps < P; ps++) {
+      const int gy1 = ty0 + TH * ps + ry;
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
-        const int gx = tx0 + 16 * s + j, c0 = kb * 32 + g * 8;
-        const bool ok = gy1 < H && gx < W && c0 < C && !(ablate & 8);
-        an[kb][s] = *(const u32x4*)(ok ? f1b + (long)(gy1 * f1sh + gx * f1sw + c0) * 2 : zp);
-      }
+      for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          const int gx = tx0 + 16 * s + j, c0 = kb * 32 + g * 8;
+          const bool ok = gy1 < H && gx < W && c0 < C && !(ablate & 8);
+          an[ps][kb][s] = *(const u32x4*)(ok ? f1b + (long)(gy1 * f1sh + gx * f1sw + c0) * 2 : zp);
+        }
+    }
     if (MODE) {
       const char* ocb = occ.p + (long)b * occ.sb * 4;
 #pragma unroll
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
     b = tile / tpi;
     const int trem = tile - b * tpi;
     const int tyi = trem / tiles_x;
-    ty0 = tyi * TH; tx0 = (trem - tyi * tiles_x) * TW;
+    ty0 = tyi * (TH * P); tx0 = (trem - tyi * tiles_x) * TW;
   };
   bool have = ti < per_xcd && xcd * per_xcd + ti < ntiles;
   int b = 0, ty0 = 0, tx0 = 0;
@@ -194,11 +201,13 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
         if (e < GG::HH * OCC_W) ((unsigned*)s_occ)[e] = ocr[k];
       }
     }
-    bf16x8v a[KB][2];
+    bf16x8v a[P][KB][2];
 #pragma unroll
-    for (int kb = 0; kb < KB; kb++)
+    for (int ps = 0; ps < P; ps++)
 #pragma unroll
-      for (int s = 0; s < 2; s++) a[kb][s] = __builtin_bit_cast(bf16x8v, an[kb][s]);
+      for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) a[ps][kb][s] = __builtin_bit_cast(bf16x8v, an[ps][kb][s]);
     const int cb = b, cty0 = ty0, ctx0 = tx0;
     __syncthreads();
     // ---- next tile of this workgroup: its loads fly under everything below
@@ -210,8 +219,11 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- band GEMM + band write of this wave's row and dy share
-    const int gy1 = cty0 + ry;
+#pragma unroll
+    for (int ps = 0; ps < P; ps++) {
+    // ---- band GEMM + band write of this wave's row and dy share (pass ps: rows TH * ps .. TH * ps + TH - 1 of the staged tile)
+    constexpr int RO = ROWPX * NUM;  // slots per halo row
+    const int gy1 = cty0 + TH * ps + ry;
     const bool row_live = gy1 < H;
     if (row_live) {
 #pragma unroll
@@ -223,20 +235,19 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
           for (int t = 0; t < 4; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kb = 0; kb < KB; kb++) {
-            constexpr int RO = ROWPX * NUM;  // slots per halo row
-            const bf16x8v b0 = __builtin_bit_cast(bf16x8v, fb[0][kb * GG::PLANE + i * RO]);
-            const bf16x8v b1 = __builtin_bit_cast(bf16x8v, fb[1][kb * GG::PLANE + i * RO]);
-            const bf16x8v b2 = __builtin_bit_cast(bf16x8v, fb[2][kb * GG::PLANE + i * RO]);
+            const bf16x8v b0 = __builtin_bit_cast(bf16x8v, fb[0][kb * GG::PLANE + (i + TH * ps) * RO]);
+            const bf16x8v b1 = __builtin_bit_cast(bf16x8v, fb[1][kb * GG::PLANE + (i + TH * ps) * RO]);
+            const bf16x8v b2 = __builtin_bit_cast(bf16x8v, fb[2][kb * GG::PLANE + (i + TH * ps) * RO]);
             if (ablate & 1) { acc[0][0] += (float)b0[0]; acc[1][0] += (float)b1[0]; acc[3][0] += (float)b2[0]; continue; }
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][0], b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][0], b1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][1], b1, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][1], b2, acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ps][kb][0], b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ps][kb][0], b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ps][kb][1], b1, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ps][kb][1], b2, acc[3], 0, 0, 0);
           }
           float o[3] = {1.f, 1.f, 1.f};
           if (MODE) {
 #pragma unroll
-            for (int t = 0; t < 3; t++) o[t] = ob[t][i * OCC_W];
+            for (int t = 0; t < 3; t++) o[t] = ob[t][(i + TH * ps) * OCC_W];
           }
 #pragma unroll
           for (int s = 0; s < 2; s++) {
@@ -281,6 +292,8 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
           for (int e = nvec * 8 + lane; e < row_elems; e += 64) ((unsigned short*)gp)[e] = s_out[ry * ROW_ELEMS + e];
       }
     }
+    if (P > 1 && WPR > 1 && ps + 1 < P) __syncthreads();  // the row image is rewritten by the next pass: every wave has copied its share out
+    }  // passes
     ti = nti; have = nhave;
     if (have) __syncthreads();  // every fragment / occlusion read of this tile is done before the next commit rewrites the LDS images
   }
@@ -446,10 +459,10 @@ static int rows_num_cus() {
   return n;
 }
 
-template <int KB, int TH, int WPR, int MODE>
+template <int KB, int TH, int WPR, int MODE, int P = 1>
 static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out, int B, int C, int H, int W, hipStream_t st) {
-  using GG = rw::G<KB, TH, WPR>;
-  const int tx = (W + rw::TW - 1) / rw::TW, ty = (H + TH - 1) / TH;
+  using GG = rw::G<KB, TH, WPR, P>;
+  const int tx = (W + rw::TW - 1) / rw::TW, ty = (H + TH * P - 1) / (TH * P);
   const long ntiles = (long)B * tx * ty;
   if (ntiles > 0x7fffffffL) return OCF_EUNSUPPORTED;
   size_t lds = GG::lds_bytes(MODE);
@@ -459,8 +472,8 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
   static int wg_per_cu = 0;
   if (wg_per_cu == 0) {
     int nb = 0;
-    (void)hipFuncSetAttribute((const void*)corr_fwd_rows<KB, TH, WPR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_rows<KB, TH, WPR, MODE>, GG::NT, lds);
+    (void)hipFuncSetAttribute((const void*)corr_fwd_rows<KB, TH, WPR, MODE, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_rows<KB, TH, WPR, MODE, P>, GG::NT, lds);
     wg_per_cu = (e == hipSuccess && nb >= 1) ? (nb > (KB == 1 ? 3 : 2) ? (KB == 1 ? 3 : 2) : nb) : 1;
     // the occupancy API is advisory: LDS is handed out in 1280-byte granules (a persistent grid sized for a workgroup that is not
     // resident would run that workgroup's tiles after everyone else has finished)
@@ -476,7 +489,7 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
   if (ps.start && ps.stop) {  // one-shot: the events receive this dispatch's own begin / end timestamps
     hipEvent_t e0 = ps.start, e1 = ps.stop;
     ps.start = nullptr; ps.stop = nullptr;
-    hipExtLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE>), grid, block, lds, st, e0, e1, 0, f1, f2, occ, out, B, C, H, W, tx, ty, 0);
+    hipExtLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE, P>), grid, block, lds, st, e0, e1, 0, f1, f2, occ, out, B, C, H, W, tx, ty, 0);
   } else {
     int ablate = 0;
 #ifdef OCF_TUNING_BUILD
@@ -485,12 +498,12 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
     static bool told = false;
     if (!told) {
       int nb = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_rows<KB, TH, WPR, MODE>, GG::NT, lds);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_rows<KB, TH, WPR, MODE, P>, GG::NT, lds);
       fprintf(stderr, "[tuning] corr_fwd_rows<%d,%d,%d,%d>: %zu B LDS, %d workgroups per CU, ablate %d\n", KB, TH, WPR, MODE, lds, nb, ab);
       told = true;
     }
 #endif
-    hipLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE>), grid, block, lds, st, f1, f2, occ, out, B, C, H, W, tx, ty, ablate);
+    hipLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE, P>), grid, block, lds, st, f1, f2, occ, out, B, C, H, W, tx, ty, ablate);
   }
   return launch_status();
 }
@@ -522,7 +535,12 @@ int corr_fwd_bf16_rows(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_t
     return occ ? launch_direct_kb<8, 1>(a, bq, oc, o, B, C, H, W, st) : launch_direct_kb<8, 0>(a, bq, oc, o, B, C, H, W, st);
   }
   if (C <= 32) return occ ? launch_rows<1, 4, 1, 1>(a, bq, oc, o, B, C, H, W, st) : launch_rows<1, 4, 1, 0>(a, bq, oc, o, B, C, H, W, st);
-  return occ ? launch_rows<2, 2, 2, 1>(a, bq, oc, o, B, C, H, W, st) : launch_rows<2, 2, 2, 0>(a, bq, oc, o, B, C, H, W, st);
+#ifdef OCF_TUNING_BUILD
+  static const int p1 = getenv("OCF_ROWS_K2_PASSES") ? atoi(getenv("OCF_ROWS_K2_PASSES")) : 2;
+  if (p1 == 1) return occ ? launch_rows<2, 2, 2, 1>(a, bq, oc, o, B, C, H, W, st) : launch_rows<2, 2, 2, 0>(a, bq, oc, o, B, C, H, W, st);
+#endif
+  // two passes of two rows over one 12-row halo tile (see struct G)
+  return occ ? launch_rows<2, 2, 2, 1, 2>(a, bq, oc, o, B, C, H, W, st) : launch_rows<2, 2, 2, 0, 2>(a, bq, oc, o, B, C, H, W, st);
 }
 
 }  // namespace ocf

@@ -240,12 +240,14 @@ static int launch_wave_kb(const T4& f1, const T4& f2, const T4& flow, const T4& 
   }
 }
 
-// two strips per wave once that still leaves more waves than the chip has SIMDs several times over; one strip below that
+// strips per wave: two wherever the map is wider than one strip (measured at B = 8, tools/kbench: 28 x 64: 6.4 vs 7.0 us, 14 x 32: 4.7 vs 5.1 us
+// -- half the f1 fragment loads per output pixel and 3 instead of 4 column tiles of f2 per 32 pixels outweigh the smaller wave count)
 static int wave_strips(int B, int H, int W) {
 #ifdef OCF_TUNING_BUILD
-  if (const char* e = getenv("OCF_WAVE_STRIPS")) return atoi(e) == 2 ? 2 : 1;
+  if (const char* e = getenv("OCF_WAVE_STRIPS"))
+    if (atoi(e) > 0) return atoi(e) == 2 && W > 16 ? 2 : 1;
 #endif
-  return (W > 16 && (long)B * H * ((W + 31) / 32) * wv::N >= 3072) ? 2 : 1;
+  return W > 16 ? 2 : 1;
 }
 
 // operands the wave kernel takes: bf16 (checked by the caller), d = 4, channel-contiguous features with 8-byte (16-byte when a flow is

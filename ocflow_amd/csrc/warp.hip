@@ -342,10 +342,164 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(T4 flow, T4 gout, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// BINNED variant of kernel A (round 3): the window form above only serves sources whose taps land within NEAR_R = 6 pixels of themselves;
+// what the model feeds it is not that tame -- with random-init weights 25 % of the level-2 and 44 % of the level-3 sources move further
+// (scripts/flow_stats.py) and went through the float-atomic far path, which made the launch 2.5x slower inside the model (99.6 us at
+// 8 x 32 x 109 x 256) than in the small-motion micro-benchmark (39 us).  Here the sources of a destination tile are not FOUND by scanning
+// a window, they are LISTED: a binning pass (one thread per source pixel, 8 bytes of flow each) appends the source's index to the bin
+// of every destination tile one of its taps lands in (1-4 tiles; one integer atomic per (source, tile) pair), and the gather kernel
+// walks its tile's bin instead of a window -- any displacement is "near".  A bin holds WBIN_CAP entries (3.5x the average of a 32 x 8
+// tile); pairs beyond that go to an overflow list that the per-source kernel afterwards scatters with float atomics (taps of that
+// tile only), so convergent flows stay correct.
+// workspace: [tiles + 1 counters (the last one = overflow count) | bins: tiles x WBIN_CAP u32 | overflow: 4 * B*H*W x (source, tile) u32 pairs]
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int WBIN_CAP = 896;
+
+// One returning device-scope atomic per (wave, destination tile) instead of one per (source, tile): the lanes of a wave are a 32 x 2
+// patch of sources, whose taps land in a handful of tiles; the lanes that target the same tile are counted with a ballot, the first of
+// them reserves that many bin slots, the others take consecutive slots after its base.  (One atomic per source measured 4x SLOWER than
+// the window kernel: 270,000 returning atomics on 896 counters are ~50-140 us of memory-side atomic traffic at the level-2 shape.)
+__device__ __forceinline__ void warp_bin_push_wave(bool active, int tile, unsigned src, unsigned* cnt, unsigned* bins, unsigned* ovf, int ntiles) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+  while (todo) {  // (wave-uniform loop: every lane of the wave runs it)
+    const int leader = __builtin_ctzll(todo);
+    const int t = __builtin_amdgcn_readlane(tile, leader);
+    const bool mine = active && tile == t;
+    const unsigned long long same = __ballot(mine);
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&cnt[t], (unsigned)__popcll(same));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+    if (mine) {
+      const unsigned slot = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+      if (slot < (unsigned)WBIN_CAP) {
+        bins[(long)t * WBIN_CAP + slot] = src;
+      } else {
+        const unsigned o = atomicAdd(&cnt[ntiles], 1u);
+        ovf[2 * (long)o] = src;
+        ovf[2 * (long)o + 1] = (unsigned)t;
+      }
+    }
+    todo &= ~same;
+  }
+}
+
+// grid = source tiles (32 x 8 pixels, the destination tile shape), lanes = pixels: a wave = two rows of 32 sources
+__global__ __launch_bounds__(256) void warp_bwd_bin_kernel(T4 flow, int B, int H, int W, float fs, WarpGeom wg, int tiles_x, int tiles_y,
+                                                           unsigned* cnt, unsigned* bins, unsigned* ovf, long npix) {
+  const int tpi = tiles_x * tiles_y;
+  const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
+  const int x = (trem % tiles_x) * WT_W + (threadIdx.x & (WT_W - 1)), y = (trem / tiles_x) * WT_H + (threadIdx.x >> 5);
+  const bool live = x < W && y < H;
+  const int xc = live ? x : 0, yc = live ? y : 0;
+  const float* fl = (const float*)flow.p + (long)b * flow.sb + (long)yc * flow.sh + (long)xc * flow.sw;
+  const Bilin s = bilin_setup(((float)xc + fl[0] * fs) * wg.ax + wg.bx, ((float)yc + fl[flow.sc] * fs) * wg.ay + wg.by, H, W);
+  // destination tiles of the (in-image) taps: columns x0, x0 + 1 and rows y0, y0 + 1 each fall into one or two tiles
+  const int ntiles = B * tpi;
+  const int txa = s.vx0 ? s.x0 / WT_W : -1, txb = s.vx1 ? (s.x0 + 1) / WT_W : -1;
+  const int tya = s.vy0 ? s.y0 / WT_H : -1, tyb = s.vy1 ? (s.y0 + 1) / WT_H : -1;
+  const unsigned src = (unsigned)(yc * W + xc);
+  const int tb = b * tpi;
+  const bool xb = txb >= 0 && txb != txa, yb = tyb >= 0 && tyb != tya;
+  warp_bin_push_wave(live && txa >= 0 && tya >= 0, tb + tya * tiles_x + txa, src, cnt, bins, ovf, ntiles);
+  warp_bin_push_wave(live && xb && tya >= 0, tb + tya * tiles_x + txb, src, cnt, bins, ovf, ntiles);
+  warp_bin_push_wave(live && yb && txa >= 0, tb + tyb * tiles_x + txa, src, cnt, bins, ovf, ntiles);
+  warp_bin_push_wave(live && yb && xb, tb + tyb * tiles_x + txb, src, cnt, bins, ovf, ntiles);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void warp_bwd_gather_binned_kernel(T4 flow, T4 gout, T4 gimg, int B, int C, int H, int W, float fs,
+                                                                     WarpGeom wg, int tiles_x, int tiles_y, const unsigned* cnt,
+                                                                     const unsigned* bins) {
+  constexpr int ES = (int)sizeof(T), U = Unit<T>::U, NU = 32 / U;
+  __shared__ float s_w[4 * WBIN_CAP];      // list entry (bin entry e, tap k) lives in slot 4 e + k: weight
+  __shared__ unsigned s_nx[4 * WBIN_CAP];  //                                                         next entry of the same pixel
+  __shared__ unsigned s_src[WBIN_CAP];     // source pixel (y * W + x) of bin entry e
+  __shared__ unsigned s_head[WT_W * WT_H];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x, c0 = blockIdx.y * 32;
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi, trem = tile - b * tpi;
+  const int ty0 = (trem / tiles_x) * WT_H, tx0 = (trem % tiles_x) * WT_W;
+  const float* fl = (const float*)flow.p + (long)b * flow.sb;
+  s_head[tid] = WL_END;
+  const int n = min((int)cnt[tile], WBIN_CAP);
+  __syncthreads();
+  // ---- phase 1, lanes = bin entries: push every tap of the source that lands in THIS tile onto its destination pixel's list
+  for (int e = tid; e < n; e += 256) {
+    const unsigned src = bins[(long)tile * WBIN_CAP + e];
+    const int sy = (int)(src / (unsigned)W), sx = (int)(src - (unsigned)sy * (unsigned)W);
+    s_src[e] = ((unsigned)sy << 16) | (unsigned)sx;  // (H, W < 65536: host-checked) -- phase 2 decodes it without a division
+    const long fo = (long)sy * flow.sh + (long)sx * flow.sw;
+    const Bilin s = bilin_setup(((float)sx + fl[fo] * fs) * wg.ax + wg.bx, ((float)sy + fl[fo + flow.sc] * fs) * wg.ay + wg.by, H, W);
+    unsigned prev[4];
+    bool push[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int ddx = k & 1, ddy = k >> 1;
+      const int lx = s.x0 + ddx - tx0, ly = s.y0 + ddy - ty0;
+      push[k] = ((ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0)) && lx >= 0 && lx < WT_W && ly >= 0 && ly < WT_H;
+      prev[k] = WL_END;
+      if (push[k]) prev[k] = atomicExch(&s_head[ly * WT_W + lx], (unsigned)(4 * e + k));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (push[k]) {
+        s_w[4 * e + k] = ((k & 1) ? s.wx1 : 1.f - s.wx1) * ((k >> 1) ? s.wy1 : 1.f - s.wy1);
+        s_nx[4 * e + k] = prev[k];
+      }
+  }
+  __syncthreads();
+  // ---- phase 2: one thread per destination pixel walks its list two entries at a time (as in the window kernel)
+  const char* gb = gout.p + (long)b * gout.sb * ES;
+  float acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = 0.f;
+  auto src_row = [&](unsigned ent) __attribute__((always_inline)) {
+    const unsigned src = s_src[ent >> 2];
+    const int sy = (int)(src >> 16), sx = (int)(src & 0xffffu);
+    return gb + ((long)sy * gout.sh + (long)sx * gout.sw + c0) * ES;
+  };
+  T4 gv = gout;
+  for (unsigned cur = s_head[tid]; cur != WL_END;) {
+    const unsigned n0 = s_nx[cur];
+    const bool two = n0 != WL_END;
+    const unsigned e1 = two ? n0 : cur;
+    const float w0 = s_w[cur], w1 = two ? s_w[e1] : 0.f;
+    const char* r0 = src_row(cur);
+    const char* r1 = src_row(e1);
+    float f0[NU][U], f1[NU][U];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      gv.p = (char*)r0; load_unit_f<T, VEC>(gv, 0, u * U, C - c0, f0[u]);
+      gv.p = (char*)r1; load_unit_f<T, VEC>(gv, 0, u * U, C - c0, f1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++)
+#pragma unroll
+      for (int k = 0; k < U; k++) acc[u * U + k] = __builtin_fmaf(w1, f1[u][k], __builtin_fmaf(w0, f0[u][k], acc[u * U + k]));
+    cur = two ? s_nx[e1] : WL_END;
+  }
+  const int y = ty0 + tid / WT_W, x = tx0 + (tid % WT_W);
+  if (y < H && x < W) {
+    float* gi = (float*)gimg.p + (long)b * gimg.sb + (long)y * gimg.sh + (long)x * gimg.sw + c0;
+    if (c0 + 32 <= C && ((gimg.sw | gimg.sh | gimg.sb) & 3) == 0) {
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) *(f32x4*)(gi + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; k++)
+        if (c0 + k < C) gi[k] = acc[k];
+    }
+  }
+}
+
 // kernel B: lanes = (source pixel, 16-byte channel unit).  UPP = units per pixel (a power of two <= 64 so that a pixel's lanes share a wave)
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(T4 img, T4 flow, T4 gout, T4 gimg, T4 gflow, int B, int C, int H, int W, float fs,
-                                                            WarpGeom wg, long total, int upp, int upp_pad) {
+                                                            WarpGeom wg, long total, int upp, int upp_pad, const unsigned* ovf_cnt,
+                                                            const unsigned* ovf, int tiles_x, int tiles_y) {
   constexpr int U = Unit<T>::U;
   const float* fl = (const float*)flow.p;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -386,7 +540,41 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(T4 img, T4 flow, T4 
   // 237 us inside the benchmark model at 8x32x109x256, where 25 % of the sources are far -- 2.3x the plain scatter kernel.  Instead
   // the wave walks its far pixels one at a time (ballot; the pixel's sample geometry broadcast through SGPRs) with lanes = (2 taps x
   // 32 channels): every atomic instruction is two full 128-byte rows.
-  if (gimg.p) {
+  if (gimg.p && ovf_cnt) {
+    // BINNED mode: nothing is "far"; what is scattered here are the (source, tile) pairs that did not fit their tile's bin -- normally
+    // none.  Wave w of the grid takes overflow entries w, w + #waves, ...; lanes = (2 taps in x) x 32 channels, taps outside that
+    // tile are skipped (they were binned, or overflowed, with their own tile).
+    const unsigned novf = *ovf_cnt;
+    if (novf) {
+      const int lane = threadIdx.x & 63, ch = lane & 31, ddx = lane >> 5;
+      const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+      const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+      for (long e = wave0; e < (long)novf; e += nwaves) {
+        const unsigned src = ovf[2 * e], tl = ovf[2 * e + 1];
+        const int tpi = tiles_x * tiles_y;
+        const int ob = (int)(tl / (unsigned)tpi), trem = (int)(tl - (unsigned)ob * (unsigned)tpi);
+        const int oty0 = (trem / tiles_x) * WT_H, otx0 = (trem % tiles_x) * WT_W;
+        const int sy = (int)(src / (unsigned)W), sx = (int)(src - (unsigned)sy * (unsigned)W);
+        const long ofo = (long)ob * flow.sb + (long)sy * flow.sh + (long)sx * flow.sw;
+        const Bilin os = bilin_setup(((float)sx + fl[ofo] * fs) * wg.ax + wg.bx, ((float)sy + fl[ofo + flow.sc] * fs) * wg.ay + wg.by, H, W);
+        const int tx = os.x0 + ddx;
+        const bool vx = (ddx ? os.vx1 : os.vx0) && tx >= otx0 && tx < otx0 + WT_W;
+        const float wxx = ddx ? os.wx1 : 1.f - os.wx1;
+        const long go = (long)ob * gout.sb + (long)sy * gout.sh + (long)sx * gout.sw;
+        float* gi = (float*)gimg.p + (long)ob * gimg.sb + (long)tx * gimg.sw;
+        for (int cb = 0; cb < C; cb += 32) {
+          const int c = cb + ch;
+          const float gv = c < C ? ldf<T>(gout.p, go + c) : 0.f;
+#pragma unroll
+          for (int ddy = 0; ddy < 2; ddy++) {
+            const int tyy = os.y0 + ddy;
+            const bool ok = vx && (ddy ? os.vy1 : os.vy0) && tyy >= oty0 && tyy < oty0 + WT_H && c < C;
+            if (ok) atomicAdd(gi + (long)tyy * gimg.sh + c, wxx * (ddy ? os.wy1 : 1.f - os.wy1) * gv);
+          }
+        }
+      }
+    }
+  } else if (gimg.p) {
     const bool far = live && un == 0 && !warp_is_near(s, x, y);
     unsigned long long todo = __ballot(far);
     const int lane = threadIdx.x & 63;
@@ -474,7 +662,7 @@ static bool warp_bwd_use_gather(const ocf_tensor4* img, const ocf_tensor4* gout,
   const bool cl = img->sc == 1 && gout->sc == 1 && gimg && gimg->sc == 1 && C >= 4;
   const bool gf_dense = !gflow || (gflow->sw == 1 && gflow->sh == W && gflow->sc == (long)H * W && gflow->sb == 2L * H * W);
   if (!cl || !gf_dense || npix * C >= (1L << 40) || policy == OCF_WARP_BWD_POLICY_SCATTER ||
-      (policy == OCF_WARP_BWD_POLICY_AUTO && npix * C < (1L << 20)))
+      (policy == OCF_WARP_BWD_POLICY_AUTO && npix * C < (1L << 20)) || (long)H * W >= (1L << 31))
     return false;
   const int vec = min_vec(vec_width<T>(img), vec_width<T>(gout));
   const int upp = (C + Unit<T>::U - 1) / Unit<T>::U;
@@ -486,9 +674,12 @@ static bool warp_bwd_use_gather(const ocf_tensor4* img, const ocf_tensor4* gout,
   return tiles <= 0x7fffffffL && (npix * upp_pad + 255) / 256 <= 0x7fffffffL;
 }
 
+// workspace of the binned path: counters padded to a multiple of 64 entries (bins stay 256-byte aligned)
+static inline long warp_ws_counters(long tiles) { return ((tiles + 1 + 63) / 64) * 64; }
+
 template <typename T>
 static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
-                      const ocf_tensor4* gflow, int B, int C, int H, int W, float fs, int ac, int policy, hipStream_t st) {
+                      const ocf_tensor4* gflow, void* workspace, int B, int C, int H, int W, float fs, int ac, int policy, hipStream_t st) {
   const long npix = (long)B * H * W;
   const WarpGeom wg(H, W, ac);
   // channels_last fast path: unit channel stride everywhere and a dense fp32 grad_flow the launcher can zero
@@ -509,6 +700,30 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
       int upp_pad = 1;
       while (upp_pad < upp) upp_pad *= 2;
       const long totalb = npix * upp_pad;
+      const dim3 gb((unsigned)((totalb + 255) / 256));
+      const bool binned = workspace && policy != OCF_WARP_BWD_POLICY_GATHER && H < 65536 && W < 65536;
+      if (binned) {
+        // counters (zeroed here) | bins | overflow pairs: see the note above warp_bwd_bin_kernel
+        unsigned* cnt = (unsigned*)workspace;
+        unsigned* bins = cnt + warp_ws_counters(tiles);
+        unsigned* ovf = bins + tiles * WBIN_CAP;
+        if (hipMemsetAsync(cnt, 0, (size_t)warp_ws_counters(tiles) * 4, st) != hipSuccess) return OCF_ELAUNCH;
+        LaunchProf lp;
+        lp.launch(false, warp_bwd_bin_kernel, dim3((unsigned)tiles), dim3(256), 0, st, mk(flow), B, H, W, fs, wg, tx, ty, cnt, bins, ovf, npix);
+        if (vec == 16)
+          lp.launch(false, warp_bwd_gather_binned_kernel<T, 16>, dim3((unsigned)tiles, (unsigned)((C + 31) / 32)), dim3(256), 0, st, mk(flow),
+                    mk(gout), mk(gimg), B, C, H, W, fs, wg, tx, ty, (const unsigned*)cnt, (const unsigned*)bins);
+        else
+          lp.launch(false, warp_bwd_gather_binned_kernel<T, 8>, dim3((unsigned)tiles, (unsigned)((C + 31) / 32)), dim3(256), 0, st, mk(flow),
+                    mk(gout), mk(gimg), B, C, H, W, fs, wg, tx, ty, (const unsigned*)cnt, (const unsigned*)bins);
+        if (vec == 16)
+          lp.launch(true, warp_bwd_flow_kernel<T, 16>, gb, dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, fs, wg,
+                    totalb, upp, upp_pad, (const unsigned*)(cnt + tiles), (const unsigned*)ovf, tx, ty);
+        else
+          lp.launch(true, warp_bwd_flow_kernel<T, 8>, gb, dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, fs, wg,
+                    totalb, upp, upp_pad, (const unsigned*)(cnt + tiles), (const unsigned*)ovf, tx, ty);
+        return launch_status();
+      }
       {
         LaunchProf lp;
         if (vec == 16)
@@ -517,13 +732,12 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
         else
           lp.launch(false, warp_bwd_gather_kernel<T, 8>, dim3((unsigned)tiles, (unsigned)((C + 31) / 32)), dim3(256), 0, st, mk(flow), mk(gout),
                     mk(gimg), B, C, H, W, fs, wg, tx, ty);
-        const dim3 gb((unsigned)((totalb + 255) / 256));
         if (vec == 16)
           lp.launch(true, warp_bwd_flow_kernel<T, 16>, gb, dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, fs, wg,
-                    totalb, upp, upp_pad);
+                    totalb, upp, upp_pad, (const unsigned*)nullptr, (const unsigned*)nullptr, tx, ty);
         else
           lp.launch(true, warp_bwd_flow_kernel<T, 8>, gb, dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, fs, wg,
-                    totalb, upp, upp_pad);
+                    totalb, upp, upp_pad, (const unsigned*)nullptr, (const unsigned*)nullptr, tx, ty);
         return launch_status();
       }
     }
@@ -555,11 +769,18 @@ extern "C" int ocf_warp_fwd(const ocf_tensor4* img, const ocf_tensor4* flow, con
   return OCF_EINVAL;
 }
 
+extern "C" int ocf_warp_bwd_workspace_bytes(int B, int C, int H, int W, int64_t* bytes) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !bytes) return OCF_EINVAL;
+  const long tiles = (long)B * ((W + ocf::WT_W - 1) / ocf::WT_W) * ((H + ocf::WT_H - 1) / ocf::WT_H);
+  *bytes = (ocf::warp_ws_counters(tiles) + tiles * ocf::WBIN_CAP + 8L * B * H * W) * 4;
+  return OCF_OK;
+}
+
 extern "C" int ocf_warp_bwd_plan(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C,
                                  int H, int W, int dtype, int policy) {
   if (!img || !gout || !img->data || !gout->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
-  if (policy < OCF_WARP_BWD_POLICY_AUTO || policy > OCF_WARP_BWD_POLICY_GATHER) return OCF_EINVAL;
+  if (policy < OCF_WARP_BWD_POLICY_AUTO || policy > OCF_WARP_BWD_POLICY_BINNED) return OCF_EINVAL;
   bool gather = false;
   if (dtype == OCF_F32) gather = ocf::warp_bwd_use_gather<float>(img, gout, gimg, gflow, B, C, H, W, policy);
   else if (dtype == OCF_BF16) gather = ocf::warp_bwd_use_gather<ocf::bf16>(img, gout, gimg, gflow, B, C, H, W, policy);
@@ -569,15 +790,15 @@ extern "C" int ocf_warp_bwd_plan(const ocf_tensor4* img, const ocf_tensor4* gout
 
 extern "C" int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
                             const ocf_tensor4* gflow, int B, int C, int H, int W, float flow_scale, int align_corners,
-                            int dtype, int policy, void* stream) {
+                            int dtype, int policy, void* workspace, void* stream) {
   ocf::clear_stale_error();
   if (!img || !flow || !gout || !img->data || !flow->data || !gout->data) return OCF_EINVAL;
   if ((gimg && !gimg->data) || (gflow && !gflow->data) || (!gimg && !gflow)) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
-  if (policy < OCF_WARP_BWD_POLICY_AUTO || policy > OCF_WARP_BWD_POLICY_GATHER) return OCF_EINVAL;
+  if (policy < OCF_WARP_BWD_POLICY_AUTO || policy > OCF_WARP_BWD_POLICY_BINNED) return OCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == OCF_F32) return ocf::warp_bwd_t<float>(img, flow, gout, gimg, gflow, B, C, H, W, flow_scale, align_corners, policy, st);
+  if (dtype == OCF_F32) return ocf::warp_bwd_t<float>(img, flow, gout, gimg, gflow, workspace, B, C, H, W, flow_scale, align_corners, policy, st);
   if (dtype == OCF_BF16)
-    return ocf::warp_bwd_t<ocf::bf16>(img, flow, gout, gimg, gflow, B, C, H, W, flow_scale, align_corners, policy, st);
+    return ocf::warp_bwd_t<ocf::bf16>(img, flow, gout, gimg, gflow, workspace, B, C, H, W, flow_scale, align_corners, policy, st);
   return OCF_EINVAL;
 }

@@ -213,14 +213,21 @@ def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flo
     # the scatter kernel accumulates into grad_img with float atomics (zero it first); the gather kernels overwrite it.  Plan and
     # launch receive the SAME policy value and evaluate one decision function in the library.
     policy = POLICY.warp_bwd if policy is None else policy
-    if gimg is not None and _lib.load().ocf_warp_bwd_plan(_t4(img), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W, _dtype_code(img),
-                                                          policy) != 0:
+    zero_first = gimg is not None and _lib.load().ocf_warp_bwd_plan(_t4(img), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W,
+                                                                    _dtype_code(img), policy) != 0
+    if zero_first:
         gimg.zero_()
+
+    # scratch of the binned gather (only allocated where the gather path is taken at all: plan == 0)
+    ws = None
+    if gimg is not None and policy in (_lib.WARP_BWD_AUTO, _lib.WARP_BWD_BINNED) and not zero_first:
+        ws = _workspace(_lib.load().ocf_warp_bwd_workspace_bytes, B, C_, H, W, device=img.device)
 
     def launch():
         with torch.cuda.device(img.device):
             _lib.check(_lib.load().ocf_warp_bwd(_t4(img), _t4(flow), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W,
-                                                float(flow_scale), int(bool(align_corners)), _dtype_code(img), policy, _stream(img)),
+                                                float(flow_scale), int(bool(align_corners)), _dtype_code(img), policy,
+                                                None if ws is None else C.c_void_p(ws.data_ptr()), _stream(img)),
                        "ocf_warp_bwd")
 
     # read gout + img (es each), flow 8; write (atomics) fp32 grad_img 4C, grad_flow 8
@@ -471,9 +478,62 @@ def _moments(f):
     return sums
 
 
+def _norm_kernels_take(feats) -> bool:
+    """ocf_norm_*: dense (NCHW-contiguous or channels_last) maps of one stride pattern with whole 16-byte units per sample"""
+    f0 = feats[0]
+    if not all(f.stride() == f0.stride() and (f.is_contiguous() or f.is_contiguous(memory_format=torch.channels_last)) for f in feats):
+        return False
+    return (f0[0].numel() * f0.element_size()) % 16 == 0 and all(f.data_ptr() % 16 == 0 for f in feats) and f0.shape[0] <= 4096
+
+
+class _NormalizeKernelFn(Function):
+    """normalize_features on the HIP kernels of csrc/norm.hip: forward = ocf_moments + ONE pass per map, backward = ONE reduction pass +
+    ONE elementwise pass per map (the composed form below takes ~10 framework passes per direction)."""
+
+    @staticmethod
+    def forward(ctx, *feats):
+        S, (B, C_, H, W) = len(feats), feats[0].shape
+        L = _lib.load()
+        sums = torch.empty((S, B, 2), device=feats[0].device, dtype=torch.float64)
+        outs = []
+        with torch.cuda.device(feats[0].device):
+            for s, f in enumerate(feats):
+                _lib.check(L.ocf_moments(_t4(f), C.c_void_p(sums[s].data_ptr()), B, C_, H, W, _dtype_code(f), _stream(f)), "ocf_moments")
+            for s, f in enumerate(feats):
+                y = torch.empty_like(f)
+                _lib.check(L.ocf_norm_fwd(_t4(f), _t4(y), C.c_void_p(sums.data_ptr()), S, s, B, C_, H, W, _dtype_code(f), _stream(f)), "ocf_norm_fwd")
+                outs.append(y)
+        ctx.save_for_backward(*feats, sums)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gouts):
+        *feats, sums = ctx.saved_tensors
+        S, (B, C_, H, W) = len(feats), feats[0].shape
+        L = _lib.load()
+        gs = []
+        for g, f in zip(gouts, feats):
+            g = g if g.dtype == f.dtype else g.to(f.dtype)
+            gs.append(g if g.stride() == f.stride() else torch.empty_like(f).copy_(g))
+        bsums = torch.empty(2, device=feats[0].device, dtype=torch.float64)
+        grads = []
+        with torch.cuda.device(feats[0].device):
+            for s, (g, f) in enumerate(zip(gs, feats)):
+                _lib.check(L.ocf_norm_bwd_sums(_t4(f), _t4(g), C.c_void_p(sums.data_ptr()), C.c_void_p(bsums.data_ptr()), int(s == 0), S, B, C_, H, W,
+                                               _dtype_code(f), _stream(f)), "ocf_norm_bwd_sums")
+            for s, (g, f) in enumerate(zip(gs, feats)):
+                gx = torch.empty_like(f)
+                _lib.check(L.ocf_norm_bwd(_t4(f), _t4(g), _t4(gx), C.c_void_p(sums.data_ptr()), C.c_void_p(bsums.data_ptr()), S, s, B, C_, H, W,
+                                          _dtype_code(f), _stream(f)), "ocf_norm_bwd")
+                grads.append(gx)
+        return tuple(grads)
+
+
 class _NormalizeFn(Function):
     """(f_s - mu)/sqrt(var+1e-16) with ONE scalar mu/var over {maps, batch} (correlation_layer.py:59-82, SURVEY F6);
-    gradients flow through mu and var as in the reference."""
+    gradients flow through mu and var as in the reference.  Composed form (ocf_moments + framework elementwise passes) for layouts the
+    kernels of csrc/norm.hip do not take (strided views)."""
 
     @staticmethod
     def forward(ctx, *feats):
@@ -518,6 +578,8 @@ def normalize_features(feature_list: Sequence[torch.Tensor], normalize=True, cen
     if any(f.shape != feats[0].shape for f in feats):
         raise ValueError("normalize_features: all feature maps must have the same shape")
     feats = _features(*feats)
+    if _norm_kernels_take(feats) and os.environ.get("OCFLOW_COMPOSED_NORMALIZE", "0") != "1":
+        return list(_NormalizeKernelFn.apply(*feats))
     return list(_NormalizeFn.apply(*feats))
 
 

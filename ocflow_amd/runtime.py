@@ -20,24 +20,103 @@ import torch.nn.functional as F
 
 
 # ------------------------------------------------------------------------------------------ MIOpen tuning db
+_MIOPEN_DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+_MIOPEN_STATUS = None
+
+
+def _shipped_db_digest() -> str:
+    """content hash of the shipped db (file names + bytes): a box that ran an earlier commit must not keep serving its stale copy"""
+    import hashlib
+    h = hashlib.sha256()
+    for root, _dirs, files in sorted(os.walk(_MIOPEN_DB_DIR)):
+        for f in sorted(files):
+            p = os.path.join(root, f)
+            h.update(os.path.relpath(p, _MIOPEN_DB_DIR).encode())
+            with open(p, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _running_miopen_tag() -> Optional[str]:
+    """the version tag MIOpen puts into its db file names (e.g. 3_5_0_20250912-42-1199-g2584e35062), read from the libMIOpen.so this
+    process will load (torch bundles its own); None when it cannot be determined"""
+    import mmap
+    import re
+    cands = []
+    try:
+        import torch as _t
+        cands.append(os.path.join(os.path.dirname(_t.__file__), "lib", "libMIOpen.so"))
+    except Exception:  # pragma: no cover
+        pass
+    cands += ["/opt/rocm/lib/libMIOpen.so"]
+    for p in cands:
+        try:
+            with open(p, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as m:
+                r = re.search(rb"HIP\.(\d+_\d+_\d+_[0-9A-Za-z\-]+)\x00", m)
+                if r:
+                    return r.group(1).decode()
+        except OSError:
+            continue
+    return None
+
+
+def miopen_db_status() -> Dict[str, object]:
+    """{'shipped_tag', 'running_tag', 'matched', 'digest'}: does the find-db shipped in ocflow_amd/miopen_db belong to the MIOpen build this
+    process runs?  MIOpen only reads db files named after its own version tag; with any other build the shipped entries are IGNORED and
+    every convolution goes through the library's heuristic solver choice -- the configuration in which 32-channel aligned decoder
+    inputs once ended in a faulting library kernel, so the padding is switched off then (`_epilogue.cat_aligned`)."""
+    global _MIOPEN_STATUS
+    if _MIOPEN_STATUS is None:
+        import re
+        shipped = None
+        cfg = os.path.join(_MIOPEN_DB_DIR, "config")
+        for f in (os.listdir(cfg) if os.path.isdir(cfg) else ()):
+            r = re.match(r"gfx950[0-9a-f]*\.HIP\.(.+)\.ufdb\.txt$", f)
+            if r:
+                shipped = r.group(1)
+        running = _running_miopen_tag()
+        _MIOPEN_STATUS = {"shipped_tag": shipped, "running_tag": running, "matched": shipped is not None and shipped == running,
+                          "digest": _shipped_db_digest() if os.path.isdir(_MIOPEN_DB_DIR) else None}
+    return _MIOPEN_STATUS
+
+
 def use_repo_miopen_db(capture_dir: Optional[str] = None) -> str:
     """Point MIOpen's USER databases (find-db / perf-db text files and the compiled-kernel cache) at a writable copy of the
     ones shipped in `ocflow_amd/miopen_db/`.  A fresh MI355X box has no gfx950 find-db and no kernel cache (ROCm 7.2 ships only
     the gfx950 heuristics models), so the first step of this workload spends 50-120 s searching and JIT-compiling conv
     kernels; with the shipped db (1.6 MB, produced by this very benchmark) the same solvers are picked immediately.
-    Must run before the first convolution.  `capture_dir`: use that directory instead (to (re)generate the shipped db)."""
+    Must run before the first convolution.  `capture_dir`: use that directory instead (to (re)generate the shipped db).
+
+    The copy lives in a per-user directory (mode 0700) whose name carries the content hash of the shipped db: a new db is a new
+    directory, a stale copy from an earlier commit is never served.  `miopen_db_status()` says whether the db's version tag is the
+    running MIOpen's; when it is not, a warning is printed once and the aligned concatenations fall back to plain ones."""
     import shutil
     import tempfile
+    import warnings
     if "MIOPEN_USER_DB_PATH" in os.environ and capture_dir is None:
         return os.environ["MIOPEN_USER_DB_PATH"]
-    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+    src = _MIOPEN_DB_DIR
     if capture_dir is not None:
         dst = capture_dir
         os.makedirs(dst, exist_ok=True)
     else:
-        dst = os.path.join(tempfile.gettempdir(), f"ocflow_miopen_db_{os.getuid()}_{os.environ.get('LOCAL_RANK', '0')}")
+        st = miopen_db_status()
+        if not st["matched"]:
+            warnings.warn(f"ocflow_amd: the shipped MIOpen find-db is for MIOpen {st['shipped_tag']}, this process runs {st['running_tag']}: "
+                          "its entries will be ignored (first steps search / JIT-compile their convolution kernels) and the 32-channel "
+                          "aligned decoder inputs are switched off", RuntimeWarning, stacklevel=2)
+        base = os.path.join(tempfile.gettempdir(), f"ocflow_miopen_{os.getuid()}")
+        os.makedirs(base, mode=0o700, exist_ok=True)
+        if os.stat(base).st_uid != os.getuid():  # (a directory of that name planted by someone else)
+            base = tempfile.mkdtemp(prefix="ocflow_miopen_")
+        dst = os.path.join(base, f"{st['digest']}_{os.environ.get('LOCAL_RANK', '0')}")
         if os.path.isdir(src) and not os.path.isdir(dst):
-            shutil.copytree(src, dst)
+            tmp = dst + f".tmp{os.getpid()}"
+            shutil.copytree(src, tmp)
+            try:
+                os.replace(tmp, dst)
+            except OSError:  # another process of this rank got there first
+                shutil.rmtree(tmp, ignore_errors=True)
         os.makedirs(dst, exist_ok=True)
     os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(dst, "config")
     os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(dst, "cache")

@@ -60,17 +60,17 @@ def corr_warp_backward(f1: torch.Tensor, f2: torch.Tensor, flow: Optional[torch.
     g1, g2, gflow, gocc = ops._corr_warp_bwd_raw(f1, f2, flow, occ, _none_if_empty(warped), grad_out, max_displacement, flow_scale, align_corners,
                                                  (need_f1, need_f2, need_flow and flow is not None, need_occ and occ is not None),
                                                  ops.POLICY.corr_bwd, ops.POLICY.warp_bwd)
-    e = f1.new_empty(0)
-    return (g1 if g1 is not None else e, g2 if g2 is not None else e, gflow if gflow is not None else e.float(),
-            gocc if gocc is not None else e.float())
+    e = lambda dt: torch.empty(0, dtype=dt, device=f1.device)  # (a fresh tensor per slot: results of a custom operator may not alias)
+    return (g1 if g1 is not None else e(f1.dtype), g2 if g2 is not None else e(f1.dtype), gflow if gflow is not None else e(torch.float32),
+            gocc if gocc is not None else e(torch.float32))
 
 
 @corr_warp_backward.register_fake
 def _(f1, f2, flow, occ, warped, grad_out, max_displacement, flow_scale, align_corners, need_f1, need_f2, need_flow, need_occ):
-    e = f1.new_empty(0)
-    return (torch.empty_like(f1) if need_f1 else e, torch.empty_like(f2) if need_f2 else e,
-            torch.empty_like(flow) if (need_flow and flow is not None) else e.float(),
-            torch.empty_like(occ) if (need_occ and occ is not None and (need_f2 or need_flow or need_occ)) else e.float())
+    e = lambda dt: torch.empty(0, dtype=dt, device=f1.device)
+    return (torch.empty_like(f1) if need_f1 else e(f1.dtype), torch.empty_like(f2) if need_f2 else e(f1.dtype),
+            torch.empty_like(flow) if (need_flow and flow is not None) else e(torch.float32),
+            torch.empty_like(occ) if (need_occ and occ is not None) else e(torch.float32))
 
 
 def _cw_setup(ctx, inputs, output):

@@ -21,9 +21,29 @@ def find(d, pat):
 
 
 def short(name):
+    """a readable kernel name.  rocprofv3 leaves names whose template arguments include __bf16 (`DF16b`) MANGLED (_ZN3ocf...): those are
+    rebuilt from the length-prefixed identifiers of the nested name + the raw template-argument string."""
+    if name.startswith("_ZN"):
+        import re
+        i, parts = 3, []
+        while i < len(name) and name[i].isdigit():
+            m = re.match(r"\d+", name[i:])
+            n = int(m.group(0))
+            i += len(m.group(0))
+            parts.append(name[i:i + n])
+            i += n
+        targs = ""
+        if i < len(name) and name[i] == "I":  # template arguments up to the matching 'E' of the nested name
+            j = name.find("EEv", i)
+            targs = "<" + name[i + 1:(j if j > 0 else i + 24)].replace("DF16b", "bf16,").replace("Li", "").replace("Lb", "").replace("E", ",").strip(",") + ">"
+        return ("::".join(parts) + targs)[:90]
     n = name.split("(")[0]
     n = n.replace("void ", "")
     return n[:90]
+
+
+def ours(name):
+    return "ocf::" in name or name.startswith("_ZN3ocf")
 
 
 def trace_groups(path):
@@ -31,7 +51,7 @@ def trace_groups(path):
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name", "")
-            if "ocf::" not in name:
+            if not ours(name):
                 continue
             grid = row.get("Grid_Size_X") or row.get("Grid_Size") or "?"
             dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
@@ -44,7 +64,7 @@ def counter_groups(path):
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name", "")
-            if "ocf::" not in name:
+            if not ours(name):
                 continue
             grid = row.get("Grid_Size_X") or row.get("Grid_Size") or "?"
             groups[(short(name), grid, row.get("Counter_Name", "?"))].append(float(row.get("Counter_Value", 0)))

@@ -313,10 +313,30 @@ def test_range_map_full_batch_vs_oracle(ops):
         assert_close(oc, O.occlusion_from_range(ref), 1e-4, 1e-5, "occlusion")
 
 
+def test_warp_backward_binned_overflow(ops, lib):
+    """a CONVERGENT flow: every source of a 64 x 96 map samples near the centre, so the bins of the few central tiles (896 entries each)
+    overflow and the surplus (source, tile) pairs take the overflow list -> float-atomic path of the per-source kernel; against autograd
+    of the oracle's grid_sample warp"""
+    Bb, Cc, h, w = 2, 32, 64, 96
+    gen = torch.Generator().manual_seed(91)
+    img = torch.randn((Bb, Cc, h, w), generator=gen)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    flow = torch.stack([(w / 2 - xx) * 0.93, (h / 2 - yy) * 0.93], 0).unsqueeze(0).repeat(Bb, 1, 1, 1) + torch.randn((Bb, 2, h, w), generator=gen) * 0.3
+    cot = torch.randn((Bb, Cc, h, w), generator=gen)
+    a, f = img.clone().requires_grad_(), flow.clone().requires_grad_()
+    gir, gfr = torch.autograd.grad(O.warp(a, f, True), (a, f), cot)
+    with ops.kernel_policy(warp_bwd=lib.WARP_BWD_BINNED):
+        x, fl = cl(img).requires_grad_(), flow.to(DEV).requires_grad_()
+        gi, gf = torch.autograd.grad(ops.warp(x, fl, True), (x, fl), cl(cot))
+    assert_close(gi, gir, 1e-4, 2e-5, "grad img (overflowing bins)")
+    assert_close(gf, gfr, 1e-4, 2e-5, "grad flow", outliers=2e-3)
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 23, 45), (1, 196, 7, 16), (3, 8, 9, 33), (1, 32, 40, 70), (2, 64, 5, 130)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ac", [False, True])
-def test_warp_backward_gather_kernels_small_shapes(ops, lib, shape, dtype, ac):
+@pytest.mark.parametrize("form", ["window", "binned"])
+def test_warp_backward_gather_kernels_small_shapes(ops, lib, shape, dtype, ac, form):
     """the gather + per-source kernel pair forced on (policy OCF_WARP_BWD_POLICY_GATHER) at shapes the automatic policy would give to the scatter
     kernel: partial tiles, channel counts that are not a multiple of 32 (40, 196: 8-byte aligned pixels), fp32, both sampling
     conventions, flows with many FAR sources (|displacement| > 6 px: the float-atomic path inside the per-source kernel) and sources
@@ -328,7 +348,9 @@ def test_warp_backward_gather_kernels_small_shapes(ops, lib, shape, dtype, ac):
     cot = torch.randn(shape, generator=gen).to(dtype)
     a, f = img.float().requires_grad_(), flow.clone().requires_grad_()
     gir, gfr = torch.autograd.grad(O.warp(a, f, ac), (a, f), cot.float())
-    with ops.kernel_policy(warp_bwd=lib.WARP_BWD_GATHER):
+    # window form: sources within +-6 px gathered, the rest scattered with float atomics; binned form (round 3): every source listed in
+    # the bins of the tiles its taps land in, nothing is "far"
+    with ops.kernel_policy(warp_bwd=lib.WARP_BWD_GATHER if form == "window" else lib.WARP_BWD_BINNED):
         x, fl = cl(img).requires_grad_(), flow.to(DEV).requires_grad_()
         gi, gf = torch.autograd.grad(ops.warp(x, fl, ac), (x, fl), cl(cot))
     tol = 2e-5 if dtype == torch.float32 else 2e-2

@@ -310,15 +310,51 @@ def test_range_map_mass_conservation(ops):
 
 
 # ------------------------------------------------------------------------------------ feature normalise
-def test_normalize_golden(ops, golden):
+@pytest.mark.parametrize("form", ["kernels", "kernels_channels_last", "composed", "strided_view"])
+def test_normalize_golden(ops, golden, form, monkeypatch):
+    """normalize_features (correlation_layer.py:59-82) against the reference golden, value and the exact gradient through mu and var:
+    the kernel pair of csrc/norm.hip (dense NCHW and channels_last maps), the composed form (ocf_moments + framework passes) forced by
+    OCFLOW_COMPOSED_NORMALIZE=1, and a strided view, which the kernels refuse and the composed form takes"""
     g = golden("norm")
     f1, f2 = dev(g["f1"], True), dev(g["f2"], True)
-    n1, n2 = ops.normalize_features([f1, f2])
+    a, b = f1, f2
+    if form == "kernels_channels_last":
+        a, b = (t.detach().contiguous(memory_format=torch.channels_last).requires_grad_() for t in (f1, f2))
+    if form == "composed":
+        monkeypatch.setenv("OCFLOW_COMPOSED_NORMALIZE", "1")
+    if form == "strided_view":
+        big = [torch.zeros((t.shape[0], t.shape[1] + 3, t.shape[2], t.shape[3]), device=DEV) for t in (f1, f2)]
+        for bg, t in zip(big, (f1, f2)):
+            bg[:, 1:1 + t.shape[1]] = t.detach()
+        a, b = (bg[:, 1:1 + t.shape[1]].requires_grad_() for bg, t in zip(big, (f1, f2)))
+    assert ops._norm_kernels_take([a.detach(), b.detach()]) == (form in ("kernels", "kernels_channels_last", "composed"))
+    n1, n2 = ops.normalize_features([a, b])
     close(n1, g["n1"], 1e-5)
     close(n2, g["n2"], 1e-5)
-    gf1, gf2 = torch.autograd.grad((n1 * dev(g["c1"])).sum() + (n2 * dev(g["c2"])).sum(), (f1, f2))
+    gf1, gf2 = torch.autograd.grad((n1 * dev(g["c1"])).sum() + (n2 * dev(g["c2"])).sum(), (a, b))
     close(gf1, g["gf1"], 5e-5)
     close(gf2, g["gf2"], 5e-5)
+
+
+def test_normalize_kernels_bf16_and_batch_coupling(ops):
+    """bf16 maps at a PWC pyramid shape: kernel pair vs the fp32 oracle on the same bf16-rounded inputs (forward to bf16 resolution,
+    gradients to 2e-2 of their scale), and the batch coupling of F6 (ONE mean / variance for both maps and all samples)"""
+    gen = torch.Generator().manual_seed(44)
+    f1 = (torch.randn((4, 64, 24, 32), generator=gen) * 1.5 + 0.3).bfloat16()
+    f2 = (torch.randn((4, 64, 24, 32), generator=gen) * 0.7 - 0.2).bfloat16()
+    c1, c2 = torch.randn(f1.shape, generator=gen), torch.randn(f1.shape, generator=gen)
+    a, b = f1.float().requires_grad_(), f2.float().requires_grad_()
+    r1, r2 = O.normalize_features([a, b])
+    g1, g2 = torch.autograd.grad((r1 * c1).sum() + (r2 * c2).sum(), (a, b))
+    x = f1.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = f2.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    n1, n2 = ops.normalize_features([x, y])
+    assert n1.dtype == torch.bfloat16
+    close(n1, r1, 2e-2)
+    close(n2, r2, 2e-2)
+    gx, gy = torch.autograd.grad((n1.float() * c1.to(DEV)).sum() + (n2.float() * c2.to(DEV)).sum(), (x, y))
+    for got, want in ((gx, g1), (gy, g2)):
+        np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), rtol=5e-2, atol=2e-2 * float(want.abs().max()))
 
 
 # ------------------------------------------------------------------- full-size, size-independent properties

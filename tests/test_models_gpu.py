@@ -145,6 +145,7 @@ def test_bf16_autocast_step_runs():
 def _grads_with_and_without_padding(monkeypatch, build, run):
     """build() -> module; run(module) -> (scalar loss, tensors that need gradients).  Both variants start from the same weights/inputs."""
     out = []
+    monkeypatch.setenv("OCFLOW_PAD_ALWAYS", "1")  # (by default only shapes of the shipped find-db are aligned: _epilogue._padded_shape_is_known)
     for unpadded in (False, True):
         monkeypatch.setenv("OCFLOW_UNPADDED_CAT", "1" if unpadded else "0")
         torch.manual_seed(3)
@@ -184,6 +185,14 @@ def test_aligned_concatenation_is_the_same_block(monkeypatch, block):
     a, b = torch.randn((1, 5, 4, 6), device=DEV), torch.randn((1, 4, 4, 6), device=DEV)
     assert torch.equal(cat_aligned([a, b]), torch.cat([a, b], 1))  # fp32: plain torch.cat
     monkeypatch.setenv("OCFLOW_UNPADDED_CAT", "0")
+    # default policy: align only inputs whose convolution the shipped find-db covers (and only under the MIOpen build it was made with)
+    from ocflow_amd.models.networks import _epilogue
+    from ocflow_amd.runtime import miopen_db_status
+    small = [a.bfloat16().contiguous(memory_format=torch.channels_last), b.bfloat16().contiguous(memory_format=torch.channels_last)]
+    assert cat_aligned(small).shape[1] == 9  # a shape no find-db entry exists for stays as it is
+    if miopen_db_status()["matched"]:
+        assert _epilogue._padded_shape_is_known(8, 128, 109, 256) and not _epilogue._padded_shape_is_known(4, 128, 80, 304)
+    monkeypatch.setenv("OCFLOW_PAD_ALWAYS", "1")
     padded = cat_aligned([a.bfloat16().contiguous(memory_format=torch.channels_last), b.bfloat16().contiguous(memory_format=torch.channels_last)])
     assert padded.shape == (1, 32, 4, 6) and padded.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(padded[:, :9], torch.cat([a, b], 1).bfloat16()) and float(padded[:, 9:].abs().max()) == 0.0

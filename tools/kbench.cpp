@@ -126,9 +126,31 @@ int main(int argc, char** argv) {
              d2 / (mx2 + 1e-30), dm / (mxo + 1e-30));
     }
     CK(hipFree(wide));
-    float f_scatter = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, OCF_WARP_BWD_POLICY_SCATTER, st); }, st, 50);
-    float f = time_us([&] { ocf_warp_bwd(&t2, &tf, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, OCF_WARP_BWD_POLICY_AUTO, st); }, st, 50);
-    printf("  warp_bwd: destination-tile + far scatter %.1f us | scatter only (+ grad_img memset outside) %.1f us\n", f, f_scatter);
+    // warp backward: scatter / window gather / binned gather, on the small-motion flow and on a flow as an untrained model produces it
+    // (a quarter of the sources displaced by 8-40 pixels)
+    int64_t wsb = 0; ocf_warp_bwd_workspace_bytes(B, C, H, W, &wsb);
+    void* wws; CK(hipMalloc(&wws, (size_t)wsb));
+    void* flow_big; CK(hipMalloc(&flow_big, np * 8));
+    {
+      std::vector<float> hb2(np * 2);
+      for (size_t i = 0; i < np * 2; i++) {
+        const unsigned h = (unsigned)(i * 2654435761u) >> 8;
+        const float small = (float)(h % 4001) / 1000.f - 2.f;
+        hb2[i] = (h % 4 == 0) ? small * 10.f : small;
+      }
+      CK(hipMemcpy(flow_big, hb2.data(), np * 8, hipMemcpyHostToDevice));
+    }
+    ocf_tensor4 tfb = mkt(flow_big, B, 2, H, W, false);
+    auto wb = [&](const ocf_tensor4* fl, int policy, void* ws) {
+      return time_us([&] { ocf_warp_bwd(&t2, fl, &tg1, &tgi, &tgf, B, C, H, W, 1.25f, 0, dt, policy, ws, st); }, st, 50);
+    };
+    const float f_scatter = wb(&tf, OCF_WARP_BWD_POLICY_SCATTER, nullptr), f_win = wb(&tf, OCF_WARP_BWD_POLICY_GATHER, nullptr);
+    const float f = wb(&tf, OCF_WARP_BWD_POLICY_AUTO, wws);
+    const float fb_scatter = wb(&tfb, OCF_WARP_BWD_POLICY_SCATTER, nullptr), fb_win = wb(&tfb, OCF_WARP_BWD_POLICY_GATHER, nullptr);
+    const float fb = wb(&tfb, OCF_WARP_BWD_POLICY_AUTO, wws);
+    printf("  warp_bwd small motion: auto (binned where eligible) %.1f us | window gather + far scatter %.1f | scatter only %.1f || 25%% large motion: auto %.1f | window %.1f | scatter %.1f\n",
+           f, f_win, f_scatter, fb, fb_win, fb_scatter);
+    CK(hipFree(wws)); CK(hipFree(flow_big));
     double px = (double)np, bytes_plain = px * (2.0 * C * es + 81.0 * es);
     printf("%3dx%3dx%4d | corr %7.1f us %6.0f GB/s | +occ %7.1f us %6.0f | fused %7.1f us %6.0f | warp %6.1f us %6.0f | corr_bwd %7.1f us %6.0f (g1 %5.1f g2 %5.1f) | +occ %7.1f us | warp_bwd %7.1f us %6.0f\n",
            C, H, W, a, bytes_plain / a / 1e3, b, (bytes_plain + px * 4) / b / 1e3, c, (bytes_plain + px * 12) / c / 1e3, d, px * (2.0 * C * es + 8) / d / 1e3,
