@@ -21,12 +21,28 @@ import os as _os
 import sys as _sys
 
 
+def _hip_runtime_started() -> bool:
+    """has THIS process already initialised the ROCm runtime?  torch's own flag (`torch.cuda.is_initialized()`) only covers torch's lazy
+    initialisation: `torch.cuda.is_available()` / a ctypes call into libamdhip64 start the runtime -- which is when the variable is
+    read -- without setting it.  The runtime opens /dev/kfd when it starts: an open descriptor on it is the process-level evidence."""
+    try:
+        for fd in _os.listdir("/proc/self/fd"):
+            try:
+                if _os.readlink(f"/proc/self/fd/{fd}") == "/dev/kfd":
+                    return True
+            except OSError:
+                continue
+    except OSError:
+        pass
+    return False
+
+
 def _graph_env_guard() -> bool:
     """Set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 unless the caller chose a value; True when that came too late to take effect."""
     if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in _os.environ:
         return False  # the launcher's choice (a value other than "0" is refused by enable_graph itself)
     torch = _sys.modules.get("torch")
-    late = bool(torch is not None and torch.cuda.is_initialized())
+    late = bool(torch is not None and torch.cuda.is_initialized()) or _hip_runtime_started()
     _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
     return late
 

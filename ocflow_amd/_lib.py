@@ -22,6 +22,7 @@ OCF_F32, OCF_BF16 = 0, 1
 # per-call kernel policies (enum ocf_corr_policy, ocf_corr_bwd_policy, ocf_warp_bwd_policy, ocf_range_policy of the header)
 CORR_AUTO, CORR_BAND_ONLY, CORR_NO_WAVE, CORR_WAVE = 0, 1, 2, 3
 CORR_VARIANT_WAVE = 4  # enum ocf_corr_variant
+CORR_VARIANTS_WITH_GATHER = (1, 2, 4)  # row kernels (C <= 64) and wave kernel: the warp gathered inside the correlation launch
 CORR_BWD_AUTO, CORR_BWD_VECTOR, CORR_BWD_MFMA = 0, 1, 2
 WARP_BWD_AUTO, WARP_BWD_SCATTER, WARP_BWD_GATHER, WARP_BWD_BINNED = 0, 1, 2, 3
 RANGE_AUTO, RANGE_SPLAT, RANGE_GATHER = 0, 1, 2

@@ -14,7 +14,7 @@ int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const oc
 int corr_rows_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* out, int C, int H, int W,
                       int d);
 int corr_fwd_bf16_rows(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* occ, const ocf_tensor4* out, int B, int C, int H,
-                       int W, hipStream_t st);
+                       int W, hipStream_t st, const ocf_tensor4* flow = nullptr, float fs = 1.f, int ac = 0);
 // the wave kernel (corr_wave.hip): small levels (C > 64), any output pixel pitch, optional in-register warp gather of the second operand
 bool corr_wave_eligible(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ, const ocf_tensor4* out,
                         int B, int C, int H, int W, int d);

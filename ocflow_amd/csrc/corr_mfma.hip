@@ -475,7 +475,7 @@ int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const oc
   if (policy == OCF_CORR_POLICY_BAND_ONLY) return band_variant(B, C, H, W);
   const bool wave_ok = policy != OCF_CORR_POLICY_NO_WAVE && corr_wave_eligible(f1, f2, flow, occ, out, B, C, H, W, d);
   if (policy == OCF_CORR_POLICY_WAVE && wave_ok) return OCF_CORR_WAVE;
-  const int v = corr_rows_variant(f1, f2, flow, out, C, H, W, d);  // (0 with a flow, or when the output is not a dense cost volume)
+  const int v = corr_rows_variant(f1, f2, flow, out, C, H, W, d);  // (0 when the output is not a dense cost volume; with a flow: C <= 64 only)
   if (v == OCF_CORR_DIRECT && wave_ok) return OCF_CORR_WAVE;       // small levels: independent waves instead of nine-wave workgroups
   if (v) return v;
   // no row kernel for this request: the wave kernel takes the small levels with the warp gathered in registers, and cost volumes
@@ -488,7 +488,7 @@ int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_t
                        const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, int policy, hipStream_t st) {
   const int variant = corr_fwd_bf16_variant(f1, f2, flow, occ, out, B, C, H, W, d, policy);
   if (variant == OCF_CORR_WAVE) return corr_fwd_bf16_wave(f1, f2, flow, occ, out, B, C, H, W, fs, ac, st);
-  if (variant <= OCF_CORR_DIRECT) return corr_fwd_bf16_rows(f1, f2, occ, out, B, C, H, W, st);
+  if (variant <= OCF_CORR_DIRECT) return corr_fwd_bf16_rows(f1, f2, occ, out, B, C, H, W, st, flow, fs, ac);
   auto span = [&](const ocf_tensor4* t, long c) { return (labs(t->sh) * H + labs(t->sw) * W + labs(t->sc) * c) * 2L; };
   if (span(f1, C) >= (1L << 31) || span(f2, C) >= (1L << 31)) return OCF_EUNSUPPORTED;
   int vec = min_vec(vec_width<bf16>(f1), vec_width<bf16>(f2));

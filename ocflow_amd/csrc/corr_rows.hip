@@ -63,9 +63,17 @@ __device__ __forceinline__ int slot(int row, int x, int u) { return (row * ROWPX
 // load whose only use sits behind a condition -- hipcc sinks such a load into a branch and then waits for EVERY outstanding load)
 __device__ u32x4 g_zero16[2];  // zero-initialised; deliberately NOT const (a constant-address-space pointer would turn the selected loads into flat_load)
 
-template <int KB, int TH, int WPR, int MODE, int P = 1>
+// GATHER (round 3): the second operand is warp(f2, flow * fs) -- K1 + K2 in ONE launch at the two large pyramid levels.  The halo tile is not
+// copied from f2 but SAMPLED: every staged 16-byte unit (8 channels of one halo pixel) is the bilinear blend of the four neighbour units
+// around the pixel's sample position, loaded with address-select (invalid taps read a zero unit), blended in fp32 in ocf_warp_fwd's own
+// fma order and rounded to bf16 -- bit-identical to the materialised warp.  With a smooth flow the 16 pixels x 4 units of a wave
+// instruction sample 16 neighbouring source pixels, i.e. a tap load is as coalesced as the plain staging load, and the four taps of
+// neighbouring pixels share cache lines (L1): the cost over the plain kernel is 4x the staging load INSTRUCTIONS and ~80 VALU operations
+// per staged unit, not 4x the traffic.  The flow of the NEXT tile's halo pixels is prefetched with its f1 fragments; the tap loads are
+// issued one halo row (3-5 units per lane) at a time at the top of a tile -- three workgroups per CU cover each other's waits.
+template <int KB, int TH, int WPR, int MODE, int P = 1, bool GATHER = false>
 __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(T4 f1, T4 f2, T4 occ, T4 out, int B, int C, int H, int W, int tiles_x,
-                                                                   int tiles_y, int ablate) {
+                                                                   int tiles_y, int ablate, T4 flow, float fs, WarpGeom wg) {
 #ifndef OCF_TUNING_BUILD
   ablate = 0;  // phase-skipping switches (wrong results) exist only in the tuning build tools/kbench makes for itself
 #endif
@@ -95,8 +103,10 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
   const int xcd = blockIdx.x & 7, slots = gridDim.x >> 3;
   int ti = blockIdx.x >> 3;
 
-  u32x4 st[GG::ROWS_PER_WAVE][GG::SWEEPS], an[P][KB][2];
+  u32x4 st[GATHER ? 1 : GG::ROWS_PER_WAVE][GATHER ? 1 : GG::SWEEPS], an[P][KB][2];
+  unsigned flw[GATHER ? GG::ROWS_PER_WAVE : 1][GATHER ? GG::SWEEPS : 1][2];  // GATHER: (u, v) of the halo pixel of every staged unit
   unsigned ocr[OCC_PER];
+  const int fsh = (int)flow.sh, fsw = (int)flow.sw, fsc = (int)flow.sc;
   // ---- issue every global load of tile (b, ty0, tx0): f2 halo rows (one wave per row, lanes sweep the 16-byte units in memory
   // order), this wave's f1 fragments (lane (i = l&15, kg = l>>4): channels 8kg..8kg+7 of pixel i of a strip), the occlusion halo
   auto issue = [&](int b, int ty0, int tx0) __attribute__((always_inline)) {
@@ -107,6 +117,19 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
       const int r = wave + rr * GG::NW;
       const int gy = ty0 - D + r;
       const bool rowok = r < GG::HH && gy >= 0 && gy < H;
+      if (GATHER) {  // the flow at the (clamped) halo pixel; the taps themselves are loaded when the tile is staged
+        const float* flb = (const float*)flow.p + (long)b * flow.sb;
+        const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+#pragma unroll
+        for (int k = 0; k < GG::SWEEPS; k++) {
+          const int x = (lane + 64 * k) / (NUM * KB);
+          const int gx = tx0 - D + x, gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+          const unsigned* fp = (const unsigned*)(flb + gyc * fsh + gxc * fsw);
+          flw[rr][k][0] = fp[0];
+          flw[rr][k][1] = fp[fsc];
+        }
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < GG::SWEEPS; k++) {
         const int it = lane + 64 * k;
@@ -182,6 +205,53 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
   }
   while (have) {
     // ---- commit the prefetched operands of this tile to LDS (the previous tile's readers passed the barrier at the loop's end)
+    if (GATHER) {
+      // sample the halo tile through the warp, one halo row of this wave at a time: all tap loads of the row in flight, then the blends
+      const char* f2img = f2.p + (long)b * f2.sb * 2;
+#pragma unroll
+      for (int rr = 0; rr < GG::ROWS_PER_WAVE; rr++) {
+        const int r = wave + rr * GG::NW;
+        if (r < GG::HH) {
+          const int gy = ty0 - D + r;
+          const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+          u32x4 nb[GG::SWEEPS][4];
+          float w4[GG::SWEEPS][4];
+#pragma unroll
+          for (int k = 0; k < GG::SWEEPS; k++) {
+            const int it = lane + 64 * k;
+            const int uu = it & (NUM * KB - 1), x = it / (NUM * KB);
+            const int gx = tx0 - D + x, c0 = uu * 8;
+            const int gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            const bool ok = it < GG::ROW_ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 < C;
+            const float uf = __builtin_bit_cast(float, flw[rr][k][0]) * fs, vf = __builtin_bit_cast(float, flw[rr][k][1]) * fs;
+            const Bilin sp = bilin_setup(((float)gxc + uf) * wg.ax + wg.bx, ((float)gyc + vf) * wg.ay + wg.by, H, W);
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+              const int ddx = n & 1, ddy = n >> 1;
+              const bool okn = ok && ((ddx ? sp.vx1 : sp.vx0) & (ddy ? sp.vy1 : sp.vy0));
+              w4[k][n] = (ddx ? sp.wx1 : 1.f - sp.wx1) * (ddy ? sp.wy1 : 1.f - sp.wy1);
+              nb[k][n] = *(const u32x4*)(okn ? f2img + (long)((sp.y0 + ddy) * f2sh + (sp.x0 + ddx) * f2sw + c0) * 2 : zp);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < GG::SWEEPS; k++) {
+            const int it = lane + 64 * k;
+            const int uu = it & (NUM * KB - 1), x = it / (NUM * KB);
+            float a8[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) a8[e] = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+              float f8[8];
+              unit_to_f<bf16>(nb[k][n], f8);
+#pragma unroll
+              for (int e = 0; e < 8; e++) a8[e] = __builtin_fmaf(w4[k][n], f8[e], a8[e]);
+            }
+            if (it < GG::ROW_ITEMS) s_f2[(uu >> 2) * GG::PLANE + slot(r, x, uu & 3)] = f_to_unit<bf16>(a8);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int rr = 0; rr < GG::ROWS_PER_WAVE; rr++) {
       const int r = wave + rr * GG::NW;
@@ -193,6 +263,7 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
           if (it < GG::ROW_ITEMS) s_f2[(uu >> 2) * GG::PLANE + slot(r, x, uu & 3)] = st[rr][k];
         }
       }
+    }
     }
     if (MODE) {
 #pragma unroll
@@ -459,8 +530,9 @@ static int rows_num_cus() {
   return n;
 }
 
-template <int KB, int TH, int WPR, int MODE, int P = 1>
-static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out, int B, int C, int H, int W, hipStream_t st) {
+template <int KB, int TH, int WPR, int MODE, int P = 1, bool GATHER = false>
+static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out, int B, int C, int H, int W, hipStream_t st, const T4& flow = T4{nullptr, 0, 0, 0, 0},
+                       float fs = 1.f, int ac = 0) {
   using GG = rw::G<KB, TH, WPR, P>;
   const int tx = (W + rw::TW - 1) / rw::TW, ty = (H + TH * P - 1) / (TH * P);
   const long ntiles = (long)B * tx * ty;
@@ -472,8 +544,8 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
   static int wg_per_cu = 0;
   if (wg_per_cu == 0) {
     int nb = 0;
-    (void)hipFuncSetAttribute((const void*)corr_fwd_rows<KB, TH, WPR, MODE, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_rows<KB, TH, WPR, MODE, P>, GG::NT, lds);
+    (void)hipFuncSetAttribute((const void*)corr_fwd_rows<KB, TH, WPR, MODE, P, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_rows<KB, TH, WPR, MODE, P, GATHER>, GG::NT, lds);
     wg_per_cu = (e == hipSuccess && nb >= 1) ? (nb > (KB == 1 ? 3 : 2) ? (KB == 1 ? 3 : 2) : nb) : 1;
     // the occupancy API is advisory: LDS is handed out in 1280-byte granules (a persistent grid sized for a workgroup that is not
     // resident would run that workgroup's tiles after everyone else has finished)
@@ -489,7 +561,8 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
   if (ps.start && ps.stop) {  // one-shot: the events receive this dispatch's own begin / end timestamps
     hipEvent_t e0 = ps.start, e1 = ps.stop;
     ps.start = nullptr; ps.stop = nullptr;
-    hipExtLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE, P>), grid, block, lds, st, e0, e1, 0, f1, f2, occ, out, B, C, H, W, tx, ty, 0);
+    hipExtLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE, P, GATHER>), grid, block, lds, st, e0, e1, 0, f1, f2, occ, out, B, C, H, W, tx, ty, 0, flow, fs,
+                          WarpGeom(H, W, ac));
   } else {
     int ablate = 0;
 #ifdef OCF_TUNING_BUILD
@@ -498,12 +571,13 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
     static bool told = false;
     if (!told) {
       int nb = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_rows<KB, TH, WPR, MODE, P>, GG::NT, lds);
-      fprintf(stderr, "[tuning] corr_fwd_rows<%d,%d,%d,%d>: %zu B LDS, %d workgroups per CU, ablate %d\n", KB, TH, WPR, MODE, lds, nb, ab);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_fwd_rows<KB, TH, WPR, MODE, P, GATHER>, GG::NT, lds);
+      fprintf(stderr, "[tuning] corr_fwd_rows<%d,%d,%d,%d,%d,%d>: %zu B LDS, %d workgroups per CU, ablate %d\n", KB, TH, WPR, MODE, P, (int)GATHER, lds, nb, ab);
       told = true;
     }
 #endif
-    hipLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE, P>), grid, block, lds, st, f1, f2, occ, out, B, C, H, W, tx, ty, ablate);
+    hipLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE, P, GATHER>), grid, block, lds, st, f1, f2, occ, out, B, C, H, W, tx, ty, ablate, flow, fs,
+                       WarpGeom(H, W, ac));
   }
   return launch_status();
 }
@@ -511,8 +585,12 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
 // 0: not for these kernels; OCF_CORR_ROWS_K1 / _K2 / OCF_CORR_DIRECT otherwise
 int corr_rows_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* out, int C, int H, int W,
                       int d) {
-  if (flow || d != rw::D || C % 4 != 0) return 0;
+  if (d != rw::D || C % 4 != 0) return 0;
   const int vec = min_vec(vec_width<bf16>(f1), vec_width<bf16>(f2));
+  // with a flow (in-kernel warp gather): the two row kernels only, 16-byte units, a flow with forward strides that fit 32-bit offsets
+  if (flow && (C > 64 || vec != 16 || C % 8 != 0 || flow->sw <= 0 || flow->sh <= 0 || flow->sc <= 0 ||
+               flow->sh * (long)H + flow->sc * 2 >= (1L << 31)))
+    return 0;
   if (vec < 8 || (vec == 8 && C <= 64) || (vec == 16 && C % 8 != 0)) return 0;
   auto span = [&](const ocf_tensor4* t) { return (labs(t->sh) * H + labs(t->sw) * W + C) * 2L; };
   if (span(f1) >= (1L << 31) || span(f2) >= (1L << 31)) return 0;
@@ -527,8 +605,14 @@ int corr_rows_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_te
 }
 
 int corr_fwd_bf16_rows(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* occ, const ocf_tensor4* out, int B, int C, int H,
-                       int W, hipStream_t st) {
+                       int W, hipStream_t st, const ocf_tensor4* flow, float fs, int ac) {
   const T4 a = mk(f1), bq = mk(f2), oc = mk(occ), o = mk(out);
+  if (flow) {  // K1 + K2 in one launch (C <= 64: corr_rows_variant)
+    const T4 fl = mk(flow);
+    if (C <= 32)
+      return occ ? launch_rows<1, 4, 1, 1, 1, true>(a, bq, oc, o, B, C, H, W, st, fl, fs, ac) : launch_rows<1, 4, 1, 0, 1, true>(a, bq, oc, o, B, C, H, W, st, fl, fs, ac);
+    return occ ? launch_rows<2, 2, 2, 1, 2, true>(a, bq, oc, o, B, C, H, W, st, fl, fs, ac) : launch_rows<2, 2, 2, 0, 2, true>(a, bq, oc, o, B, C, H, W, st, fl, fs, ac);
+  }
   if (C > 64) {
     if (min_vec(vec_width<bf16>(f1), vec_width<bf16>(f2)) == 16)
       return occ ? launch_direct_kb<16, 1>(a, bq, oc, o, B, C, H, W, st) : launch_direct_kb<16, 0>(a, bq, oc, o, B, C, H, W, st);

@@ -246,7 +246,7 @@ def _fuse_warp(f1, f2, flow, occ, out, d, needs_grad) -> bool:
         return False  # backward consumes the warped tensor: kept from the forward instead of being recomputed
     B, C_, H, W = f1.shape
     v = _lib.load().ocf_corr_fwd_variant(_t4(f1), _t4(f2), _t4(flow), _t4(occ), _t4(out), B, C_, H, W, d, _dtype_code(f1), POLICY.corr_fwd)
-    return v == _lib.CORR_VARIANT_WAVE
+    return v in _lib.CORR_VARIANTS_WITH_GATHER
 
 
 def _corr_warp_fwd_raw(f1, f2, flow, occ, d, flow_scale, align_corners, out, needs_grad):

@@ -4,9 +4,10 @@ Reproduces test_unsupervised.py:35-128 for `network_type: flow` (and test.py:17-
 the YAML into `args`, build `hparams` exactly as the reference does (:44, :52-57), pick the module, fit.  The reference's
 `hparams['using_pretrained_inpainting']` KeyError for `network_type: flow` (:124) is read with `.get(..., False)`.
 `Trainer.fit` is replaced by a plain loop over `TrainStepper` (bf16 autocast, channels_last, optional hipGraph replay, one
-process per GPU under torch.distributed.run); the data module is either the caller's iterable of batches or, with no dataset on
-the box (`root` missing), synthetic Sintel-shaped batches of `image_size` -- the launcher's purpose here is the step loop, the
-checkpoint and the logged scalars, not file I/O (SURVEY 8f-3 lists the real input pipeline as a later row).
+process per GPU under torch.distributed.run).  Data: with `root` pointing at an MPI-Sintel tree, `ocflow_amd.data.datasets.DatasetModule`
+(the reference's lightning_datamodule.py: `dataset_name`, 80/10/10 split with seed 42) in its decode-only mode -- crop, resize,
+normalisation, flow rescaling and occlusion binarisation run batched on the training GPU (`prepare_batch_on_device`); with no dataset on
+the box (`root` missing), synthetic Sintel-shaped batches of `image_size`.
 
     python -m ocflow_amd.train config/unsupervised_config.yml --steps 200 --override network_type=flow model=pwc
 """
@@ -84,10 +85,37 @@ def main(argv=None):
     B = int(args["batch_size"])
     per_rank = max(1, B // env.world_size)
     size = args.get("image_size") or (436, 1024)
+    loader = None
     if args.get("root") and os.path.isdir(str(args["root"])):
-        raise NotImplementedError("dataset readers are not part of this build (SURVEY 8f-3); run without `root` for synthetic batches")
+        # test_unsupervised.py:105-107: DatasetModule(root, image_size, batch_size, dataset_name, overfit) -> prepare_data(); setup()
+        from ocflow_amd.data.datasets import DatasetModule
+        dm = DatasetModule(root=str(args["root"]), image_size=args.get("image_size"), batch_size=per_rank, dataset_name=args.get("dataset_name", "MpiSintelClean"),
+                           num_workers=int(args.get("num_workers", 6)), overfit=bool(args.get("overfit", args.get("overfit_batches", False))), raw=True)
+        dm.prepare_data()
+        dm.setup()
+
+        def batches():
+            epoch = 0
+            while True:
+                n = 0
+                for bi, raw in enumerate(dm.train_dataloader()):
+                    if raw[0].shape[0] != per_rank or bi % env.world_size != env.rank:
+                        continue  # (a fixed-shape graph replays full batches only; ranks take every world_size-th batch of one shuffle)
+                    b = dm.to_device(raw, env.device)
+                    if len(b) == 1:  # image-only datasets: the unsupervised losses need no labels, the step logs against zeros
+                        b = (b[0], torch.zeros((per_rank, 2) + tuple(b[0].shape[2:]), device=env.device))
+                    n += 1
+                    yield stepper.prepare(b)
+                epoch += 1
+                if n == 0:
+                    raise SystemExit(f"dataset under {args['root']} yields no full batch of {per_rank}")
+
+        loader = batches()
     total = a.steps if a.steps is not None else int(args.get("epochs", 1)) * a.steps_per_epoch
-    batch = stepper.prepare(synthetic_batch(per_rank, int(size[0]), int(size[1]), env.device, seed=42, index_offset=env.rank * per_rank))
+    if loader is not None:
+        batch = next(loader)
+    else:
+        batch = stepper.prepare(synthetic_batch(per_rank, int(size[0]), int(size[1]), env.device, seed=42, index_offset=env.rank * per_rank))
     loss = stepper.step(batch, 0)
     if a.graph:
         stepper.enable_graph(batch)
@@ -95,7 +123,7 @@ def main(argv=None):
     log_every = int(hparams.get("log_every_n_steps", 20))
     t0, history = time.perf_counter(), []
     for i in range(1, total):
-        loss = stepper.step(batch, i)
+        loss = stepper.step(next(loader) if loader is not None else batch, i)
         if i % log_every == 0 or i == total - 1:
             lv = float(loss)
             history.append({"step": i, "train_loss": lv})

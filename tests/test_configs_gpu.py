@@ -130,3 +130,35 @@ def test_config3_op_chain_at_375x1242(golden):
     assert abs(float(ops.masked_l1(pred.detach().contiguous(memory_format=torch.channels_last), both[:, 0:3], occ)) - float(g["o_loss"])) < 2e-5
     with pytest.raises(RuntimeError, match="no CPU fallback|HIP"):
         ops.masked_l1(pred.detach().cpu(), img1.cpu(), occ.cpu())
+
+
+def test_launcher_trains_from_a_sintel_tree(tmp_path):
+    """`python -m ocflow_amd.train` with `root` set: DatasetModule in decode-only mode (PNG / .flo / occlusion PNG on the host), crop +
+    resize + normalise + flow rescale + binarise on the GPU, the occlusion-aware unsupervised step replayed as a hipGraph over changing
+    batches (the callers and data formats either side of the hot path)"""
+    import yaml
+    from PIL import Image
+    from ocflow_amd import train
+    from ocflow_amd.data import flow_io
+    rs = np.random.RandomState(3)
+    for scene, n in (("alley_1", 6), ("cave_2", 5)):
+        for sub in ("clean", "flow", "occlusions"):
+            (tmp_path / sub / scene).mkdir(parents=True)
+        base = smooth_field((1, 3, 140, 212), seed=len(scene), amp=1.0)[0].transpose(1, 2, 0)
+        for i in range(1, n + 1):
+            img = np.clip((np.roll(base, 2 * i, axis=1) * 0.5 + 0.5) * 255, 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(tmp_path / "clean" / scene / f"frame_{i:04d}.png")
+            if i < n:
+                fl = np.zeros((140, 212, 2), np.float32)
+                fl[..., 0] = 2.0
+                flow_io.save_flow(str(tmp_path / "flow" / scene / f"frame_{i:04d}.flo"), fl)
+                Image.fromarray(((rs.rand(140, 212) < 0.2) * 255).astype(np.uint8)).save(tmp_path / "occlusions" / scene / f"frame_{i:04d}.png")
+    cfg = dict(batch_size=2, dataset_name="MpiSintelCleanFlowOcc", epochs=1, image_size=(64, 128), learning_rate=1e-4, log_every_n_steps=4,
+               model="flownet", network_type="flow", org=False, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0, displacement=4,
+               with_occ=False, occ_aware=True, root=str(tmp_path), num_workers=0)
+    path = tmp_path / "cfg.yml"
+    path.write_text(yaml.dump(cfg))
+    hist = train.main([str(path), "--steps", "13", "--out", str(tmp_path / "out")])
+    assert len(hist) >= 3 and all(np.isfinite(h["train_loss"]) for h in hist)
+    sd = torch.load(tmp_path / "out" / "state_dict.pt")
+    assert any(k.startswith("flow_pred.feature_pyramid_network.") for k in sd)

@@ -497,3 +497,20 @@ def test_split_graphs_over_the_real_rccl_process_group(tmp_path):
     mp.start_processes(_rccl_single_rank_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
     losses = torch.load(tmp_path / "rccl.pt")["losses"]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_graph_env_guard_sees_a_runtime_started_without_torchs_lazy_init():
+    """ADVICE (round 2): `torch.cuda.is_available()` starts the HIP runtime -- which is when DEBUG_CLR_GRAPH_PACKET_CAPTURE is read -- without
+    setting torch's own initialisation flag; an `import ocflow_amd` after it must report that its setting came too late (enable_graph then
+    refuses to capture on the packet path that corrupts gradients), and must not when it comes first."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    late = subprocess.run([sys.executable, "-c", "import torch; torch.cuda.is_available(); assert not torch.cuda.is_initialized(); "
+                           "import ocflow_amd; print(ocflow_amd.GRAPH_ENV_LATE)"], capture_output=True, text=True, env=env, cwd=root)
+    assert late.returncode == 0 and late.stdout.strip().splitlines()[-1] == "True", (late.stdout, late.stderr[-500:])
+    first = subprocess.run([sys.executable, "-c", "import ocflow_amd, torch; torch.cuda.is_available(); print(ocflow_amd.GRAPH_ENV_LATE)"],
+                           capture_output=True, text=True, env=env, cwd=root)
+    assert first.returncode == 0 and first.stdout.strip().splitlines()[-1] == "False", (first.stdout, first.stderr[-500:])
