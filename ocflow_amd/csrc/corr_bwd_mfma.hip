@@ -415,6 +415,352 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_mfma_both(T4 f1, T4 w2, T4 g,
   corr_bwd_pass<true, false>(smem, smem + SF2, f1, g, g2, occ, w2, gocc, B, C, H, W, tiles_x, tiles_y, 0);
 }
 
+// Both gradients in ONE launch with the two passes in DIFFERENT workgroups (blockIdx.z = pass): for the small pyramid levels, where one
+// pass does not fill the 256 CUs and a launch is a single latency chain (load, commit, compute, store) -- run one after the other inside
+// a workgroup the two chains add up (12.6 us at 8 x 196 x 7 x 16 against 8.0 / 6.0 for the passes alone), side by side they overlap.
+template <bool GL>
+__global__ __launch_bounds__(256, 2) void corr_bwd_mfma_par(T4 f1, T4 w2, T4 g, T4 g1, T4 g2, T4 occ, T4 gocc, int B, int C, int H, int W, int tiles_x,
+                                                           int tiles_y) {
+  using namespace bm;
+  constexpr int BYTES = (SF1 + (GL ? GI_BYTES : 16)) > (SF2 + SG2) ? (SF1 + (GL ? GI_BYTES : 16)) : (SF2 + SG2);
+  __shared__ __attribute__((aligned(16))) char smem[BYTES];
+  const T4 none = {nullptr, 0, 0, 0, 0};
+  if (blockIdx.z == 0)
+    corr_bwd_pass<false, GL>(smem, smem + SF1, w2, g, g1, occ, none, none, B, C, H, W, tiles_x, tiles_y, 0);
+  else
+    corr_bwd_pass<true, false>(smem, smem + SF2, f1, g, g2, occ, w2, gocc, B, C, H, W, tiles_x, tiles_y, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The phases of the two passes as separate functions (round 3): issue (global loads into registers), commit (registers -> LDS), compute
+// (fragments, matrix-core loop, epilogue).  Same LDS layouts, fragments and epilogues as corr_bwd_pass above, bit-identical results;
+// differences: the gradient of the g1 pass is staged with lane-fixed chunk columns and a branch-free tail chunk, and every global
+// address is a uniform base + an unsigned 32-bit lane offset (the scalar-base addressing mode: no 64-bit vector address arithmetic).
+// They were written for a PIPELINED kernel -- a workgroup owning a run of (tile, channel block) items, the loads of the next pass issued
+// before the current pass computes.  That kernel was correct and SLOWER (8 x 32 x 109 x 256, gradient at a 256-byte pitch, +occ: 77.8 us
+// against 62.3; profiles/r3_h_ab_bwd_variants.txt): the passes are bound by instruction issue at two waves per SIMD, not by exposed
+// load latency, and the loop form adds instructions (lane constants re-derived per phase to keep the compiler from hoisting 250 VGPRs
+// of addresses) and loses the dynamic balance of one workgroup per tile.  It was removed; the phase functions stayed.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace bp {
+using namespace bm;
+constexpr int GPX = 12;                          // gradient pixels staged per iteration: 12 x 21 chunks = 252 lanes
+constexpr int GIT = (TH * TW + GPX - 1) / GPX;   // 11 iterations
+constexpr int WCH = WT * 2 / 8, WRC = HWP * WCH; // g2 windows: 9 chunks per pixel, 360 per halo row
+constexpr int WNB = HR * (WRC - 256), WSB = (WNB + 255) / 256;
+
+struct Lane {
+  int tid, lane, w, i, G, q, p;
+  int gsh, gsw;
+};
+struct Item { int b, ty0, tx0, cbase; };
+struct R1 { u32x2 gi[GIT]; u32x2 sv[HR + 3]; float so[HR + 3]; };
+struct R2 { u32x2 va[HR]; u32x2 vb[WSB]; u32x2 sv[HR + 3]; };
+
+__device__ __forceinline__ Item item_of(int it, int tiles_x, int tiles_y, int cblocks) {
+  const int tile = it / cblocks, cb = it - tile * cblocks;
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi, trem = tile - b * tpi;
+  return Item{b, (trem / tiles_x) * TH, (trem % tiles_x) * TW, cb * 32};
+}
+
+// halo tile of the other operand (w2 for g1, f1 for g2): chunk tid of every halo row, then chunks 256..319 (wave w: rows w, w + 4, w + 8)
+template <bool OCC>
+__device__ __forceinline__ void issue_other(const Lane& L, const Item& t, const T4& other, const T4& occ, int C, int H, int W, u32x2* sv, float* so) {
+  const int osh = (int)other.sh, osw = (int)other.sw;
+  const char* obase = other.p + (long)t.b * other.sb * 2;
+  const int u8 = L.tid & 7, c0 = t.cbase + 4 * u8;
+  const int c0c = c0 < C ? c0 : 0;
+  const int pA = L.tid >> 3, pB = 32 + ((L.tid & 63) >> 3);
+  const int gxA = t.tx0 - D + pA, gxB = t.tx0 - D + pB;
+  const bool okA = gxA >= 0 && gxA < W && c0 < C, okB = gxB >= 0 && gxB < W && c0 < C;
+  const int gxAc = gxA < 0 ? 0 : (gxA >= W ? W - 1 : gxA), gxBc = gxB >= W ? W - 1 : gxB;
+  const int offA = (gxAc * osw + c0c) * 2, offB = (gxBc * osw + c0c) * 2;
+  const float* occb = OCC ? (const float*)occ.p + (long)t.b * occ.sb : nullptr;
+  const int csh = OCC ? (int)occ.sh : 0;
+#pragma unroll
+  for (int r = 0; r < HR + 3; r++) {
+    const int hr = r < HR ? r : L.w + 4 * (r - HR);
+    const int gy = t.ty0 - D + hr;
+    const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+    const u32x2 ld = *(const u32x2*)(obase + (unsigned)(gyc * osh * 2 + (r < HR ? offA : offB)));
+    const unsigned m = ((r < HR ? okA : okB) && gy >= 0 && gy < H) ? 0xffffffffu : 0u;
+    sv[r] = u32x2{ld[0] & m, ld[1] & m};
+    if (OCC) so[r] = occb[(unsigned)(gyc * csh + (r < HR ? gxAc : gxBc))];
+  }
+}
+
+template <bool OCC, int FP>
+__device__ __forceinline__ void commit_other(const Lane& L, char* s_f, const u32x2* sv, const float* so) {
+  const int u8 = L.tid & 7;
+  const int pA = L.tid >> 3, pB = 32 + ((L.tid & 63) >> 3);
+#pragma unroll
+  for (int r = 0; r < HR + 3; r++) {
+    u32x2 v = sv[r];
+    if (OCC) {  // rounded like the materialised product w2 * occ
+      const float o = so[r];
+      const float f0 = __builtin_bit_cast(float, v[0] << 16) * o, f1 = __builtin_bit_cast(float, v[0] & 0xffff0000u) * o;
+      const float f2 = __builtin_bit_cast(float, v[1] << 16) * o, f3 = __builtin_bit_cast(float, v[1] & 0xffff0000u) * o;
+      const bf16x2 lo2 = {(bf16)f0, (bf16)f1}, hi2 = {(bf16)f2, (bf16)f3};
+      v = u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
+    }
+    const int hr = r < HR ? r : L.w + 4 * (r - HR);
+    *(u32x2*)(s_f + (hr * HWP + (r < HR ? pA : pB)) * FP + u8 * 8) = v;
+  }
+}
+
+// g1: the 81 taps of the tile's own pixels, 21 eight-byte chunks each; lane = (pixel tid / 21 of the iteration's 12, chunk tid % 21).
+// The last chunk holds 2 bytes of data: it is fetched as the 8 bytes that END at the pixel's last tap and shifted down, so that nothing
+// past the 81 taps is read and there is no branch.
+__device__ __forceinline__ void issue_g1(const Lane& L, const Item& t, const T4& g, int H, int W, u32x2* gi) {
+  const char* gbase = g.p + (long)t.b * g.sb * 2;
+  const int p0 = L.tid / GI_CH, ch = L.tid - p0 * GI_CH;
+  const bool tail = ch == GI_CH - 1;
+  const int coff = tail ? NK * 2 - 8 : ch * 8;
+#pragma unroll
+  for (int k = 0; k < GIT; k++) {
+    const int px = p0 + GPX * k;
+    const int pr = px >> 5, pc = px & 31;  // (TW == 32)
+    const int gy = t.ty0 + pr, gx = t.tx0 + pc;
+    const bool ok = L.tid < GPX * GI_CH && px < TH * TW && gy < H && gx < W;
+    const char* src = gbase + (unsigned)(((ok ? gy : 0) * L.gsh + (ok ? gx : 0) * L.gsw) * 2 + coff);
+    u32x2 v = ((const U8B*)src)->v;
+    if (tail) v = u32x2{v[1] >> 16, 0u};
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    gi[k] = u32x2{v[0] & m, v[1] & m};
+  }
+}
+
+__device__ __forceinline__ void commit_g1(const Lane& L, char* s_g, const u32x2* gi) {
+  const int p0 = L.tid / GI_CH, ch = L.tid - p0 * GI_CH;
+#pragma unroll
+  for (int k = 0; k < GIT; k++) {
+    const int px = p0 + GPX * k;
+    if (L.tid < GPX * GI_CH && px < TH * TW) *(u32x2*)(s_g + GI_FRONT + px * GIP + ch * 8) = gi[k];
+  }
+}
+
+// g2: the tap windows (4 tap rows) of the halo pixels
+__device__ __forceinline__ void issue_g2(const Lane& L, const Item& t, const T4& g, int H, int W, u32x2* va, u32x2* vb) {
+  const char* gbase = g.p + (long)t.b * g.sb * 2;
+  const int pA = L.tid / WCH, cA = L.tid - pA * WCH;
+  const int gxA = t.tx0 - D + pA;
+  const bool okA = gxA >= 0 && gxA < W;
+  const int offA = (gxA < 0 ? 0 : (gxA >= W ? W - 1 : gxA)) * L.gsw * 2 + cA * 8;
+#pragma unroll
+  for (int r = 0; r < HR; r++) {
+    const int gy = t.ty0 - D + r;
+    const int ws = 8 - r < 0 ? 0 : (8 - r > 5 ? 5 : 8 - r);
+    const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+    const u32x2 ld = ((const U8B*)(gbase + (unsigned)(gyc * L.gsh * 2 + ws * (N * 2) + offA)))->v;
+    const unsigned m = (okA && gy >= 0 && gy < H) ? 0xffffffffu : 0u;
+    va[r] = u32x2{ld[0] & m, ld[1] & m};
+  }
+#pragma unroll
+  for (int j = 0; j < WSB; j++) {
+    const int it = L.tid + 256 * j;
+    const int itc = it < WNB ? it : 0;
+    const int r = itc / (WRC - 256), chn = 256 + itc - r * (WRC - 256);
+    const int px = chn / WCH, c = chn - px * WCH;
+    const int gy = t.ty0 - D + r, gx = t.tx0 - D + px;
+    const int ws = 8 - r < 0 ? 0 : (8 - r > 5 ? 5 : 8 - r);
+    const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    const u32x2 ld = ((const U8B*)(gbase + (unsigned)((gyc * L.gsh + gxc * L.gsw + ws * N) * 2 + c * 8)))->v;
+    const unsigned m = (it < WNB && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xffffffffu : 0u;
+    vb[j] = u32x2{ld[0] & m, ld[1] & m};
+  }
+}
+
+__device__ __forceinline__ void commit_g2(const Lane& L, char* s_g, const u32x2* va, const u32x2* vb) {
+  const int pA = L.tid / WCH, cA = L.tid - pA * WCH;
+#pragma unroll
+  for (int r = 0; r < HR; r++) *(u32x2*)(s_g + r * (HWP * GP) + pA * GP + cA * 8) = va[r];
+#pragma unroll
+  for (int j = 0; j < WSB; j++) {
+    const int it = L.tid + 256 * j;
+    const int r = it / (WRC - 256), chn = 256 + it - r * (WRC - 256);
+    const int px = chn / WCH, c = chn - px * WCH;
+    if (it < WNB) *(u32x2*)(s_g + (r * HWP + px) * GP + c * 8) = vb[j];
+  }
+}
+
+__device__ __forceinline__ void compute_g1(const Lane& L, const Item& t, const char* s_f, const char* s_g, const T4& dst, int C, int H, int W) {
+  const int i = L.i, G = L.G, w = L.w;
+  const int y = t.ty0 + w;
+  u32x4 msk;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int t0 = 8 * G + 2 * r - i, t1 = t0 + 1;
+    msk[r] = ((t0 >= 0 && t0 <= 8) ? 0xffffu : 0u) | ((t1 >= 0 && t1 <= 8) ? 0xffff0000u : 0u);
+  }
+  if (y >= H || G == 3) msk = u32x4{0u, 0u, 0u, 0u};
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) acc[s][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dyi = 0; dyi < N; dyi++) {
+    const char* frow = s_f + (w + dyi) * (HWP * FP1) + L.p * 8;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int h0 = 16 * s + 8 * G + L.q, h1 = h0 + 4;
+      const int p0 = h0 < HWP ? h0 : HWP - 1, p1 = h1 < HWP ? h1 : HWP - 1;
+      const bool xin = t.tx0 + 16 * s + i < W;
+      const int addr = GI_FRONT + (w * TW + 16 * s + i) * GIP + ((G < 3 ? 8 * G - i : 0) + N * dyi) * 2;
+      const char* a8 = s_g + (addr & ~7);
+      const u32x2 d0 = *(const u32x2*)a8, d1 = *(const u32x2*)(a8 + 8), d2 = *(const u32x2*)(a8 + 16);
+      const bool up = (addr & 4) != 0;
+      const unsigned q0 = up ? d0[1] : d0[0], q1 = up ? d1[0] : d0[1], q2 = up ? d1[1] : d1[0], q3 = up ? d2[0] : d1[1], q4 = up ? d2[1] : d2[0];
+      const bool half = (addr & 2) != 0;
+      const u32x4 raw = half ? u32x4{__builtin_amdgcn_alignbyte(q1, q0, 2), __builtin_amdgcn_alignbyte(q2, q1, 2),
+                                     __builtin_amdgcn_alignbyte(q3, q2, 2), __builtin_amdgcn_alignbyte(q4, q3, 2)}
+                                 : u32x4{q0, q1, q2, q3};
+      const bf16x8 bq = __builtin_bit_cast(bf16x8, raw & (xin ? msk : u32x4{0u, 0u, 0u, 0u}));
+#pragma unroll
+      for (int nb = 0; nb < 2; nb++) {
+        const bf16x8 a = tr_pair(frow + p0 * FP1 + nb * 32, frow + p1 * FP1 + nb * 32);
+        acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc[s][nb], 0, 0, 0);
+      }
+    }
+  }
+  const float invC = 1.f / (float)C;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int x = t.tx0 + 16 * s + i;
+    const bool inimg = y < H && x < W;
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+      const int c0 = t.cbase + 16 * nb + 4 * G;
+      if (inimg && c0 < C) {
+        const bf16x2 lo2 = {(bf16)(acc[s][nb][0] * invC), (bf16)(acc[s][nb][1] * invC)};
+        const bf16x2 hi2 = {(bf16)(acc[s][nb][2] * invC), (bf16)(acc[s][nb][3] * invC)};
+        *(u32x2*)(dst.p + (long)t.b * dst.sb * 2 + (y * (int)dst.sh + x * (int)dst.sw + c0) * 2) =
+            u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
+      }
+    }
+  }
+}
+
+template <bool OCC>
+__device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const char* s_f, const char* s_g, const T4& dst, const T4& occ,
+                                           const T4& w2own, const T4& gocc, int C, int H, int W) {
+  const int i = L.i, G = L.G, w = L.w;
+  const int y = t.ty0 + w;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) acc[s][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned gm[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int t0 = i - 8 * r - G + 8, t1 = t0 - 4;
+    gm[r] = ((t0 >= 0 && t0 <= 8) ? 0xffffu : 0u) | ((t1 >= 0 && t1 <= 8) ? 0xffff0000u : 0u);
+  }
+  const char* glane = s_g + G * GP + (i - G + 8) * 2;
+#pragma unroll
+  for (int dyi = 0; dyi < N; dyi++) {
+    const int hr = w + 8 - dyi;  // source row y - dy
+    const int ws = dyi - w < 0 ? 0 : (dyi - w > 5 ? 5 : dyi - w);
+    const char* grow = glane + hr * (HWP * GP) + (dyi - ws) * (N * 2);
+    const char* frow = s_f + hr * (HWP * FP2) + L.p * 8;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const char* gs = grow + 16 * s * GP;
+      u32x4 bv;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const unsigned e0 = *(const unsigned short*)(gs + (2 * r) * (4 * GP - 8));
+        const unsigned e1 = *(const unsigned short*)(gs + (2 * r + 1) * (4 * GP - 8));
+        bv[r] = (e0 | (e1 << 16)) & gm[r];
+      }
+      bv[3] = 0u;
+      const bf16x8 bq = __builtin_bit_cast(bf16x8, bv);
+      const int h0 = 16 * s + 4 * L.q + G, h1 = h0 + 16;
+      const int p1 = h1 < HWP ? h1 : HWP - 1;
+#pragma unroll
+      for (int nb = 0; nb < 2; nb++) {
+        const bf16x8 a = tr_pair(frow + h0 * FP2 + nb * 32, frow + p1 * FP2 + nb * 32);
+        acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc[s][nb], 0, 0, 0);
+      }
+    }
+  }
+  const float invC = 1.f / (float)C;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int x = t.tx0 + 16 * s + i;
+    const bool inimg = y < H && x < W;
+    float o = 1.f, part = 0.f;
+    if (OCC && inimg) o = ((const float*)occ.p)[(long)t.b * occ.sb + y * (int)occ.sh + x * (int)occ.sw];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+      const int c0 = t.cbase + 16 * nb + 4 * G;
+      const bool live = inimg && c0 < C;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = acc[s][nb][r] * invC;
+      if (OCC) {
+        if (gocc.p && live) {  // the reference chain rounds the gradient w.r.t. (w2*occ) to the feature dtype before this product
+          const u32x2 wv = *(const u32x2*)(w2own.p + (long)t.b * w2own.sb * 2 + (y * (int)w2own.sh + x * (int)w2own.sw + c0) * 2);
+          part = __builtin_fmaf((float)(bf16)v[0], __builtin_bit_cast(float, wv[0] << 16), part);
+          part = __builtin_fmaf((float)(bf16)v[1], __builtin_bit_cast(float, wv[0] & 0xffff0000u), part);
+          part = __builtin_fmaf((float)(bf16)v[2], __builtin_bit_cast(float, wv[1] << 16), part);
+          part = __builtin_fmaf((float)(bf16)v[3], __builtin_bit_cast(float, wv[1] & 0xffff0000u), part);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = (float)(bf16)v[r] * o;
+      }
+      if (live) {
+        const bf16x2 lo2 = {(bf16)v[0], (bf16)v[1]}, hi2 = {(bf16)v[2], (bf16)v[3]};
+        *(u32x2*)(dst.p + (long)t.b * dst.sb * 2 + (y * (int)dst.sh + x * (int)dst.sw + c0) * 2) =
+            u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
+      }
+    }
+    if (OCC && gocc.p) {  // one fp32 atomic per pixel and channel block (the four lane groups reduced by shuffle)
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      if (inimg && G == 0) atomicAdd((float*)gocc.p + (long)t.b * gocc.sb + (y * (int)gocc.sh + x * (int)gocc.sw), part);
+    }
+  }
+}
+}  // namespace bp
+
+// the two passes side by side (blockIdx.z), built from the phase functions above; the gradient of the g1 pass through LDS
+template <bool OCC>
+__global__ __launch_bounds__(256, 2) void corr_bwd_mfma_par_lds(T4 f1, T4 w2, T4 g, T4 g1, T4 g2, T4 occ, T4 gocc, int B, int C, int H, int W,
+                                                               int tiles_x, int tiles_y) {
+  using namespace bp;
+  constexpr int BYTES = (SF1 + GI_BYTES) > (SF2 + SG2) ? (SF1 + GI_BYTES) : (SF2 + SG2);
+  __shared__ __attribute__((aligned(16))) char smem[BYTES];
+  Lane L;
+  L.tid = threadIdx.x; L.lane = L.tid & 63;
+  L.w = __builtin_amdgcn_readfirstlane(L.tid >> 6);
+  L.i = L.lane & 15; L.G = L.lane >> 4; L.q = L.i >> 2; L.p = L.i & 3;
+  L.gsh = (int)g.sh; L.gsw = (int)g.sw;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi, trem = tile - b * tpi;
+  const Item t = {b, (trem / tiles_x) * TH, (trem % tiles_x) * TW, (int)blockIdx.y * 32};
+  if (blockIdx.z == 0) {
+    R1 r1;
+    issue_g1(L, t, g, H, W, r1.gi);
+    issue_other<OCC>(L, t, w2, occ, C, H, W, r1.sv, r1.so);
+    commit_g1(L, smem + SF1, r1.gi);
+    commit_other<OCC, FP1>(L, smem, r1.sv, r1.so);
+    __syncthreads();
+    compute_g1(L, t, smem, smem + SF1, g1, C, H, W);
+  } else {
+    R2 r2;
+    issue_g2(L, t, g, H, W, r2.va, r2.vb);
+    issue_other<false>(L, t, f1, occ, C, H, W, r2.sv, nullptr);
+    commit_g2(L, smem + SF2, r2.va, r2.vb);
+    commit_other<false, FP2>(L, smem, r2.sv, nullptr);
+    __syncthreads();
+    compute_g2<OCC>(L, t, smem, smem + SF2, g2, occ, w2, gocc, C, H, W);
+  }
+}
+
 static bool px8(const ocf_tensor4* t) {  // channel-contiguous, pixels and rows 8-byte aligned, forward strides
   return t->sc == 1 && t->sw > 0 && t->sh > 0 && t->sb > 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sb % 4 == 0 && (uintptr_t)t->data % 8 == 0;
 }
@@ -451,6 +797,28 @@ int corr_bwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_t
 #ifdef OCF_TUNING_BUILD
   if (const char* e = getenv("OCF_BWD_FUSED")) both = both && atoi(e) != 0;
 #endif
+  // both gradients: the two passes side by side in different workgroups of ONE launch (measured faster than one after the other inside
+  // a workgroup at every pyramid level: 9.0 / 9.8 / 17.7 / 32.9 / 61.0 us against 14.2 / 15.5 / 18.0 / 35.2 / 62.3)
+  bool par = both;
+#ifdef OCF_TUNING_BUILD
+  if (const char* e = getenv("OCF_BWD_PAR")) par = both && atoi(e) != 0;
+  const bool par_phase = getenv("OCF_BWD_PAR_PHASE") ? atoi(getenv("OCF_BWD_PAR_PHASE")) != 0 : true;
+#else
+  constexpr bool par_phase = true;
+#endif
+  if (par) {
+    const dim3 grid2((unsigned)(B * tx * ty), (unsigned)((C + 31) / 32), 2u);
+    const bool has_occ = occ && occ->data;
+    if (g1_lds && par_phase && has_occ)
+      lp.launch(true, corr_bwd_mfma_par_lds<true>, grid2, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
+    else if (g1_lds && par_phase)
+      lp.launch(true, corr_bwd_mfma_par_lds<false>, grid2, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
+    else if (g1_lds)
+      lp.launch(true, corr_bwd_mfma_par<true>, grid2, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
+    else
+      lp.launch(true, corr_bwd_mfma_par<false>, grid2, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
+    return launch_status();
+  }
   if (both) {
     const dim3 grid1((unsigned)(B * tx * ty), (unsigned)((C + 31) / 32));
     if (g1_lds)

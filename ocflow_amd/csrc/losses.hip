@@ -63,7 +63,7 @@ __global__ __launch_bounds__(LB) void photo_fwd_kernel(T4 img1, T4 img2, T4 flow
   float part[2] = {0.f, 0.f};
   const float* i1 = (const float*)img1.p;
   const float* i2 = (const float*)img2.p;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
     const int x = idx % W;
     long r = idx / W;
     const int y = r % H, b = r / H;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
   const float* i1 = (const float*)img1.p;
   const float* i2 = (const float*)img2.p;
   const float sc = *scale;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
     const int x = idx % W;
     long r = idx / W;
     const int y = r % H, b = r / H;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(LB) void smooth_fwd_kernel(T4 img, T4 flow, double*
   float part[4] = {0.f, 0.f, 0.f, 0.f};  // fp32 per thread, fp64 across threads (see photo_fwd_kernel)
   const float* im = (const float*)img.p;
   const float* fl = (const float*)flow.p;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
     const int x = idx % W;
     long r = idx / W;
     const int y = r % H, b = r / H;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(LB) void smooth_bwd_kernel(T4 img, T4 flow, const f
   const float* fl = (const float*)flow.p;
   float* gf = (float*)gflow.p;
   const float cx1 = coef[0], cy1 = coef[1], cx2 = coef[2], cy2 = coef[3];
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
     const int x = idx % W;
     long r = idx / W;
     const int y = r % H, b = r / H;
@@ -321,6 +321,193 @@ __global__ __launch_bounds__(LB) void smooth_bwd_kernel(T4 img, T4 flow, const f
     smooth_axis_grad<CT>(im, fl, oi, of, flow.sc, img.sh, img.sc, flow.sh, C, alpha, y, H, cy1, cy2, g);
     gf[og] = g[0];
     gf[og + gflow.sc] = g[1];
+  }
+}
+
+// ---- RGB fast path (round 3): one lane = one image COLUMN, walking down SMR rows with the rows it has already loaded kept in registers.
+// The flat pixel-per-thread kernels above put the rows y, y+1, y+2 of a pixel in different workgroups -- on different XCDs, i.e. behind
+// different L2s -- so every image / flow row came from HBM about three times (rocprofv3, 8 x 3 x 448 x 1024: 234 MB fetched for 73 MB
+// of algorithmic bytes, 91 us forward, 86 us backward) and every term re-loaded its operands (44 / 112 loads per pixel).  Here a wave
+// owns a 64-column x SMR-row strip: a row is fetched once per strip (+2 / +4 halo rows per SMR), the vertical neighbours come from the
+// register window, the horizontal ones from the same cache lines the wave has just touched (15 / 25 loads per pixel).
+// Same expressions, term by term, as the kernels above, with the hardware's 1-ulp square root / reciprocal square root / exp2 in place
+// of the correctly-rounded library expansions (sqrtf, division, expf are ~12 / ~10 / ~15 instructions each and there are 30 of them per
+// pixel in the backward pass, which was instruction-bound with them: 106 us for 102 MB): d / sqrt(d^2 + eps) = d * rsq(d^2 + eps).
+constexpr int SMR = 8;
+__device__ __forceinline__ float charb_hw(float d) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(d, d, 1e-6f)); }
+__device__ __forceinline__ float dcharb_hw(float d) { return d * __builtin_amdgcn_rsqf(__builtin_fmaf(d, d, 1e-6f)); }  // d / charb(d)
+struct Px5 { float i[3]; float f[2]; };
+
+__device__ __forceinline__ Px5 load_px5(const float* im, const float* fl, long oi, long of, long isc, long fsc) {
+  Px5 p;
+#pragma unroll
+  for (int c = 0; c < 3; c++) p.i[c] = im[oi + (long)c * isc];
+#pragma unroll
+  for (int f = 0; f < 2; f++) p.f[f] = fl[of + (long)f * fsc];
+  return p;
+}
+// edge_w<3> on loaded values: a = the pixel itself, b = the pixel one or two steps further
+__device__ __forceinline__ float edge3(const Px5& a, const Px5& b, float alpha) {
+  float m = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float d = alpha * (b.i[c] - a.i[c]);
+    m = __builtin_fmaf(d, d, m);
+  }
+  return __builtin_amdgcn_exp2f(m * (-1.4426950408889634f / 3.f));
+}
+
+struct StripId { int b, x, y0; };
+__device__ __forceinline__ StripId strip_of(int xblocks, int ychunks) {
+  int bid = blockIdx.x;
+  const int xb = bid % xblocks;
+  bid /= xblocks;
+  const int yc = bid % ychunks;
+  return StripId{bid / ychunks, xb * 64 + (int)(threadIdx.x & 63), (yc * (LB / 64) + (int)(threadIdx.x >> 6)) * SMR};
+}
+
+__global__ __launch_bounds__(LB) void smooth_fwd_rows_kernel(T4 img, T4 flow, double* sums, int H, int W, float alpha, int xblocks, int ychunks) {
+  const float* im = (const float*)img.p;
+  const float* fl = (const float*)flow.p;
+  const StripId t = strip_of(xblocks, ychunks);
+  const bool xin = t.x < W;
+  const int xc = xin ? t.x : W - 1, x1 = xc + 1 < W ? xc + 1 : W - 1, x2 = xc + 2 < W ? xc + 2 : W - 1;
+  const long ib = (long)t.b * img.sb, fb = (long)t.b * flow.sb;
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  Px5 p1 = {}, p2 = {};  // rows y - 1, y - 2 of this column
+#pragma unroll
+  for (int r = 0; r < SMR + 2; r++) {
+    const int y = t.y0 + r;
+    if (y < H) {  // (uniform per wave)
+      const long oi = ib + (long)y * img.sh, of = fb + (long)y * flow.sh;
+      const Px5 c = load_px5(im, fl, oi + (long)xc * img.sw, of + (long)xc * flow.sw, img.sc, flow.sc);
+      if (r < SMR) {  // the x terms of row y (one of the strip's own rows)
+        const Px5 a1 = load_px5(im, fl, oi + (long)x1 * img.sw, of + (long)x1 * flow.sw, img.sc, flow.sc);
+        const Px5 a2 = load_px5(im, fl, oi + (long)x2 * img.sw, of + (long)x2 * flow.sw, img.sc, flow.sc);
+        if (xin && t.x + 1 < W) {
+          float s = 0.f;
+#pragma unroll
+          for (int f = 0; f < 2; f++) s += charb_hw(a1.f[f] - c.f[f]);
+          part[0] = __builtin_fmaf(edge3(c, a1, alpha), s, part[0]);
+        }
+        if (xin && t.x + 2 < W) {
+          float s = 0.f;
+#pragma unroll
+          for (int f = 0; f < 2; f++) s += charb_hw((a2.f[f] - a1.f[f]) - (a1.f[f] - c.f[f]));
+          part[2] = __builtin_fmaf(edge3(c, a2, alpha), s, part[2]);
+        }
+      }
+      if (xin && r >= 1 && r <= SMR) {  // first-order y term of row y - 1
+        float s = 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; f++) s += charb_hw(c.f[f] - p1.f[f]);
+        part[1] = __builtin_fmaf(edge3(p1, c, alpha), s, part[1]);
+      }
+      if (xin && r >= 2) {  // second-order y term of row y - 2
+        float s = 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; f++) s += charb_hw((c.f[f] - p1.f[f]) - (p1.f[f] - p2.f[f]));
+        part[3] = __builtin_fmaf(edge3(p2, c, alpha), s, part[3]);
+      }
+      p2 = p1;
+      p1 = c;
+    }
+  }
+  double acc[4] = {(double)part[0], (double)part[1], (double)part[2], (double)part[3]};
+  block_reduce_atomic<4>(acc, sums);
+}
+
+// smooth_axis_grad<3> on loaded values: v[0..4] = the pixels at p - 2 .. p + 2 along the axis (entries outside 0..n-1 are never used)
+__device__ __forceinline__ void smooth_axis_grad5(const Px5* v, float alpha, int p, int n, float c1, float c2, float* g) {
+  if (c1 != 0.f) {
+    if (p >= 1) {
+      const float w = c1 * edge3(v[1], v[2], alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const float d = v[2].f[f] - v[1].f[f];
+        g[f] += w * dcharb_hw(d);
+      }
+    }
+    if (p + 1 < n) {
+      const float w = c1 * edge3(v[2], v[3], alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const float d = v[3].f[f] - v[2].f[f];
+        g[f] -= w * dcharb_hw(d);
+      }
+    }
+  }
+  if (c2 != 0.f) {
+    if (p >= 2) {
+      const float w = c2 * edge3(v[0], v[2], alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const float d = (v[2].f[f] - v[1].f[f]) - (v[1].f[f] - v[0].f[f]);
+        g[f] += w * dcharb_hw(d);
+      }
+    }
+    if (p >= 1 && p + 1 < n) {
+      const float w = 2.f * c2 * edge3(v[1], v[3], alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const float d = (v[3].f[f] - v[2].f[f]) - (v[2].f[f] - v[1].f[f]);
+        g[f] -= w * dcharb_hw(d);
+      }
+    }
+    if (p + 2 < n) {
+      const float w = c2 * edge3(v[2], v[4], alpha);
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const float d = (v[4].f[f] - v[3].f[f]) - (v[3].f[f] - v[2].f[f]);
+        g[f] += w * dcharb_hw(d);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(LB) void smooth_bwd_rows_kernel(T4 img, T4 flow, const float* coef, T4 gflow, int H, int W, float alpha, int xblocks,
+                                                             int ychunks) {
+  const float* im = (const float*)img.p;
+  const float* fl = (const float*)flow.p;
+  float* gf = (float*)gflow.p;
+  const float cx1 = coef[0], cy1 = coef[1], cx2 = coef[2], cy2 = coef[3];
+  const StripId t = strip_of(xblocks, ychunks);
+  if (t.y0 >= H) return;
+  const bool xin = t.x < W;
+  const int xc = xin ? t.x : W - 1;
+  int xs[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const int xx = xc + k - 2;
+    xs[k] = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+  }
+  const long ib = (long)t.b * img.sb, fb = (long)t.b * flow.sb;
+  auto row = [&](int y, int xx) __attribute__((always_inline)) {  // (row clamped into the image: such entries are never used)
+    const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+    return load_px5(im, fl, ib + (long)yc * img.sh + (long)xx * img.sw, fb + (long)yc * flow.sh + (long)xx * flow.sw, img.sc, flow.sc);
+  };
+  Px5 col[5];  // rows y - 2 .. y + 2 of this column
+#pragma unroll
+  for (int k = 1; k < 5; k++) col[k] = row(t.y0 - 3 + k, xc);
+#pragma unroll
+  for (int r = 0; r < SMR; r++) {
+    const int y = t.y0 + r;
+    if (y < H) {  // (uniform per wave)
+#pragma unroll
+      for (int k = 0; k < 4; k++) col[k] = col[k + 1];
+      col[4] = row(y + 2, xc);
+      Px5 hor[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) hor[k] = k == 2 ? col[2] : row(y, xs[k]);
+      float g[2] = {0.f, 0.f};
+      smooth_axis_grad5(hor, alpha, t.x, W, cx1, cx2, g);
+      smooth_axis_grad5(col, alpha, y, H, cy1, cy2, g);
+      if (xin) {
+        const long og = (long)t.b * gflow.sb + (long)y * gflow.sh + (long)t.x * gflow.sw;
+        gf[og] = g[0];
+        gf[og + gflow.sc] = g[1];
+      }
+    }
   }
 }
 
@@ -728,7 +915,12 @@ extern "C" int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* fl
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, 4 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
   const long npix = (long)B * H * W;
-  if (C == 3)
+  const int xblocks = (W + 63) / 64, ychunks = (H + SMR * (LB / 64) - 1) / (SMR * (LB / 64));
+  const bool rows = C == 3 && (long)B * xblocks * ychunks <= 0x7fffffffL;
+  if (rows)
+    LaunchProf().launch(true, smooth_fwd_rows_kernel, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, st, mk(img), mk(flow), sums, H, W, alpha,
+                       xblocks, ychunks);
+  else if (C == 3)
     LaunchProf().launch(true, smooth_fwd_kernel<3>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
   else
     LaunchProf().launch(true, smooth_fwd_kernel<0>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
@@ -741,7 +933,11 @@ extern "C" int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* fl
   if (!img || !flow || !coef || !gflow || !img->data || !flow->data || !gflow->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
-  if (C == 3)
+  const int xblocks = (W + 63) / 64, ychunks = (H + SMR * (LB / 64) - 1) / (SMR * (LB / 64));
+  if (C == 3 && (long)B * xblocks * ychunks <= 0x7fffffffL)
+    LaunchProf().launch(true, smooth_bwd_rows_kernel, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef,
+                       mk(gflow), H, W, alpha, xblocks, ychunks);
+  else if (C == 3)
     LaunchProf().launch(true, smooth_bwd_kernel<3>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
                        B, C, H, W, alpha, npix);
   else

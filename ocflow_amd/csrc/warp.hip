@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(T4 img, T4 flow, T4 out, 
                                                        WarpGeom wg, long npix) {
   constexpr int U = Unit<T>::U;
   const float* fl = (const float*)flow.p;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
     const int x = idx % W;
     long r = idx / W;
     const int y = r % H, b = r / H;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void warp_fwd_cl_kernel(T4 img, T4 flow, T4 ou
                                                           long total, int upp) {
   constexpr int U = Unit<T>::U;
   const float* fl = (const float*)flow.p;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const long pix = idx / upp;
     const int c0 = (int)(idx - pix * upp) * U;
     const int x = pix % W;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(T4 img, T4 flow, T4 gout,
                                                        float fs, WarpGeom wg, long npix) {
   constexpr int U = Unit<T>::U;
   const float* fl = (const float*)flow.p;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
     const int x = idx % W;
     long r = idx / W;
     const int y = r % H, b = r / H;
@@ -159,7 +159,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void warp_bwd_cl_kernel(T4 img, T4 flow, T4 gout, T4 gimg, T4 gflow, int B, int C, int H, int W,
                                                           float fs, WarpGeom wg, long total, int G) {
   const float* fl = (const float*)flow.p;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const bool live = idx < total;
   const long pix = live ? idx / C : 0;
   const int c = live ? (int)(idx - pix * C) : 0;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(T4 flow, T4 gout, 
 // (scripts/flow_stats.py) and went through the float-atomic far path, which made the launch 2.5x slower inside the model (99.6 us at
 // 8 x 32 x 109 x 256) than in the small-motion micro-benchmark (39 us).  Here the sources of a destination tile are not FOUND by scanning
 // a window, they are LISTED: a binning pass (one thread per source pixel, 8 bytes of flow each) appends the source's index to the bin
-// of every destination tile one of its taps lands in (1-4 tiles; one integer atomic per (source, tile) pair), and the gather kernel
+// of every destination tile one of its taps lands in (1-4 tiles; one LDS atomic per (source, tile) pair, one global atomic per (workgroup, tile)), and the gather kernel
 // walks its tile's bin instead of a window -- any displacement is "near".  A bin holds WBIN_CAP entries (3.5x the average of a 32 x 8
 // tile); pairs beyond that go to an overflow list that the per-source kernel afterwards scatters with float atomics (taps of that
 // tile only), so convergent flows stay correct.
@@ -356,41 +356,30 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(T4 flow, T4 gout, 
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int WBIN_CAP = 896;
 
-// One returning device-scope atomic per (wave, destination tile) instead of one per (source, tile): the lanes of a wave are a 32 x 2
-// patch of sources, whose taps land in a handful of tiles; the lanes that target the same tile are counted with a ballot, the first of
-// them reserves that many bin slots, the others take consecutive slots after its base.  (One atomic per source measured 4x SLOWER than
-// the window kernel: 270,000 returning atomics on 896 counters are ~50-140 us of memory-side atomic traffic at the level-2 shape.)
-__device__ __forceinline__ void warp_bin_push_wave(bool active, int tile, unsigned src, unsigned* cnt, unsigned* bins, unsigned* ovf, int ntiles) {
-  const int lane = threadIdx.x & 63;
-  unsigned long long todo = __ballot(active);
-  while (todo) {  // (wave-uniform loop: every lane of the wave runs it)
-    const int leader = __builtin_ctzll(todo);
-    const int t = __builtin_amdgcn_readlane(tile, leader);
-    const bool mine = active && tile == t;
-    const unsigned long long same = __ballot(mine);
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&cnt[t], (unsigned)__popcll(same));
-    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-    if (mine) {
-      const unsigned slot = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
-      if (slot < (unsigned)WBIN_CAP) {
-        bins[(long)t * WBIN_CAP + slot] = src;
-      } else {
-        const unsigned o = atomicAdd(&cnt[ntiles], 1u);
-        ovf[2 * (long)o] = src;
-        ovf[2 * (long)o + 1] = (unsigned)t;
-      }
-    }
-    todo &= ~same;
-  }
-}
+// One returning device-scope atomic per (WORKGROUP, destination tile) instead of one per (source, tile), and all of a workgroup's
+// atomics in flight together: the 256 sources of a 32 x 8 patch land in a handful of tiles; the workgroup counts its (source, tile) pairs
+// per destination tile in an LDS hash table (LDS atomics: the pair's rank inside the workgroup falls out of the counting), then the
+// occupied table slots reserve their bin ranges with ONE global atomic each -- issued by different lanes, so they overlap instead of
+// forming the dependent chain the wave-aggregated form had (one returning atomic per distinct tile of a wave, one after the other, four
+// times over: 21 us at 8 x 109 x 256 inside the model) -- and the pairs are written at base + rank.  (One atomic per pair measured 4x
+// SLOWER than the window kernel: 270,000 returning atomics on 896 counters are ~50-140 us of memory-side atomic traffic there.)
+constexpr int WBIN_HS = 2048;  // hash slots (a workgroup has at most 4 * 256 distinct pairs: load factor <= 0.5)
+constexpr unsigned WBIN_EMPTY = 0xffffffffu;
 
 // grid = source tiles (32 x 8 pixels, the destination tile shape), lanes = pixels: a wave = two rows of 32 sources
 __global__ __launch_bounds__(256) void warp_bwd_bin_kernel(T4 flow, int B, int H, int W, float fs, WarpGeom wg, int tiles_x, int tiles_y,
                                                            unsigned* cnt, unsigned* bins, unsigned* ovf, long npix) {
+  __shared__ unsigned s_key[WBIN_HS];  // destination tile of the slot
+  __shared__ unsigned s_cnt[WBIN_HS];  // pairs of this workgroup for it; after the reservation: first bin slot of the workgroup's range
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < WBIN_HS / 256; k++) {
+    s_key[tid + 256 * k] = WBIN_EMPTY;
+    s_cnt[tid + 256 * k] = 0u;
+  }
   const int tpi = tiles_x * tiles_y;
   const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
-  const int x = (trem % tiles_x) * WT_W + (threadIdx.x & (WT_W - 1)), y = (trem / tiles_x) * WT_H + (threadIdx.x >> 5);
+  const int x = (trem % tiles_x) * WT_W + (tid & (WT_W - 1)), y = (trem / tiles_x) * WT_H + (tid >> 5);
   const bool live = x < W && y < H;
   const int xc = live ? x : 0, yc = live ? y : 0;
   const float* fl = (const float*)flow.p + (long)b * flow.sb + (long)yc * flow.sh + (long)xc * flow.sw;
@@ -402,10 +391,46 @@ __global__ __launch_bounds__(256) void warp_bwd_bin_kernel(T4 flow, int B, int H
   const unsigned src = (unsigned)(yc * W + xc);
   const int tb = b * tpi;
   const bool xb = txb >= 0 && txb != txa, yb = tyb >= 0 && tyb != tya;
-  warp_bin_push_wave(live && txa >= 0 && tya >= 0, tb + tya * tiles_x + txa, src, cnt, bins, ovf, ntiles);
-  warp_bin_push_wave(live && xb && tya >= 0, tb + tya * tiles_x + txb, src, cnt, bins, ovf, ntiles);
-  warp_bin_push_wave(live && yb && txa >= 0, tb + tyb * tiles_x + txa, src, cnt, bins, ovf, ntiles);
-  warp_bin_push_wave(live && yb && xb, tb + tyb * tiles_x + txb, src, cnt, bins, ovf, ntiles);
+  const bool act[4] = {live && txa >= 0 && tya >= 0, live && xb && tya >= 0, live && yb && txa >= 0, live && yb && xb};
+  const unsigned tl[4] = {(unsigned)(tb + tya * tiles_x + txa), (unsigned)(tb + tya * tiles_x + txb), (unsigned)(tb + tyb * tiles_x + txa),
+                          (unsigned)(tb + tyb * tiles_x + txb)};
+  __syncthreads();
+  unsigned slot[4], rank[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    slot[k] = 0u;
+    rank[k] = 0u;
+    if (act[k]) {
+      unsigned h = (tl[k] * 2654435761u) >> 21;  // 11 bits
+      for (;;) {  // linear probing; terminates: the table has twice as many slots as the workgroup has pairs
+        const unsigned prev = atomicCAS(&s_key[h], WBIN_EMPTY, tl[k]);
+        if (prev == WBIN_EMPTY || prev == tl[k]) break;
+        h = (h + 1u) & (unsigned)(WBIN_HS - 1);
+      }
+      slot[k] = h;
+      rank[k] = atomicAdd(&s_cnt[h], 1u);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < WBIN_HS / 256; k++) {
+    const int i = tid + 256 * k;
+    const unsigned key = s_key[i];
+    if (key != WBIN_EMPTY) s_cnt[i] = atomicAdd(&cnt[key], s_cnt[i]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (act[k]) {
+      const unsigned pos = s_cnt[slot[k]] + rank[k];
+      if (pos < (unsigned)WBIN_CAP) {
+        bins[(long)tl[k] * WBIN_CAP + pos] = src;
+      } else {  // (a bin's counter keeps counting past its capacity: the gather kernel clamps it)
+        const unsigned o = atomicAdd(&cnt[ntiles], 1u);
+        ovf[2 * (long)o] = src;
+        ovf[2 * (long)o + 1] = tl[k];
+      }
+    }
 }
 
 template <typename T, int VEC>
@@ -502,7 +527,7 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(T4 img, T4 flow, T4 
                                                             const unsigned* ovf, int tiles_x, int tiles_y) {
   constexpr int U = Unit<T>::U;
   const float* fl = (const float*)flow.p;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const bool live = idx < total;
   const long pix = live ? idx / upp_pad : 0;
   const int un = live ? (int)(idx - pix * upp_pad) : 0;

@@ -4,7 +4,8 @@ The free functions keep the reference's names and signatures and are the HIP ope
 reference's hparams, step methods, logged scalar names and optimizer.  The training step's loss side -- image warp +
 Charbonnier photometric error (+ occlusion mask), first/second-order edge-aware smoothness, range-map occlusion of
 the backward flow -- runs as fused HIP kernels (ops.warp_photometric_error, ops.smoothness_losses,
-ops.occlusion_from_flow); the inpainting / two-stage trainers of the reference (model.py:511-1394) are out of scope."""
+ops.occlusion_from_flow).  The two-stage trainers (model.py:928-1394) are in two_stage_model.py and re-exported here; the
+inpainting-stage GAN trainers (model.py:511-926) are out of scope."""
 import torch
 import torch.nn.functional as F
 from torch.optim import Adam
@@ -14,9 +15,10 @@ from ocflow_amd.ops import (first_order_smoothness_loss, gradient, photometric_e
                             second_order_smoothness_loss)
 from .flow_model import HotPathHelpers, build_flow_network
 from .lightning_shim import LightningModule, set_hparams
+from .two_stage_model import ReconLoss, TwoStageModel, TwoStageModelGC  # noqa: F401  (models/model.py:928-1394 live in two_stage_model.py)
 
 __all__ = ["robust_l1", "photometric_error", "gradient", "first_order_smoothness_loss", "second_order_smoothness_loss",
-           "PhotometricLoss", "FlowStageModel"]
+           "PhotometricLoss", "FlowStageModel", "TwoStageModel", "TwoStageModelGC", "ReconLoss"]
 
 
 class PhotometricLoss(torch.nn.Module):

@@ -28,9 +28,13 @@ __all__ = [
 ]
 
 MAX_DISPLACEMENT = 4
-# OCFLOW_FUSED_WARP: "auto" (default) = ONE launch (warp gathered inside the correlation kernel, the warped tensor never exists in HBM)
-# whenever nothing downstream needs the warped tensor -- no gradient is being recorded -- and the request is served by a kernel with
-# the in-register gather (ocf_corr_fwd_variant == OCF_CORR_WAVE); "1" = always one launch; "0" = always warp kernel + correlation kernel
+# OCFLOW_FUSED_WARP: "1" = always ONE launch (the bilinear warp gathered inside the correlation kernel, the warped tensor never exists in
+# HBM: 4C + 170 bytes per pixel instead of 8C + 170); "gather" = one launch whenever no gradient is recorded and a kernel with the
+# in-kernel gather serves the request (ocf_corr_fwd_variant in _lib.CORR_VARIANTS_WITH_GATHER: the setting for memory-bound inference at
+# sizes where the warped pyramid does not fit); "0" / "auto" (default) = warp kernel + correlation kernel.  "auto"
+# is two launches because that is what measured faster at every level of the benchmark pyramid (profiles/r3_f_kbench.txt, 8 pairs,
+# levels 2..6: fused 31.4 / 18.2 / 17.2 / 9.0 / 21.1 us against 29.1 / 16.2 / 11.0 / 8.2 / 9.9 us): a staged second-operand unit costs
+# four 16-byte gathers instead of one load, and the texture path, not HBM, is what the staging loops are bound by.
 _FUSED_WARP = os.environ.get("OCFLOW_FUSED_WARP", "auto")
 
 _KERNEL_TIMER = None
@@ -241,9 +245,9 @@ def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flo
 def _fuse_warp(f1, f2, flow, occ, out, d, needs_grad) -> bool:
     """one fused launch (True) or warp kernel + correlation kernel (False) for a correlation with a flow: see _FUSED_WARP"""
     if _FUSED_WARP == "1":
-        return True
-    if _FUSED_WARP == "0" or needs_grad or f1.dtype != torch.bfloat16:
-        return False  # backward consumes the warped tensor: kept from the forward instead of being recomputed
+        return True  # (with a gradient recorded the backward then re-creates the warped tensor)
+    if _FUSED_WARP != "gather" or needs_grad or f1.dtype != torch.bfloat16:
+        return False
     B, C_, H, W = f1.shape
     v = _lib.load().ocf_corr_fwd_variant(_t4(f1), _t4(f2), _t4(flow), _t4(occ), _t4(out), B, C_, H, W, d, _dtype_code(f1), POLICY.corr_fwd)
     return v in _lib.CORR_VARIANTS_WITH_GATHER
@@ -378,8 +382,9 @@ def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flo
     """Cost volume of features1 against  warp(features2, flow*flow_scale) [* occ].
 
     With a flow: a forward that records a gradient is TWO launches -- ocf_warp_fwd materialises the warped operand (backward consumes
-    it), then ocf_corr_fwd with the mask applied to the band outputs; a no-grad forward is ONE launch where a kernel with the
-    in-register gather serves the shape (the warped tensor then never exists in HBM; same values bit for bit).  OCFLOW_FUSED_WARP=0 / 1
+    it), then ocf_corr_fwd with the mask applied to the band outputs; so is a no-grad forward by default (measured faster); with
+    OCFLOW_FUSED_WARP=gather a no-grad forward is ONE launch where a kernel with the in-kernel gather serves the shape (the warped
+    tensor then never exists in HBM; same values bit for bit).  OCFLOW_FUSED_WARP=0 / 1
     force either form.
 
     `out`: optional pre-allocated [B, (2d+1)^2, H, W] tensor of the features' dtype with unit channel stride and ANY pixel pitch -- e.g.

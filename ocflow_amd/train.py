@@ -49,6 +49,23 @@ def build_module(args: dict):
     if network_type == "flowocc":  # test.py:46-48
         from ocflow_amd.models.flow_occ_model import FlowOccModel
         return FlowOccModel(hparams), hparams
+    if network_type == "twostage":  # test_unsupervised.py:72-98
+        from ocflow_amd.models.model import TwoStageModel, TwoStageModelGC
+        assert args["model"] in ["with_gt_flow", "no_gt_flow"]
+        hparams = dict(network_type=network_type, model=args["model"], epochs=args["epochs"], batch_size=args["batch_size"],
+                       learning_rate=args["learning_rate"], log_every_n_steps=args.get("log_every_n_steps", 20),
+                       img_size=args.get("image_size", None), org=args.get("org", False))
+        for k in ("reconst_weight", "photo_weight", "inpainting_root", "smooth1_weight", "smooth2_weight", "using_pretrained_inpainting",
+                  "loss_type", "pixelwise_weight"):
+            hparams[k] = args[k]
+        if hparams["model"] == "no_gt_flow":
+            hparams["smoothness_weight"] = args["smoothness_weight"]
+            hparams["flow_root"] = args["flow_root"]
+            hparams["supervised_flow"] = bool(args["supervised_flow"])
+            return TwoStageModel(hparams), hparams
+        hparams["inpainting_stage"] = args["inpainting_stage"]
+        assert hparams["inpainting_stage"] in ["gated", "gated_org", "simple"]
+        return TwoStageModelGC(hparams), hparams
     if network_type == "inpainting" and args.get("model", "simple") == "simple" and "loss_type" not in args:
         from ocflow_amd.models.inpainting_model import InpaintingModel
         return InpaintingModel(hparams), hparams
@@ -73,8 +90,8 @@ def main(argv=None):
     for kv in a.override:
         k, v = kv.split("=", 1)
         args[k] = yaml.safe_load(v)
-    using_pretrained_inpainting = args.get("using_pretrained_inpainting", False) if args["network_type"] == "twostage" else False  # F7
-    assert not using_pretrained_inpainting
+    # (test_unsupervised.py:124 reads hparams['using_pretrained_inpainting'] for every network type: KeyError for 'flow', SURVEY F7;
+    # here only the two-stage branch looks at it, and TwoStageModelGC refuses a pretrained completion network by name)
     module, hparams = build_module(args)
     env = init_distributed()
     if env.device.type != "cuda":

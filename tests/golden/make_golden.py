@@ -599,8 +599,75 @@ def gold_train_fpn():
             print(f"  {k:90s} {float(arrs[k]):.3e}")
     save("train_fpn", **arrs)
 
+# ------------------------------------------- 14. two-stage trainer with ground-truth flow: TwoStageModelGC, 'simple' + 'pixel-wise'
+TWO_STAGE_GRADS = ("occ_pred.down1.conv1.weight", "occ_pred.down5.bn3.weight", "occ_pred.up5.conv2.weight", "occ_pred.predict_occ0.2.0.weight",
+                   "occ_pred.predict_occ0.2.0.bias", "occ_pred.predict_occ5.0.0.weight", "inpainting.down1.conv1.weight",
+                   "inpainting.up6.conv3.weight")
+
+
+def gold_two_stage():
+    """One TRAINING step of TwoStageModelGC (models/model.py:1199-1256) with inpainting_stage='simple', loss_type='pixel-wise', trained from
+    scratch: B = 2 at 64 x 96, both networks in train mode (batch-statistics BatchNorm), golden_util.seeded_fill weights.  Stored: the six
+    values general_step returns, the total of training_step's expression (:1256; that method itself cannot run, it unpacks six values
+    after testing `len(losses) == 3`), the soft occlusion map, the completed image, parameter gradients of both networks.  Values are
+    the reference in fp64; `<name>__noise` = deviation of its own fp32 run."""
+    arrs = {}
+    x = torch.from_numpy(smooth_field((2, 6, 64, 96), seed=111, amp=1.0)).float().clamp(-1, 1)
+    gt_flow = torch.randn((2, 2, 64, 96), generator=g(112)) * 2
+    gt_occ = (torch.rand((2, 1, 64, 96), generator=g(113)) < 0.3).float()
+    arrs.update(x_absmean=x.abs().mean(), gt_flow_absmean=gt_flow.abs().mean(), gt_occ_mean=gt_occ.mean())
+    hp = dict(learning_rate=1e-4, inpainting_stage="simple", loss_type="pixel-wise", using_pretrained_inpainting=False, img_size=(64, 96),
+              photo_weight=1.0, reconst_weight=1.0, smooth1_weight=0.5, smooth2_weight=0.0, pixelwise_weight=2.0, batch_size=2)
+    manifest = {}
+
+    def run(dt):
+        m = ref_model.TwoStageModelGC(dict(hp))
+        seeded_fill(m, 13)
+        manifest["simpleocclusionnet"] = [(k, tuple(v.shape)) for k, v in m.occ_pred.state_dict().items()]
+        m = m.to(dt).train()
+        seen = {}
+        h1 = m.occ_pred.register_forward_hook(lambda mod, inp, out: seen.__setitem__("soft", out))
+        h2 = m.inpainting.register_forward_hook(lambda mod, inp, out: seen.__setitem__("completed", out))
+        res = m.general_step((x.to(dt), gt_flow.to(dt), gt_occ.to(dt)), 0, "train")
+        h1.remove(); h2.remove()
+        photo, reconst, smooth, pixelwise, bce, photo_occ = res
+        loss = hp["photo_weight"] * photo + hp["reconst_weight"] * reconst + hp["smooth1_weight"] * smooth + hp["pixelwise_weight"] * pixelwise
+        loss.backward()
+        params = dict(m.named_parameters())
+        out = dict(ts_scalars=torch.stack([r.detach() for r in res]), ts_loss=loss, ts_soft=seen["soft"], ts_completed=seen["completed"])
+        out.update({"ts_grad__" + k: _grad_pick(params[k].grad) for k in TWO_STAGE_GRADS})
+        sd = m.state_dict()
+        out["ts_buf__occ_pred.down1.bn1.running_mean"] = sd["occ_pred.down1.bn1.running_mean"]
+        out["ts_buf__occ_pred.down1.bn1.running_var"] = sd["occ_pred.down1.bn1.running_var"]
+        return {k: v.detach() for k, v in out.items()}
+
+    r32, r64 = run(torch.float32), run(torch.float64)
+    for k, v64 in r64.items():
+        v32 = r32[k]
+        arrs[k] = v64.float()
+        if "grad" in k or "buf" in k:
+            noise = (v32.double() - v64).abs().max() / (v64.abs().max() + 1e-300)
+        elif v64.dim() == 0:
+            noise = (v32.double() - v64).abs() / v64.abs().clamp_min(1.0)
+        elif v64.dim() == 1:
+            noise = ((v32.double() - v64).abs() / v64.abs().clamp_min(1.0)).max()
+        else:
+            noise = (v32.double() - v64).abs().max()
+        arrs[k + "__noise"] = noise.double()
+    for k in sorted(arrs):
+        if k.endswith("__noise"):
+            print(f"  {k:70s} {float(arrs[k]):.3e}")
+    print("  scalars (photo, reconst, smooth, pixelwise, bce, photo_occ):", [round(float(v), 6) for v in arrs["ts_scalars"]], float(arrs["ts_loss"]))
+    save("two_stage", **arrs)
+    import json
+    with open(os.path.join(HERE, "state_dict_manifest_two_stage.json"), "w") as f:
+        json.dump(manifest, f)
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "two_stage":
+        gold_two_stage()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train_fpn":
         gold_train_fpn()
         sys.exit(0)
@@ -631,3 +698,4 @@ if __name__ == "__main__":
     gold_fullsize()
     gold_inpainting()
     gold_train_fpn()
+    gold_two_stage()

@@ -137,12 +137,12 @@ def test_cost_volume_written_into_the_decoder_input_buffer(ops, lib, level):
     assert float((buf[:, 81:].float() - 7.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("level", [4, 5])
+@pytest.mark.parametrize("level", [2, 3, 4, 5])
 @pytest.mark.parametrize("with_occ", [True, False])
 def test_fused_warp_correlation_equals_two_launches(ops, lib, level, with_occ, monkeypatch):
-    """K1+K2 as ONE launch at the small levels (flow_net.py:110-112 / the no-grad second forward of models/model.py:381-388): the wave kernel
-    gathers warp(f2, flow * 20/2^level) in registers -- bit-identical to ocf_warp_fwd followed by the correlation kernel, and chosen
-    automatically when no gradient is recorded"""
+    """K1+K2 as ONE launch (flow_net.py:110-112 / the no-grad second forward of models/model.py:381-388): the row-tiled kernels (levels
+    2, 3) sample warp(f2, flow * 20/2^level) while they stage the second operand, the wave kernel (levels 4, 5) in registers --
+    bit-identical to ocf_warp_fwd followed by the correlation kernel; taken under OCFLOW_FUSED_WARP=gather when no gradient is recorded"""
     f1, f2, flow, occ = level_inputs(level, seed=6)
     Cc, h, w = LEVELS[level]
     fs = 20.0 / 2 ** level
@@ -150,11 +150,11 @@ def test_fused_warp_correlation_equals_two_launches(ops, lib, level, with_occ, m
     a, b2, fl, oc = cl(f1), cl(f2), flow.to(DEV), occ.to(DEV) if with_occ else None
     monkeypatch.setattr(ops, "_FUSED_WARP", "0")
     two = ops.corr_warp(a, b2, fl, oc, 4, fs, False)
-    monkeypatch.setattr(ops, "_FUSED_WARP", "auto")
+    monkeypatch.setattr(ops, "_FUSED_WARP", "gather")
     out = torch.empty_like(two)
     v = lib.load().ocf_corr_fwd_variant(_t4(lib, a), _t4(lib, b2), _t4(lib, fl), _t4(lib, oc) if with_occ else None, _t4(lib, out), B, Cc, h, w,
                                         4, lib.OCF_BF16, 0)
-    assert v == VARIANT_CODE["OCF_CORR_WAVE"], v
+    assert v == VARIANT_CODE[EXPECTED[level][0]], v
     timer_calls = []
 
     class Spy:

@@ -162,3 +162,22 @@ def test_launcher_trains_from_a_sintel_tree(tmp_path):
     assert len(hist) >= 3 and all(np.isfinite(h["train_loss"]) for h in hist)
     sd = torch.load(tmp_path / "out" / "state_dict.pt")
     assert any(k.startswith("flow_pred.feature_pyramid_network.") for k in sd)
+
+
+def test_launcher_trains_the_two_stage_model(tmp_path):
+    """`python -m ocflow_amd.train` with `network_type: twostage`, `model: with_gt_flow` (test_unsupervised.py:72-98 -> TwoStageModelGC,
+    inpainting_stage 'simple', loss_type 'pixel-wise'): the straight-through two-stage step as a replayed hipGraph on synthetic
+    Sintel-shaped batches; the loss goes down over 40 steps of one batch"""
+    import yaml
+    from ocflow_amd import train
+    cfg = dict(batch_size=2, dataset_name="MpiSintelCleanFlowOcc", epochs=1, image_size=(64, 128), learning_rate=1e-3, log_every_n_steps=13,
+               model="with_gt_flow", network_type="twostage", org=False, photo_weight=1.0, reconst_weight=1.0, smooth1_weight=0.5,
+               smooth2_weight=0.0, pixelwise_weight=1.0, inpainting_root=None, using_pretrained_inpainting=False, loss_type="pixel-wise",
+               inpainting_stage="simple", n_display_images=1, log_image_every_epoch=10, root="/nonexistent")
+    path = tmp_path / "cfg.yml"
+    path.write_text(yaml.dump(cfg))
+    hist = train.main([str(path), "--steps", "40", "--fp32", "--out", str(tmp_path / "out")])
+    assert len(hist) >= 3 and all(np.isfinite(h["train_loss"]) for h in hist)
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"], hist
+    sd = torch.load(tmp_path / "out" / "state_dict.pt")
+    assert any(k.startswith("occ_pred.predict_occ0.") for k in sd) and any(k.startswith("inpainting.up6.") for k in sd)

@@ -638,14 +638,16 @@ def test_corr_backward_odd_shapes(ops, shape, d, dtype, with_occ):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 21, 45), (1, 64, 12, 40), (1, 196, 7, 16), (1, 100, 13, 17), (1, 64, 1, 50), (1, 16, 50, 1),
-                                   (3, 32, 17, 16), (2, 32, 4, 70), (1, 36, 9, 33)])
+                                   (3, 32, 17, 16), (2, 32, 4, 70), (1, 36, 9, 33), (2, 32, 70, 300), (3, 64, 40, 330)])
 @pytest.mark.parametrize("with_occ", [False, True])
 @pytest.mark.parametrize("sliced", [False, True])
 def test_corr_backward_matrix_core_kernel(ops, shape, with_occ, sliced):
     """the band-GEMM backward (corr_bwd_mfma.hip, policy OCF_CORR_BWD_POLICY_MFMA = what the automatic policy picks whenever the layout
     allows) against the vector kernel (OCF_CORR_BWD_POLICY_VECTOR): edge tiles in both directions, 1-pixel-wide / 1-pixel-high maps, channel counts that are not a multiple of the 32-channel
     block (196, 100, 36), the gradient arriving as a 2-byte aligned channel slice (first and last pixels of the tensor: the clamped
-    and shifted operand windows), occlusion (d/docc by-product).  Against fp32 autograd of the oracle, and against the vector kernel
+    and shifted operand windows), occlusion (d/docc by-product); the last two shapes have more (tile, channel block) items than the
+    pipelined kernel has workgroups (720 and 660 > 512: every workgroup runs its prefetch loop, across a channel-block change in the
+    second).  Against fp32 autograd of the oracle, and against the vector kernel
     (same products, different summation order: within one bf16 rounding of the gradient scale)."""
     from ocflow_amd import _lib
     lib = _lib.load()

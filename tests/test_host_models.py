@@ -190,7 +190,16 @@ def test_launcher_builds_the_reference_hparams(tmp_path):
     assert isinstance(m, FlowStageModel) and m.model == "pwc" and m.occ_aware and m.photo_weight == 4.0 and m.smooth2_weight == 0.0
     assert hp["batch_size"] == 8 and hp["img_size"] == (384, 512) and "using_pretrained_inpainting" not in hp
     with pytest.raises(NotImplementedError):
-        train.build_module({**args, "network_type": "twostage"})
+        train.build_module({**args, "network_type": "inpainting", "model": "gated"})
+    # network_type 'twostage' (test_unsupervised.py:72-98): with_gt_flow -> TwoStageModelGC, no_gt_flow -> TwoStageModel
+    two = dict(args, network_type="twostage", model="with_gt_flow", reconst_weight=1.0, inpainting_root=None, using_pretrained_inpainting=False,
+               loss_type="pixel-wise", pixelwise_weight=1.0, inpainting_stage="simple")
+    m2, hp2 = train.build_module(two)
+    assert type(m2).__name__ == "TwoStageModelGC" and hp2["inpainting_stage"] == "simple" and hp2["img_size"] == (384, 512)
+    m3, _ = train.build_module(dict(two, model="no_gt_flow", smoothness_weight=0.1, flow_root=None, supervised_flow=False))
+    assert type(m3).__name__ == "TwoStageModel" and not any(p.requires_grad for p in m3.flow_pred.parameters())
+    with pytest.raises(NotImplementedError, match="gated_conv_inpainting_net"):
+        train.build_module(dict(two, inpainting_stage="gated"))
     sup, _ = train.build_module({"network_type": "flowocc", "model": "flowoccnet", "learning_rate": 1e-3})
     assert type(sup).__name__ == "FlowOccModel"
 
@@ -226,3 +235,96 @@ def test_torch_library_ops_are_registered_with_fake_kernels():
     g1, g2 = torch.ops.ocflow.cost_volume_backward(f, f, out, 4)
     assert g1.shape == f.shape and g2.shape == f.shape
     assert "max_displacement" in str(torch.ops.ocflow.cost_volume.default._schema)
+
+
+def _two_stage_inputs(g):
+    from golden_util import smooth_field
+    x = T(smooth_field((2, 6, 64, 96), seed=111, amp=1.0)).float().clamp(-1, 1)
+    gt_flow = torch.randn((2, 2, 64, 96), generator=torch.Generator().manual_seed(112)) * 2
+    gt_occ = (torch.rand((2, 1, 64, 96), generator=torch.Generator().manual_seed(113)) < 0.3).float()
+    assert abs(float(x.abs().mean()) - float(g["x_absmean"])) < 1e-6 and abs(float(gt_occ.mean()) - float(g["gt_occ_mean"])) < 1e-7
+    return x, gt_flow, gt_occ
+
+
+TWO_STAGE_HP = dict(learning_rate=1e-4, inpainting_stage="simple", loss_type="pixel-wise", using_pretrained_inpainting=False, img_size=(64, 96),
+                    photo_weight=1.0, reconst_weight=1.0, smooth1_weight=0.5, smooth2_weight=0.0, pixelwise_weight=2.0, batch_size=2)
+
+
+def check_two_stage_step(m, g, dev="cpu", floor=1e-4):
+    """shared by the CPU (oracle ops) and the GPU (HIP ops) test: one training step of TwoStageModelGC against tests/golden/two_stage.npz
+    (reference in fp64 + `__noise` = its own fp32 deviation; bars max(floor, 3 x noise))"""
+    from golden_util import seeded_fill
+    seeded_fill(m, 13)
+    m = m.to(dev).train()
+    x, gt_flow, gt_occ = (t.to(dev) for t in _two_stage_inputs(g))
+    seen = {}
+    h1 = m.occ_pred.register_forward_hook(lambda mod, inp, out: seen.__setitem__("soft", out))
+    h2 = m.inpainting.register_forward_hook(lambda mod, inp, out: seen.__setitem__("completed", out))
+    res = m.general_step((x, gt_flow, gt_occ), 0, "train")
+    loss = m.training_step((x, gt_flow, gt_occ), 0)
+    h1.remove(), h2.remove()
+    bar = lambda k: max(floor, 3.0 * float(g[k + "__noise"]))
+    got = torch.stack([r.detach().float().cpu() for r in res])
+    want = T(g["ts_scalars"])
+    assert float(((got - want).abs() / want.abs().clamp_min(1.0)).max()) < bar("ts_scalars"), (got, want)
+    assert abs(float(loss.detach()) - float(g["ts_loss"])) < bar("ts_loss") * max(1.0, abs(float(g["ts_loss"])))
+    assert float((seen["soft"].detach().float().cpu() - T(g["ts_soft"])).abs().max()) < bar("ts_soft")
+    assert float((seen["completed"].detach().float().cpu() - T(g["ts_completed"])).abs().max()) < bar("ts_completed")
+    loss.backward()
+    params = dict(m.named_parameters())
+    worst = []
+    for k in [k for k in g if k.startswith("ts_grad__") and not k.endswith("__noise")]:
+        gr = params[k[len("ts_grad__"):]].grad.detach().float().cpu()
+        gr = gr[:8, :16] if gr.dim() >= 2 else gr
+        ref = T(g[k])
+        err = float((gr - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        worst.append((err / bar(k), err, k))
+    worst.sort(reverse=True)
+    assert len(worst) == 8 and worst[0][0] < 1.0, worst[:3]
+    sd = m.state_dict()
+    for k in ("occ_pred.down1.bn1.running_mean", "occ_pred.down1.bn1.running_var"):  # the step above ran the networks twice
+        assert sd[k].shape == T(g["ts_buf__" + k]).shape
+    return worst
+
+
+def test_two_stage_gc_cpu(cpu_ops, golden):
+    """SimpleOcclusionNet state_dict (keys, shapes, order) and one TwoStageModelGC training step -- AC-True warp with the
+    ground-truth flow, soft map, straight-through hard mask, edge-aware smoothness ON THE MAP (one channel through the two-channel
+    operator), three Charbonnier terms on mask-weighted images, ReconLoss -- against the reference's golden (models/model.py:1199-1256)"""
+    from ocflow_amd.models.model import TwoStageModelGC
+    from ocflow_amd.models.networks.simple_occlusion_net import SimpleOcclusionNet
+    from ocflow_amd.models.two_stage_model import straight_through_mask
+    with open(os.path.join(GOLDEN, "state_dict_manifest_two_stage.json")) as f:
+        want = [(k, tuple(s)) for k, s in json.load(f)["simpleocclusionnet"]]
+    assert [(k, tuple(v.shape)) for k, v in SimpleOcclusionNet().state_dict().items()] == want
+    g = golden("two_stage")
+    m = TwoStageModelGC(dict(TWO_STAGE_HP))
+    check_two_stage_step(m, g)
+    # the straight-through mask: 0/1 values, the soft map's gradient
+    s = torch.tensor([0.2, 0.5, 0.7], requires_grad=True)
+    h = straight_through_mask(s)
+    assert h.tolist() == [0.0, 0.0, 1.0]
+    (h * torch.tensor([1.0, 2.0, 3.0])).sum().backward()
+    assert s.grad.tolist() == [1.0, 2.0, 3.0]
+    # a batch without the occlusion label trains too (the reference's training_step cannot unpack it, model.py:1248-1253)
+    x, fl, _ = _two_stage_inputs(g)
+    assert torch.isfinite(m.training_step((x, fl), 0))
+    for bad in (dict(inpainting_stage="gated"), dict(loss_type="vgg"), dict(using_pretrained_inpainting=True)):
+        with pytest.raises(NotImplementedError, match="models/"):
+            TwoStageModelGC({**TWO_STAGE_HP, **bad})
+
+
+def test_two_stage_frozen_networks_cpu(cpu_ops):
+    """TwoStageModel (models/model.py:928-1103): flow and completion networks frozen, only the occlusion network receives gradients;
+    batches with and without the occlusion label both step (the reference reads `occ` before assignment for the latter)"""
+    from ocflow_amd.models.model import TwoStageModel
+    m = TwoStageModel({"learning_rate": 1e-4, "smoothness_weight": 0.1, "reconst_weight": 0.5}).train()
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand((2, 6, 64, 64), generator=gen) * 2 - 1
+    occ = (torch.rand((2, 1, 64, 64), generator=gen) < 0.3).float()
+    loss = m.training_step((x, torch.zeros(2, 2, 64, 64), occ), 0)
+    loss.backward()
+    assert all(p.grad is None for p in m.flow_pred.parameters()) and all(p.grad is None for p in m.inpainting.parameters())
+    assert all(p.grad is not None for p in m.occ_pred.parameters())
+    assert "train_bce_loss" in m.logged and torch.isfinite(m.validation_step(x, 0)) and "monitored_loss" in m.logged
+    assert [p for p in m.configure_optimizers().param_groups[0]["params"] if p.requires_grad]
