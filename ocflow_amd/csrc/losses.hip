@@ -375,15 +375,27 @@ __global__ __launch_bounds__(LB) void smooth_fwd_rows_kernel(T4 img, T4 flow, do
   const long ib = (long)t.b * img.sb, fb = (long)t.b * flow.sb;
   float part[4] = {0.f, 0.f, 0.f, 0.f};
   Px5 p1 = {}, p2 = {};  // rows y - 1, y - 2 of this column
+  // the loads of row r + 1 are issued before row r is evaluated: a wave walks its rows one after the other, and without the lookahead
+  // every row is a full memory round trip (37.8 us at 8 x 3 x 448 x 1024 with 1.9 TB/s of algorithmic bytes)
+  auto fetch = [&](int r, Px5& c, Px5& a1, Px5& a2) __attribute__((always_inline)) {
+    const int y = t.y0 + r;
+    const int yc = y < H ? y : H - 1;
+    const long oi = ib + (long)yc * img.sh, of = fb + (long)yc * flow.sh;
+    c = load_px5(im, fl, oi + (long)xc * img.sw, of + (long)xc * flow.sw, img.sc, flow.sc);
+    if (r < SMR) {
+      a1 = load_px5(im, fl, oi + (long)x1 * img.sw, of + (long)x1 * flow.sw, img.sc, flow.sc);
+      a2 = load_px5(im, fl, oi + (long)x2 * img.sw, of + (long)x2 * flow.sw, img.sc, flow.sc);
+    }
+  };
+  Px5 cn = {}, a1n = {}, a2n = {};
+  fetch(0, cn, a1n, a2n);
 #pragma unroll
   for (int r = 0; r < SMR + 2; r++) {
     const int y = t.y0 + r;
+    const Px5 c = cn, a1 = a1n, a2 = a2n;
+    if (r + 1 < SMR + 2) fetch(r + 1, cn, a1n, a2n);
     if (y < H) {  // (uniform per wave)
-      const long oi = ib + (long)y * img.sh, of = fb + (long)y * flow.sh;
-      const Px5 c = load_px5(im, fl, oi + (long)xc * img.sw, of + (long)xc * flow.sw, img.sc, flow.sc);
       if (r < SMR) {  // the x terms of row y (one of the strip's own rows)
-        const Px5 a1 = load_px5(im, fl, oi + (long)x1 * img.sw, of + (long)x1 * flow.sw, img.sc, flow.sc);
-        const Px5 a2 = load_px5(im, fl, oi + (long)x2 * img.sw, of + (long)x2 * flow.sw, img.sc, flow.sc);
         if (xin && t.x + 1 < W) {
           float s = 0.f;
 #pragma unroll
@@ -489,16 +501,28 @@ __global__ __launch_bounds__(LB) void smooth_bwd_rows_kernel(T4 img, T4 flow, co
   Px5 col[5];  // rows y - 2 .. y + 2 of this column
 #pragma unroll
   for (int k = 1; k < 5; k++) col[k] = row(t.y0 - 3 + k, xc);
+  // (one-row lookahead as in the forward kernel: the new bottom row and the four horizontal neighbours of the NEXT row are in flight
+  // while this row is evaluated)
+  Px5 nbot = row(t.y0 + 2, xc), nh[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++)
+    if (k != 2) nh[k] = row(t.y0, xs[k]);
 #pragma unroll
   for (int r = 0; r < SMR; r++) {
     const int y = t.y0 + r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) col[k] = col[k + 1];
+    col[4] = nbot;
+    Px5 hor[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) hor[k] = k == 2 ? col[2] : nh[k];
+    if (r + 1 < SMR) {
+      nbot = row(y + 3, xc);
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+        if (k != 2) nh[k] = row(y + 1, xs[k]);
+    }
     if (y < H) {  // (uniform per wave)
-#pragma unroll
-      for (int k = 0; k < 4; k++) col[k] = col[k + 1];
-      col[4] = row(y + 2, xc);
-      Px5 hor[5];
-#pragma unroll
-      for (int k = 0; k < 5; k++) hor[k] = k == 2 ? col[2] : row(y, xs[k]);
       float g[2] = {0.f, 0.f};
       smooth_axis_grad5(hor, alpha, t.x, W, cx1, cx2, g);
       smooth_axis_grad5(col, alpha, y, H, cy1, cy2, g);
@@ -516,15 +540,22 @@ __global__ __launch_bounds__(LB) void smooth_bwd_rows_kernel(T4 img, T4 flow, co
 // on every side) with ds_add_f32 and the window is flushed with one global atomic per touched target: a smooth flow sends the
 // 1024 contributions of a tile to ~300-500 distinct targets, so the global float-atomic count -- the bound of this kernel --
 // drops 2-3x (199 -> ~90 us at 8 x 436 x 1024).  Targets outside the window (|flow| > RSR) go straight to global memory.
+// (Round 3, measured and dropped: flushing only the bounding box of the touched cells -- 11 instead of 20 flush instructions per
+// workgroup on a smooth flow -- was 12 us SLOWER, 110.5 vs 98.7 us: the wave reductions and the extra barrier cost more than the
+// partially filled atomic instructions they remove.)
 constexpr int RSW = 32, RSH = 8, RSR = 8, RWW = RSW + 2 * RSR + 1, RWH = RSH + 2 * RSR + 1;
+// The window accumulates in 32-bit FIXED POINT (integer ds_add_u32 instead of ds_add_f32): a weight is in [0, 1], a cell receives at most
+// 256 x 4 of them from one workgroup (< 2^10), so 2^-22 steps fit 32 bits; the rounding of one contribution (<= 1.2e-7 absolute: half a step) is that of an
+// fp32 add into a sum of order 1.
+constexpr float RFIX = 4194304.f;  // 2^22
 __global__ __launch_bounds__(LB) void range_splat_kernel(T4 flow, float* range, int B, int H, int W, int tiles_x, int tiles_y) {
-  __shared__ float win[RWH * RWW];
+  __shared__ unsigned win[RWH * RWW];  // fixed point, 2^-22 (see RFIX)
   const float* fl = (const float*)flow.p;
   const int tile = blockIdx.x;
   const int tpi = tiles_x * tiles_y;
   const int b = tile / tpi, trem = tile - b * tpi;
   const int ty0 = (trem / tiles_x) * RSH, tx0 = (trem % tiles_x) * RSW;
-  for (int i = threadIdx.x; i < RWH * RWW; i += LB) win[i] = 0.f;
+  for (int i = threadIdx.x; i < RWH * RWW; i += LB) win[i] = 0u;
   __syncthreads();
   const int x = tx0 + (threadIdx.x & (RSW - 1)), y = ty0 + (threadIdx.x >> 5);
   float* dst = range + (long)b * H * W;
@@ -544,7 +575,7 @@ __global__ __launch_bounds__(LB) void range_splat_kernel(T4 flow, float* range, 
         if (tx >= 0 && tx < W && ty >= 0 && ty < H) {
           const float w = (di ? rx : 1.f - rx) * (dj ? ry : 1.f - ry);
           const int wx = tx - (tx0 - RSR), wy = ty - (ty0 - RSR);
-          if (wx >= 0 && wx < RWW && wy >= 0 && wy < RWH) atomicAdd(&win[wy * RWW + wx], w);
+          if (wx >= 0 && wx < RWW && wy >= 0 && wy < RWH) atomicAdd(&win[wy * RWW + wx], (unsigned)__builtin_fmaf(w, RFIX, 0.5f));
           else atomicAdd(dst + (long)ty * W + tx, w);
         }
       }
@@ -552,8 +583,9 @@ __global__ __launch_bounds__(LB) void range_splat_kernel(T4 flow, float* range, 
   }
   __syncthreads();
   for (int i = threadIdx.x; i < RWH * RWW; i += LB) {
-    const float v = win[i];
-    if (v != 0.f) {
+    const unsigned q = win[i];
+    if (q != 0u) {
+      const float v = (float)q * (1.f / RFIX);
       const int wy = i / RWW, wx = i - wy * RWW;
       atomicAdd(dst + (long)(ty0 - RSR + wy) * W + (tx0 - RSR + wx), v);  // in range by construction: only in-image targets were added
     }
