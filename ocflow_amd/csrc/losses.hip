@@ -34,6 +34,7 @@ __device__ __forceinline__ void block_reduce_atomic(double (&v)[NS], double* sum
 __device__ __forceinline__ float charb(float d) { return sqrtf(__builtin_fmaf(d, d, 1e-6f)); }
 
 // ------------------------------------------------------------------------------------ photometric
+struct __attribute__((packed, aligned(4))) F3 { float v[3]; };  // the three channels of a channels_last RGB pixel: one 12-byte load
 struct PhotoPix {
   float w[4];
   long off[4];
@@ -70,7 +71,24 @@ __global__ __launch_bounds__(LB) void photo_fwd_kernel(T4 img1, T4 img2, T4 flow
     const float vis = occ.p ? 1.f - ((const float*)occ.p)[(long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw] : 1.f;
     const long o1 = (long)b * img1.sb + (long)y * img1.sh + (long)x * img1.sw;
     float e = 0.f;
-    if (flow.p) {
+    if (CT == 3 && flow.p && img1.sc == 1 && img2.sc == 1) {
+      // channels_last RGB (in the model: the two halves of a six-channel image pair): a tap is ONE 12-byte load instead of three 4-byte
+      // loads 24 bytes apart across the wave -- 5 instead of 15 image loads per pixel.  Taps outside the image load the pixel's own
+      // position (always valid) and are zeroed by the select.
+      const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
+      const long own = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
+      F3 nb[4];
+#pragma unroll
+      for (int n = 0; n < 4; n++) nb[n] = *(const F3*)(i2 + (p.off[n] >= 0 ? p.off[n] : own));
+      const F3 a = *(const F3*)(i1 + o1);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; n++) v = __builtin_fmaf(p.w[n], p.off[n] >= 0 ? nb[n].v[c] : 0.f, v);
+        e += charb(v - a.v[c]);
+      }
+    } else if (flow.p) {
       const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
       OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) {
         // all four neighbour loads issued before the first use (select, not branch: a branch per tap serialises the loads)
@@ -106,7 +124,35 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
     const float vis = occ.p ? 1.f - ((const float*)occ.p)[(long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw] : 1.f;
     const long o1 = (long)b * img1.sb + (long)y * img1.sh + (long)x * img1.sw;
     const float k = sc * vis;
-    if (flow.p) {
+    if (CT == 3 && flow.p && img1.sc == 1 && img2.sc == 1) {  // channels_last RGB: packed 12-byte loads (see photo_fwd_kernel)
+      const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
+      const long own = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
+      F3 t[4];
+#pragma unroll
+      for (int n = 0; n < 4; n++) t[n] = *(const F3*)(i2 + (p.off[n] >= 0 ? p.off[n] : own));
+      const F3 a = *(const F3*)(i1 + o1);
+      float gx = 0.f, gy = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float nb[4];
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+          nb[n] = p.off[n] >= 0 ? t[n].v[c] : 0.f;
+          v = __builtin_fmaf(p.w[n], nb[n], v);
+        }
+        const float dlt = v - a.v[c];
+        const float ge = k * dlt / charb(dlt);
+        gx = __builtin_fmaf(ge, (1.f - p.wy1) * (nb[1] - nb[0]) + p.wy1 * (nb[3] - nb[2]), gx);
+        gy = __builtin_fmaf(ge, (1.f - p.wx1) * (nb[2] - nb[0]) + p.wx1 * (nb[3] - nb[1]), gy);
+      }
+      if (gflow.p) {
+        float* gf = (float*)gflow.p;
+        const long o = (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
+        gf[o] = gx * wg.ax;
+        gf[o + gflow.sc] = gy * wg.ay;
+      }
+    } else if (flow.p) {
       const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
       float gx = 0.f, gy = 0.f;
       OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) {
@@ -338,10 +384,19 @@ __device__ __forceinline__ float charb_hw(float d) { return __builtin_amdgcn_sqr
 __device__ __forceinline__ float dcharb_hw(float d) { return d * __builtin_amdgcn_rsqf(__builtin_fmaf(d, d, 1e-6f)); }  // d / charb(d)
 struct Px5 { float i[3]; float f[2]; };
 
+// CL (image channel stride 1): a channels_last image -- in the model the first or last three of the six channels of an image pair -- is
+// ONE 12-byte load per pixel instead of three 4-byte loads 24 bytes apart across the wave
+template <bool CL>
 __device__ __forceinline__ Px5 load_px5(const float* im, const float* fl, long oi, long of, long isc, long fsc) {
   Px5 p;
+  if (CL) {
+    const F3 t = *(const F3*)(im + oi);
 #pragma unroll
-  for (int c = 0; c < 3; c++) p.i[c] = im[oi + (long)c * isc];
+    for (int c = 0; c < 3; c++) p.i[c] = t.v[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; c++) p.i[c] = im[oi + (long)c * isc];
+  }
 #pragma unroll
   for (int f = 0; f < 2; f++) p.f[f] = fl[of + (long)f * fsc];
   return p;
@@ -366,6 +421,7 @@ __device__ __forceinline__ StripId strip_of(int xblocks, int ychunks) {
   return StripId{bid / ychunks, xb * 64 + (int)(threadIdx.x & 63), (yc * (LB / 64) + (int)(threadIdx.x >> 6)) * SMR};
 }
 
+template <bool CL>
 __global__ __launch_bounds__(LB) void smooth_fwd_rows_kernel(T4 img, T4 flow, double* sums, int H, int W, float alpha, int xblocks, int ychunks) {
   const float* im = (const float*)img.p;
   const float* fl = (const float*)flow.p;
@@ -381,10 +437,10 @@ __global__ __launch_bounds__(LB) void smooth_fwd_rows_kernel(T4 img, T4 flow, do
     const int y = t.y0 + r;
     const int yc = y < H ? y : H - 1;
     const long oi = ib + (long)yc * img.sh, of = fb + (long)yc * flow.sh;
-    c = load_px5(im, fl, oi + (long)xc * img.sw, of + (long)xc * flow.sw, img.sc, flow.sc);
+    c = load_px5<CL>(im, fl, oi + (long)xc * img.sw, of + (long)xc * flow.sw, img.sc, flow.sc);
     if (r < SMR) {
-      a1 = load_px5(im, fl, oi + (long)x1 * img.sw, of + (long)x1 * flow.sw, img.sc, flow.sc);
-      a2 = load_px5(im, fl, oi + (long)x2 * img.sw, of + (long)x2 * flow.sw, img.sc, flow.sc);
+      a1 = load_px5<CL>(im, fl, oi + (long)x1 * img.sw, of + (long)x1 * flow.sw, img.sc, flow.sc);
+      a2 = load_px5<CL>(im, fl, oi + (long)x2 * img.sw, of + (long)x2 * flow.sw, img.sc, flow.sc);
     }
   };
   Px5 cn = {}, a1n = {}, a2n = {};
@@ -477,6 +533,7 @@ __device__ __forceinline__ void smooth_axis_grad5(const Px5* v, float alpha, int
   }
 }
 
+template <bool CL>
 __global__ __launch_bounds__(LB) void smooth_bwd_rows_kernel(T4 img, T4 flow, const float* coef, T4 gflow, int H, int W, float alpha, int xblocks,
                                                              int ychunks) {
   const float* im = (const float*)img.p;
@@ -496,7 +553,7 @@ __global__ __launch_bounds__(LB) void smooth_bwd_rows_kernel(T4 img, T4 flow, co
   const long ib = (long)t.b * img.sb, fb = (long)t.b * flow.sb;
   auto row = [&](int y, int xx) __attribute__((always_inline)) {  // (row clamped into the image: such entries are never used)
     const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
-    return load_px5(im, fl, ib + (long)yc * img.sh + (long)xx * img.sw, fb + (long)yc * flow.sh + (long)xx * flow.sw, img.sc, flow.sc);
+    return load_px5<CL>(im, fl, ib + (long)yc * img.sh + (long)xx * img.sw, fb + (long)yc * flow.sh + (long)xx * flow.sw, img.sc, flow.sc);
   };
   Px5 col[5];  // rows y - 2 .. y + 2 of this column
 #pragma unroll
@@ -949,9 +1006,12 @@ extern "C" int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* fl
   const long npix = (long)B * H * W;
   const int xblocks = (W + 63) / 64, ychunks = (H + SMR * (LB / 64) - 1) / (SMR * (LB / 64));
   const bool rows = C == 3 && (long)B * xblocks * ychunks <= 0x7fffffffL;
-  if (rows)
-    LaunchProf().launch(true, smooth_fwd_rows_kernel, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, st, mk(img), mk(flow), sums, H, W, alpha,
-                       xblocks, ychunks);
+  if (rows && img->sc == 1)
+    LaunchProf().launch(true, smooth_fwd_rows_kernel<true>, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, st, mk(img), mk(flow), sums, H, W,
+                       alpha, xblocks, ychunks);
+  else if (rows)
+    LaunchProf().launch(true, smooth_fwd_rows_kernel<false>, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, st, mk(img), mk(flow), sums, H, W,
+                       alpha, xblocks, ychunks);
   else if (C == 3)
     LaunchProf().launch(true, smooth_fwd_kernel<3>, dim3(rgrid_reduce(npix)), dim3(LB), 0, st, mk(img), mk(flow), sums, B, C, H, W, alpha, npix);
   else
@@ -966,9 +1026,12 @@ extern "C" int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* fl
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
   const int xblocks = (W + 63) / 64, ychunks = (H + SMR * (LB / 64) - 1) / (SMR * (LB / 64));
-  if (C == 3 && (long)B * xblocks * ychunks <= 0x7fffffffL)
-    LaunchProf().launch(true, smooth_bwd_rows_kernel, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef,
-                       mk(gflow), H, W, alpha, xblocks, ychunks);
+  if (C == 3 && (long)B * xblocks * ychunks <= 0x7fffffffL && img->sc == 1)
+    LaunchProf().launch(true, smooth_bwd_rows_kernel<true>, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow),
+                       coef, mk(gflow), H, W, alpha, xblocks, ychunks);
+  else if (C == 3 && (long)B * xblocks * ychunks <= 0x7fffffffL)
+    LaunchProf().launch(true, smooth_bwd_rows_kernel<false>, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow),
+                       coef, mk(gflow), H, W, alpha, xblocks, ychunks);
   else if (C == 3)
     LaunchProf().launch(true, smooth_bwd_kernel<3>, dim3(rgrid(npix)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow), coef, mk(gflow),
                        B, C, H, W, alpha, npix);

@@ -260,9 +260,12 @@ def _loss_inputs():
     return img1, img2, flow, occ
 
 
-def test_loss_kernels_full_size_vs_oracle(ops):
+@pytest.mark.parametrize("pair_layout", [False, True])
+def test_loss_kernels_full_size_vs_oracle(ops, pair_layout):
     """photometric (fused AC-True warp + mask), first/second-order smoothness and SSIM at 8 x 3 x 436 x 1024: values and flow
-    gradients vs the oracle (multi-block fp64-atomic reductions, 1024-block grids) -- fp32 bar"""
+    gradients vs the oracle (multi-block fp64-atomic reductions, 1024-block grids) -- fp32 bar.  pair_layout: the images as the model
+    hands them over -- the two halves of ONE six-channel channels_last tensor (channel stride 1, pixel pitch 24 bytes: the packed
+    12-byte-load forms of the photometric and smoothness kernels)"""
     img1, img2, flow, occ = _loss_inputs()
     # the photometric reference in float64: at W = 1024 an fp32 sample coordinate x + u only resolves 6e-5 px (and the reference's
     # normalise / un-normalise round trip of the grid loses more), so two fp32 evaluations of the flow gradient -- a piecewise
@@ -275,6 +278,10 @@ def test_loss_kernels_full_size_vs_oracle(ops):
     (gs_ref,) = torch.autograd.grad(0.7 * s1_ref + 0.3 * s2_ref, fl2)
 
     d1, d2, dfl, docc = img1.to(DEV), img2.to(DEV), flow.to(DEV).requires_grad_(), occ.to(DEV)
+    if pair_layout:
+        pair = torch.cat((d1, d2), 1).contiguous(memory_format=torch.channels_last)
+        d1, d2 = pair[:, 0:3], pair[:, 3:6]
+        assert d1.stride(1) == 1 and d1.stride(3) == 6
     p = ops.warp_photometric_error(d1, d2, dfl, docc)
     assert abs(float(p) - float(ref_p)) <= 2e-5 * abs(float(ref_p))
     (gp,) = torch.autograd.grad(p, dfl)

@@ -181,3 +181,35 @@ def test_launcher_trains_the_two_stage_model(tmp_path):
     assert hist[-1]["train_loss"] < hist[0]["train_loss"], hist
     sd = torch.load(tmp_path / "out" / "state_dict.pt")
     assert any(k.startswith("occ_pred.predict_occ0.") for k in sd) and any(k.startswith("inpainting.up6.") for k in sd)
+
+
+def test_fpn_net_step_at_a_shape_outside_the_find_db():
+    """the safe default of the decoder-input alignment: at 4 x 320 x 1216 -- a shape the shipped MIOpen find-db has no entry
+    for -- the concatenations stay unaligned (`_padded_shape_is_known` says no for every decoder input of the step) and the
+    occlusion-aware step of FlowStageModel('flownet') trains: finite, decreasing loss on a fixed batch, finite gradients"""
+    from ocflow_amd.models.model import FlowStageModel
+    from ocflow_amd.models.networks import _epilogue
+    from ocflow_amd.runtime import DistEnv, TrainStepper, synthetic_batch, use_repo_miopen_db
+    use_repo_miopen_db()
+    torch.manual_seed(4)
+    asked = []
+    real = _epilogue._padded_shape_is_known
+
+    def spy(n, c, h, w):
+        r = real(n, c, h, w)
+        asked.append(((n, c, h, w), r))
+        return r
+
+    _epilogue._padded_shape_is_known = spy
+    try:
+        hp = dict(learning_rate=1e-4, model="flownet", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0, with_occ=False,
+                  occ_aware=True)
+        st = TrainStepper(FlowStageModel(hp), DistEnv(device=torch.device(DEV)), amp_dtype=torch.bfloat16, channels_last=True, fused_optimizer=True)
+        batch = st.prepare(synthetic_batch(4, 320, 1216, DEV, seed=6))
+        losses = [float(st.step(batch, i)) for i in range(8)]
+    finally:
+        _epilogue._padded_shape_is_known = real
+    assert all(np.isfinite(losses)) and min(losses[4:]) < losses[0], losses
+    assert asked and not any(r for _, r in asked), [a for a in asked if a[1]][:3]
+    gmax = max(float(p.grad.abs().max()) for p in st.raw.parameters() if p.grad is not None)
+    assert np.isfinite(gmax) and gmax < 1e4
