@@ -12,9 +12,12 @@ Two ways to produce a batch:
 
 Decoding uses PIL (the reference uses imageio, absent here; both decode PNG to the same uint8 array).  Resizing: the reference calls
 `cv2.resize(..., INTER_LINEAR)` = bilinear with half-pixel centres and no antialiasing; here `F.interpolate(mode='bilinear',
-align_corners=False)` on float data.  cv2 is absent from this image, so the resize is the one rule of this file that is restated from
-the published definition rather than pinned by a golden (parity unpinned for `image_size != None`; everything else is pinned by
-running the reference's own dataset class on a synthetic tree: tests/golden/make_golden.py::gold_datasets)."""
+align_corners=False)` on float data.  PARITY UNPINNED for this file: the reference's dataset classes need imageio, cv2 and torchvision,
+none of which this image has, so they cannot be run to produce fixtures; the rules are restated from the reference's source and
+checked against hand-computed expectations on synthetic trees (`tests/test_data_formats.py`).
+
+FlyingChairs (`*.ppm` pairs + `*.flo`, datasets.py:465-530) and FlyingChairs2 (`*-img_0/1.png`, `*-flow_01.flo`, `*-occ_01.png`,
+:587-669 -- the dataset of the reference's shipped `config/unsupervised_config.yml`) share the sample rules; only the file pairing differs."""
 from __future__ import annotations
 
 import os
@@ -85,38 +88,19 @@ def _default_transform(img_uint8: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(normalize_image(img_uint8))
 
 
-class _SintelBase(Dataset):
-    """shared listing / sample logic of MpiSintel (flow), MpiSintelOcc (occlusions) and MpiSintelFlowOcc (both): datasets.py:113-330"""
+class _PairDataset(Dataset):
+    """shared sample logic of the pair datasets; subclasses provide `_list(root)` -> fills image_list / flow_list / occ_list"""
 
-    def __init__(self, transform=_default_transform, root="", dstype="clean", replicates=1, image_size=None, stack_imgs=True, raw=False,
-                 want_flow=True, want_occ=False):
-        self.transform, self.replicates, self.image_size, self.stack_imgs, self.raw = transform, replicates, image_size, stack_imgs, raw
+    def __init__(self, transform=_default_transform, root="", replicates=1, image_size=None, stack_imgs=True, raw=False, want_flow=True,
+                 want_occ=False):
+        self.transform = transform
+        self.replicates, self.image_size, self.stack_imgs, self.raw = replicates, image_size, stack_imgs, raw
         self.want_flow, self.want_occ = want_flow, want_occ
-        flow_root, occ_root, image_root = join(root, "flow"), join(root, "occlusions"), join(root, dstype)
-        flow_files = sorted(glob(join(flow_root, "*/*.flo"))) if want_flow else []
-        occ_files = sorted(glob(join(occ_root, "*/*.png"))) if want_occ else []
-        if want_flow and want_occ:
-            assert len(occ_files) == len(flow_files), "number of occlusion maps should be equal to number of flows"
         self.flow_list, self.occ_list, self.image_list = [], [], []
-        keys = flow_files if want_flow else occ_files
-        key_root = flow_root if want_flow else occ_root
-        for k, file in enumerate(keys):
-            fbase = file[len(key_root) + 1:]
-            fprefix, fnum = fbase[:-8], int(fbase[-8:-4])
-            img1 = join(image_root, fprefix + "{:04d}".format(fnum + 0) + ".png")
-            img2 = join(image_root, fprefix + "{:04d}".format(fnum + 1) + ".png")
-            for f in (img1, img2, file):
-                assert isfile(f), "Cannot find file: {}".format(f)
-            self.image_list.append([img1, img2])
-            if want_flow:
-                self.flow_list.append(file)
-            if want_occ:
-                occ_file = occ_files[k]
-                assert isfile(occ_file), "Cannot find file: {}".format(occ_file)
-                self.occ_list.append(occ_file)
+        self._list(root)
         self.size = len(self.image_list)
         if self.size == 0:
-            raise FileNotFoundError(f"no samples under {root!r} (expected {dstype}/<scene>/frame_XXXX.png with flow/ or occlusions/)")
+            raise FileNotFoundError(f"no samples under {root!r} ({self._layout})")
         h, w = read_gen(self.image_list[0][0]).shape[:2]
         self.render_size = list(render_size(h, w)) if (h % 64 or w % 64) else [h, w]
 
@@ -166,6 +150,68 @@ class _SintelBase(Dataset):
         return tuple(out)
 
 
+class _SintelBase(_PairDataset):
+    """listing of MpiSintel (flow), MpiSintelOcc (occlusions) and MpiSintelFlowOcc (both): datasets.py:113-330"""
+    _layout = "expected <dstype>/<scene>/frame_XXXX.png with flow/ or occlusions/"
+
+    def __init__(self, transform=_default_transform, root="", dstype="clean", replicates=1, image_size=None, stack_imgs=True, raw=False,
+                 want_flow=True, want_occ=False):
+        self.dstype = dstype
+        super().__init__(transform, root, replicates, image_size, stack_imgs, raw, want_flow, want_occ)
+
+    def _list(self, root):
+        want_flow, want_occ, dstype = self.want_flow, self.want_occ, self.dstype
+        flow_root, occ_root, image_root = join(root, "flow"), join(root, "occlusions"), join(root, dstype)
+        flow_files = sorted(glob(join(flow_root, "*/*.flo"))) if want_flow else []
+        occ_files = sorted(glob(join(occ_root, "*/*.png"))) if want_occ else []
+        if want_flow and want_occ:
+            assert len(occ_files) == len(flow_files), "number of occlusion maps should be equal to number of flows"
+        keys = flow_files if want_flow else occ_files
+        key_root = flow_root if want_flow else occ_root
+        for k, file in enumerate(keys):
+            fbase = file[len(key_root) + 1:]
+            fprefix, fnum = fbase[:-8], int(fbase[-8:-4])
+            img1 = join(image_root, fprefix + "{:04d}".format(fnum + 0) + ".png")
+            img2 = join(image_root, fprefix + "{:04d}".format(fnum + 1) + ".png")
+            for f in (img1, img2, file):
+                assert isfile(f), "Cannot find file: {}".format(f)
+            self.image_list.append([img1, img2])
+            if want_flow:
+                self.flow_list.append(file)
+            if want_occ:
+                occ_file = occ_files[k]
+                assert isfile(occ_file), "Cannot find file: {}".format(occ_file)
+                self.occ_list.append(occ_file)
+
+
+class _ChairsBase(_PairDataset):
+    """FlyingChairs / FlyingChairs2: a flat directory, consecutive sorted images form the pairs (datasets.py:465-530, 587-669)"""
+
+    def __init__(self, transform=_default_transform, root="", replicates=1, image_size=None, stack_imgs=True, raw=False):
+        super().__init__(transform, root, replicates, image_size, stack_imgs, raw, want_flow=True, want_occ=self._occ_glob is not None)
+
+    def _list(self, root):
+        images = sorted(glob(join(root, self._img_glob)))
+        self.flow_list = sorted(glob(join(root, self._flow_glob)))
+        self.occ_list = sorted(glob(join(root, self._occ_glob))) if self._occ_glob else []
+        assert len(images) // 2 == len(self.flow_list)
+        self.image_list = [[images[2 * i], images[2 * i + 1]] for i in range(len(self.flow_list))]
+        assert len(self.image_list) == len(self.flow_list), "The number of image pairs should be equal to the number of optical flow"
+        if self._occ_glob:
+            assert len(self.occ_list) == len(self.flow_list), "number of occlusion maps should be equal to number of flows"
+
+
+class FlyingChairs(_ChairsBase):
+    """`XXXXX_img1.ppm`, `XXXXX_img2.ppm`, `XXXXX_flow.flo` -> (images, flow)  (datasets.py:465-530)"""
+    _img_glob, _flow_glob, _occ_glob, _layout = "*.ppm", "*.flo", None, "expected *.ppm image pairs and *.flo flows in one directory"
+
+
+class FlyingChairs2(_ChairsBase):
+    """`XXXXXXX-img_0.png`, `-img_1.png`, `-flow_01.flo`, `-occ_01.png` -> (images, flow, occ)  (datasets.py:587-669)"""
+    _img_glob, _flow_glob, _occ_glob = "*-img_*.png", "*-flow_01.flo", "*-occ_01.png"
+    _layout = "expected *-img_0.png / *-img_1.png / *-flow_01.flo / *-occ_01.png in one directory"
+
+
 def _variant(name, dstype, **kw):
     def __init__(self, transform=_default_transform, root="", replicates=1, image_size=None, stack_imgs=True, raw=False):
         _SintelBase.__init__(self, transform=transform, root=root, dstype=dstype, replicates=replicates, image_size=image_size,
@@ -180,7 +226,7 @@ MpiSintelFinalOcc = _variant("MpiSintelFinalOcc", "final", want_flow=False, want
 MpiSintelCleanFlowOcc = _variant("MpiSintelCleanFlowOcc", "clean", want_flow=True, want_occ=True)
 MpiSintelFinalFlowOcc = _variant("MpiSintelFinalFlowOcc", "final", want_flow=True, want_occ=True)
 DATASETS = {c.__name__: c for c in (MpiSintelClean, MpiSintelFinal, MpiSintelCleanOcc, MpiSintelFinalOcc, MpiSintelCleanFlowOcc,
-                                    MpiSintelFinalFlowOcc)}
+                                    MpiSintelFinalFlowOcc, FlyingChairs, FlyingChairs2)}
 
 
 @torch.no_grad()

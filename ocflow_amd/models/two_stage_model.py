@@ -18,9 +18,10 @@
 The smoothness kernel takes a two-channel field: the one-channel map is passed as two views of itself (`expand`, no copy) -- the mean
 over two identical channels is the mean over one, and autograd adds the two gradient planes back together.
 
-Scope: `inpainting_stage='simple'` (InpaintingNet) and `loss_type='pixel-wise'`; the gated-convolution generators
-(gated_conv_inpainting_net*.py) and the VGG perceptual loss need pretrained torchvision weights / a 4 M-parameter GAN generator that
-SURVEY section 8 puts outside the hot path -- asking for them raises NotImplementedError naming the reference file.  Reference defects
+Scope: `inpainting_stage='simple'` (InpaintingNet) or `'gated'` (InpaintSANet, networks/gated_conv_inpainting_net.py), trained from
+scratch, with `loss_type='pixel-wise'`.  The VGG perceptual loss (pretrained torchvision weights), a pretrained completion network
+(`using_pretrained_inpainting`: a Lightning checkpoint of the GAN trainer) and the non-projected generator `'gated_org'` raise
+NotImplementedError naming the reference file.  Reference defects
 not reproduced: `training_step` / `test_step` test `len(losses) == 3` although `general_step` returns 5 or 6 values, so a batch without
 an occlusion label cannot train there (ValueError at model.py:1253); `TwoStageModel.general_step` reads `occ` before assignment for such
 batches (:1030) and calls the inpainting network without its mask argument (:1023).  Here both batch forms work."""
@@ -31,6 +32,7 @@ from torch.optim import Adam
 
 from ocflow_amd import ops
 from .lightning_shim import LightningModule, set_hparams
+from .networks.gated_conv_inpainting_net import InpaintSANet
 from .networks.image_inpainting_net import InpaintingNet
 from .networks.simple_flow_net import SimpleFlowNet
 from .networks.simple_occlusion_net import SimpleOcclusionNet
@@ -78,6 +80,12 @@ def _unpack(batch):
     raise ValueError("Not supported dataset")
 
 
+def _bce(pred, target):
+    """F.binary_cross_entropy in fp32 (autocast refuses it in reduced precision); identical in fp32 mode"""
+    with torch.autocast(device_type=pred.device.type, enabled=False):
+        return F.binary_cross_entropy(pred.float(), target.float())
+
+
 def _map_smoothness(img, soft):
     """first_order_smoothness_loss(img, soft) for a ONE-channel map on the two-channel HIP kernel"""
     return ops.first_order_smoothness_loss(img, soft.expand(-1, 2, -1, -1))
@@ -123,10 +131,13 @@ class TwoStageModelGC(_TwoStageBase):
         if self.using_pretrained_inpainting:
             raise NotImplementedError("using_pretrained_inpainting=True loads an InpaintingStageModel checkpoint (models/model.py:1134): "
                                       "outside the hot path (SURVEY 8f-4); train the completion network from scratch")
-        if self.inpainting_stage != "simple":
-            raise NotImplementedError(f"inpainting_stage '{self.inpainting_stage}': the gated-convolution generators "
-                                      "(models/networks/gated_conv_inpainting_net*.py) are outside the hot path; use 'simple'")
-        self.inpainting = InpaintingNet()
+        if self.inpainting_stage == "simple":
+            self.inpainting = InpaintingNet()
+        elif self.inpainting_stage == "gated":
+            self.inpainting = InpaintSANet(img_size=self.img_size)
+        else:
+            raise NotImplementedError(f"inpainting_stage '{self.inpainting_stage}': InpaintSANetOrg (models/networks/gated_conv_inpainting_net.py:"
+                                      "430-514, the non-projected generator) is not built; use 'gated' or 'simple'")
         if self.loss_type != "pixel-wise":
             raise NotImplementedError(f"loss_type '{self.loss_type}': VGGPerceptualLoss (models/model.py:116-153) needs pretrained torchvision "
                                       "weights; use 'pixel-wise'")
@@ -146,11 +157,13 @@ class TwoStageModelGC(_TwoStageBase):
         soft = self.occ_pred(imgs)
         smoothness_loss = _map_smoothness(img_warped, soft)
         img_completed = self.inpainting(img_warped, soft)
+        if self.inpainting_stage == "gated":
+            img_completed = img_completed[1]  # (coarse, refined): the step uses the refined completion (model.py:1222)
         photo_error = ops.photometric_error(img_warped * (1 - soft), img1 * (1 - soft))
         photo_error_occluded = ops.photometric_error(img_warped * soft, img1 * soft)
         reconst_error = self.loss_func(soft * img_completed, soft * img1)
         pixelwise_loss, _, _ = self.pixelwise_loss_func(img_completed, img1, soft)
-        bce_loss = F.binary_cross_entropy(soft, occ) if occ is not None else None
+        bce_loss = _bce(soft, occ) if occ is not None else None
         return photo_error, reconst_error, smoothness_loss, pixelwise_loss, bce_loss, photo_error_occluded
 
     _NAMES = ("photometric", "reconst", "smoothness", "pixelwise", "bce_loss", "photometric_occluded")
@@ -221,7 +234,7 @@ class TwoStageModel(_TwoStageBase):
         smoothness_term = ops.first_order_smoothness_loss(img1, flow_pred)
         photo_error = ops.photometric_error(img_warped * (1 - occ_pred), img1 * (1 - occ_pred))
         reconst_error = ops.photometric_error(img_warped * occ_pred, img1 * occ_pred)
-        bce_loss = F.binary_cross_entropy(occ_pred, occ) if occ is not None else None
+        bce_loss = _bce(occ_pred, occ) if occ is not None else None
         self.last_completed = img_completed.detach()
         return photo_error, reconst_error, smoothness_term, bce_loss
 

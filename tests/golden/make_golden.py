@@ -663,8 +663,85 @@ def gold_two_stage():
     with open(os.path.join(HERE, "state_dict_manifest_two_stage.json"), "w") as f:
         json.dump(manifest, f)
 
+# ------------------------------------------- 15. gated-convolution generator (second half): InpaintSANet + the 'gated' two-stage step
+GATED_GRADS = ("occ_pred.down1.conv1.weight", "occ_pred.predict_occ0.2.0.weight", "inpainting.coarse_net.0.conv2d.conv2.weight",
+               "inpainting.coarse_net.6.mask_conv2d.conv2.weight", "inpainting.coarse_net.12.conv2d.mask_conv2d.conv3.bias",
+               "inpainting.refine_attn.gamma", "inpainting.refine_attn.query_conv.weight", "inpainting.refine_upsample_net.6.batch_norm.weight")
+
+
+def gold_gated():
+    """(a) InpaintSANet(img_size=(64, 96)) alone, golden_util.seeded_fill weights (gamma of the attention block != 0), evaluation and training
+    mode: coarse and refined completions of a 2 x 64 x 96 batch; state_dict manifest.  (b) one TRAINING step of TwoStageModelGC with
+    inpainting_stage='gated', loss_type='pixel-wise', from scratch (models/model.py:1199-1256): the six step values, the total, eight
+    gradients.  fp64 values + `__noise` (the reference's own fp32 deviation) as in gold_two_stage."""
+    from models.networks.gated_conv_inpainting_net import InpaintSANet
+    import json
+    arrs = {}
+    imgs = torch.from_numpy(smooth_field((2, 3, 64, 96), seed=121, amp=1.0)).float().clamp(-1, 1)
+    masks = (torch.from_numpy(smooth_field((2, 1, 64, 96), seed=122, amp=1.0)) > 0.3).float()
+    arrs.update(imgs_absmean=imgs.abs().mean(), masks_mean=masks.mean())
+
+    def run_net(dt, train):
+        net = InpaintSANet(img_size=(64, 96))
+        seeded_fill(net, 17)
+        net = net.to(dt)
+        net.train(train)
+        with torch.no_grad():
+            c, r = net(imgs.to(dt), masks.to(dt))
+        tag = "train" if train else "eval"
+        return {f"net_{tag}_coarse": c, f"net_{tag}_refined": r}, [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+
+    manifest = None
+    for train in (False, True):
+        (r32, manifest), (r64, _) = run_net(torch.float32, train), run_net(torch.float64, train)
+        for k in r64:
+            arrs[k] = r64[k].float()
+            arrs[k + "__noise"] = (r32[k].double() - r64[k]).abs().max().double()
+
+    x = torch.from_numpy(smooth_field((2, 6, 64, 96), seed=123, amp=1.0)).float().clamp(-1, 1)
+    gt_flow = torch.randn((2, 2, 64, 96), generator=g(124)) * 2
+    gt_occ = (torch.rand((2, 1, 64, 96), generator=g(125)) < 0.3).float()
+    arrs.update(x_absmean=x.abs().mean(), gt_occ_mean=gt_occ.mean())
+    hp = dict(learning_rate=1e-4, inpainting_stage="gated", loss_type="pixel-wise", using_pretrained_inpainting=False, img_size=(64, 96),
+              photo_weight=4.0, reconst_weight=1.0, smooth1_weight=0.5, smooth2_weight=0.0, pixelwise_weight=2.0, batch_size=2)
+
+    def run_step(dt):
+        m = ref_model.TwoStageModelGC(dict(hp))
+        seeded_fill(m, 19)
+        m = m.to(dt).train()
+        res = m.general_step((x.to(dt), gt_flow.to(dt), gt_occ.to(dt)), 0, "train")
+        photo, reconst, smooth, pixelwise, bce, photo_occ = res
+        loss = hp["photo_weight"] * photo + hp["reconst_weight"] * reconst + hp["smooth1_weight"] * smooth + hp["pixelwise_weight"] * pixelwise
+        loss.backward()
+        params = dict(m.named_parameters())
+        out = dict(gs_scalars=torch.stack([r.detach() for r in res]), gs_loss=loss)
+        out.update({"gs_grad__" + k: _grad_pick(params[k].grad) for k in GATED_GRADS})
+        return {k: v.detach() for k, v in out.items()}
+
+    r32, r64 = run_step(torch.float32), run_step(torch.float64)
+    for k, v64 in r64.items():
+        v32 = r32[k]
+        arrs[k] = v64.float()
+        if "grad" in k:
+            noise = (v32.double() - v64).abs().max() / (v64.abs().max() + 1e-300)
+        elif v64.dim() == 0:
+            noise = (v32.double() - v64).abs() / v64.abs().clamp_min(1.0)
+        else:
+            noise = ((v32.double() - v64).abs() / v64.abs().clamp_min(1.0)).max()
+        arrs[k + "__noise"] = noise.double()
+    for k in sorted(arrs):
+        if k.endswith("__noise"):
+            print(f"  {k:70s} {float(arrs[k]):.3e}")
+    print("  scalars:", [round(float(v), 6) for v in arrs["gs_scalars"]], float(arrs["gs_loss"]))
+    save("gated", **arrs)
+    with open(os.path.join(HERE, "state_dict_manifest_gated.json"), "w") as f:
+        json.dump({"inpaintsanet": manifest}, f)
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gated":
+        gold_gated()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "two_stage":
         gold_two_stage()
         sys.exit(0)
@@ -699,3 +776,4 @@ if __name__ == "__main__":
     gold_inpainting()
     gold_train_fpn()
     gold_two_stage()
+    gold_gated()

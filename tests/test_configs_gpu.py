@@ -5,6 +5,8 @@
   configs[2]  FlowStageModel('pwc', occ_aware) training steps at 8 x 384 x 512 (bf16, channels_last): finite decreasing loss, range-map
               mass conservation on the model's own backward flow;
   configs[3]  the inpainting head at the KITTI render size 4 x 320 x 1216 and the op chain at 375 x 1242 against the reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -213,3 +215,30 @@ def test_fpn_net_step_at_a_shape_outside_the_find_db():
     assert asked and not any(r for _, r in asked), [a for a in asked if a[1]][:3]
     gmax = max(float(p.grad.abs().max()) for p in st.raw.parameters() if p.grad is not None)
     assert np.isfinite(gmax) and gmax < 1e4
+
+
+def test_launcher_runs_the_shipped_two_stage_configuration(tmp_path):
+    """config/unsupervised_twostage.yml = the reference's default run (twostage / with_gt_flow / gated / pixel-wise / FlyingChairs2 at
+    96 x 128) with the completion network trained from scratch: a synthetic FlyingChairs2 directory, decode on the host, sample rules on
+    the GPU, the step (occlusion U-Net + gated generator with attention + HIP loss kernels) replayed as a hipGraph"""
+    from PIL import Image
+    from ocflow_amd import train
+    from ocflow_amd.data import flow_io
+    rs = np.random.RandomState(7)
+    root = tmp_path / "chairs2"
+    root.mkdir()
+    base = smooth_field((1, 3, 140, 200), seed=9, amp=1.0)[0].transpose(1, 2, 0)
+    for i in range(12):
+        for j in (0, 1):
+            img = np.clip((np.roll(base, 3 * i + 2 * j, axis=1) * 0.5 + 0.5) * 255, 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(root / f"{i:07d}-img_{j}.png")
+        fl = np.zeros((140, 200, 2), np.float32)
+        fl[..., 0] = 2.0
+        flow_io.save_flow(str(root / f"{i:07d}-flow_01.flo"), fl)
+        Image.fromarray(((rs.rand(140, 200) < 0.2) * 255).astype(np.uint8)).save(root / f"{i:07d}-occ_01.png")
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "unsupervised_twostage.yml")
+    hist = train.main([cfg, "--steps", "13", "--override", f"root={root}", "batch_size=4", "num_workers=0", "log_every_n_steps=4",
+                       "--out", str(tmp_path / "out")])
+    assert len(hist) >= 3 and all(np.isfinite(h["train_loss"]) for h in hist)
+    sd = torch.load(tmp_path / "out" / "state_dict.pt")
+    assert any(k.startswith("inpainting.refine_attn.") for k in sd) and any(k.startswith("occ_pred.") for k in sd)

@@ -136,3 +136,42 @@ def test_dataset_module_splits_like_the_reference(tmp_path):
     assert imgs.shape == (2, 6, 64, 64) and flow.shape == (2, 2, 64, 64) and occ.shape == (2, 1, 64, 64)
     with pytest.raises(ValueError, match="Unsupported dataset type"):
         D.DatasetModule(root=str(tmp_path), dataset_name="KITTI").setup()
+
+
+def test_flying_chairs_layouts(tmp_path):
+    """FlyingChairs (`*.ppm` + `*.flo`) and FlyingChairs2 (`-img_0/1.png`, `-flow_01.flo`, `-occ_01.png`: the dataset of the reference's shipped
+    unsupervised_config.yml) pair consecutive sorted images, crop to multiples of 64, and return (images, flow[, occ]) with the shared sample
+    rules (datasets.py:465-530, 587-669); the decode-only mode + device-side preparation gives the same batch"""
+    from PIL import Image
+    from ocflow_amd.data import flow_io
+    from ocflow_amd.data.datasets import DATASETS, FlyingChairs, FlyingChairs2, prepare_batch_on_device
+    rs = np.random.RandomState(5)
+    c1, c2 = tmp_path / "chairs", tmp_path / "chairs2"
+    c1.mkdir(), c2.mkdir()
+    h, w = 70, 130  # -> render size 64 x 128
+    for i in range(3):
+        for j in (1, 2):
+            Image.fromarray(rs.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(c1 / f"{i:05d}_img{j}.ppm")
+        flow_io.save_flow(str(c1 / f"{i:05d}_flow.flo"), rs.randn(h, w, 2).astype(np.float32))
+        for j in (0, 1):
+            Image.fromarray(rs.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(c2 / f"{i:07d}-img_{j}.png")
+        flow_io.save_flow(str(c2 / f"{i:07d}-flow_01.flo"), rs.randn(h, w, 2).astype(np.float32))
+        Image.fromarray(((rs.rand(h, w) < 0.3) * 255).astype(np.uint8)).save(c2 / f"{i:07d}-occ_01.png")
+    assert DATASETS["FlyingChairs2"] is FlyingChairs2
+    d1 = FlyingChairs(root=str(c1), stack_imgs=False)
+    imgs, flow = d1[1]
+    assert len(d1) == 3 and imgs.shape == (6, 64, 128) and flow.shape == (2, 64, 128) and float(imgs.min()) >= -1.0 and float(imgs.max()) <= 1.0
+    ref = np.asarray(Image.open(c1 / "00001_img1.ppm"))[3:67, 1:129]
+    np.testing.assert_allclose(imgs[:3].numpy(), (ref.transpose(2, 0, 1) / 255.0 - 0.5) / 0.5, atol=1e-6)
+    d2 = FlyingChairs2(root=str(c2), stack_imgs=False)
+    imgs2, flow2, occ2 = d2[2]
+    assert imgs2.shape == (6, 64, 128) and flow2.shape == (2, 64, 128) and occ2.shape == (1, 64, 128)
+    assert set(np.unique(occ2.numpy()).tolist()) <= {0.0, 1.0} and 0.1 < float(occ2.mean()) < 0.5
+    np.testing.assert_array_equal(occ2[0].numpy(), (np.asarray(Image.open(c2 / "0000002-occ_01.png"))[3:67, 1:129] > 0).astype(np.float32))
+    raw = FlyingChairs2(root=str(c2), raw=True)[2]
+    x, fl, oc = prepare_batch_on_device(raw[0][None], raw[1][None], raw[2][None], None, "cpu", channels_last=False)
+    np.testing.assert_allclose(x[0].numpy(), imgs2.numpy(), atol=1e-6)
+    np.testing.assert_array_equal(fl[0].numpy(), flow2.numpy())
+    np.testing.assert_array_equal(oc[0].numpy(), occ2.numpy())
+    with pytest.raises(FileNotFoundError, match="img_0"):
+        FlyingChairs2(root=str(tmp_path / "empty"))

@@ -199,7 +199,9 @@ def test_launcher_builds_the_reference_hparams(tmp_path):
     m3, _ = train.build_module(dict(two, model="no_gt_flow", smoothness_weight=0.1, flow_root=None, supervised_flow=False))
     assert type(m3).__name__ == "TwoStageModel" and not any(p.requires_grad for p in m3.flow_pred.parameters())
     with pytest.raises(NotImplementedError, match="gated_conv_inpainting_net"):
-        train.build_module(dict(two, inpainting_stage="gated"))
+        train.build_module(dict(two, inpainting_stage="gated_org"))
+    m4, _ = train.build_module(dict(two, inpainting_stage="gated"))  # the reference's shipped config/unsupervised_config.yml, from scratch
+    assert type(m4.inpainting).__name__ == "InpaintSANet"
     sup, _ = train.build_module({"network_type": "flowocc", "model": "flowoccnet", "learning_rate": 1e-3})
     assert type(sup).__name__ == "FlowOccModel"
 
@@ -309,7 +311,7 @@ def test_two_stage_gc_cpu(cpu_ops, golden):
     # a batch without the occlusion label trains too (the reference's training_step cannot unpack it, model.py:1248-1253)
     x, fl, _ = _two_stage_inputs(g)
     assert torch.isfinite(m.training_step((x, fl), 0))
-    for bad in (dict(inpainting_stage="gated"), dict(loss_type="vgg"), dict(using_pretrained_inpainting=True)):
+    for bad in (dict(inpainting_stage="gated_org"), dict(loss_type="vgg"), dict(using_pretrained_inpainting=True)):
         with pytest.raises(NotImplementedError, match="models/"):
             TwoStageModelGC({**TWO_STAGE_HP, **bad})
 
@@ -328,3 +330,85 @@ def test_two_stage_frozen_networks_cpu(cpu_ops):
     assert all(p.grad is not None for p in m.occ_pred.parameters())
     assert "train_bce_loss" in m.logged and torch.isfinite(m.validation_step(x, 0)) and "monitored_loss" in m.logged
     assert [p for p in m.configure_optimizers().param_groups[0]["params"] if p.requires_grad]
+
+
+def check_gated_net(g, dev="cpu", floor=1e-4):
+    """InpaintSANet forward (evaluation and training mode) against tests/golden/gated.npz"""
+    from golden_util import seeded_fill, smooth_field
+    from ocflow_amd.models.networks.gated_conv_inpainting_net import InpaintSANet
+    imgs = T(smooth_field((2, 3, 64, 96), seed=121, amp=1.0)).float().clamp(-1, 1)
+    masks = (T(smooth_field((2, 1, 64, 96), seed=122, amp=1.0)) > 0.3).float()
+    assert abs(float(imgs.abs().mean()) - float(g["imgs_absmean"])) < 1e-6 and abs(float(masks.mean()) - float(g["masks_mean"])) < 1e-7
+    worst = 0.0
+    for train in (False, True):
+        net = seeded_fill(InpaintSANet(img_size=(64, 96)), 17).to(dev)
+        if dev != "cpu":
+            net = net.to(memory_format=torch.channels_last)
+        net.train(train)
+        with torch.no_grad():
+            c, r = net(imgs.to(dev), masks.to(dev))
+        tag = "train" if train else "eval"
+        for name, got in ((f"net_{tag}_coarse", c), (f"net_{tag}_refined", r)):
+            err = float((got.float().cpu() - T(g[name])).abs().max())
+            assert err < max(floor, 3.0 * float(g[name + "__noise"])), (name, err)
+            worst = max(worst, err)
+    return worst
+
+
+GATED_HP = dict(learning_rate=1e-4, inpainting_stage="gated", loss_type="pixel-wise", using_pretrained_inpainting=False, img_size=(64, 96),
+                photo_weight=4.0, reconst_weight=1.0, smooth1_weight=0.5, smooth2_weight=0.0, pixelwise_weight=2.0, batch_size=2)
+
+
+def check_gated_step(m, g, dev="cpu", floor=1e-4, noise_mult=3.0):
+    """one training step of TwoStageModelGC(inpainting_stage='gated') against tests/golden/gated.npz (bars: max(floor, noise_mult x noise),
+    noise = the deviation of the reference's own fp32 run from its fp64 run)"""
+    from golden_util import seeded_fill, smooth_field
+    seeded_fill(m, 19)
+    m = m.to(dev).train()
+    x = T(smooth_field((2, 6, 64, 96), seed=123, amp=1.0)).float().clamp(-1, 1)
+    gt_flow = torch.randn((2, 2, 64, 96), generator=torch.Generator().manual_seed(124)) * 2
+    gt_occ = (torch.rand((2, 1, 64, 96), generator=torch.Generator().manual_seed(125)) < 0.3).float()
+    assert abs(float(x.abs().mean()) - float(g["x_absmean"])) < 1e-6 and abs(float(gt_occ.mean()) - float(g["gt_occ_mean"])) < 1e-7
+    batch = tuple(t.to(dev) for t in (x, gt_flow, gt_occ))
+    res = m.general_step(batch, 0, "train")
+    bar = lambda k: max(floor, noise_mult * float(g[k + "__noise"]))
+    got, want = torch.stack([r.detach().float().cpu() for r in res]), T(g["gs_scalars"])
+    assert float(((got - want).abs() / want.abs().clamp_min(1.0)).max()) < bar("gs_scalars"), (got, want)
+    loss = m._total(res, m.pixelwise_weight)
+    assert abs(float(loss.detach()) - float(g["gs_loss"])) < bar("gs_loss") * max(1.0, abs(float(g["gs_loss"])))
+    loss.backward()
+    params = dict(m.named_parameters())
+    worst = []
+    for k in [k for k in g if k.startswith("gs_grad__") and not k.endswith("__noise")]:
+        gr = params[k[len("gs_grad__"):]].grad.detach().float().cpu()
+        gr = gr[:8, :16] if gr.dim() >= 2 else gr
+        ref = T(g[k])
+        err = float((gr - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        worst.append((err / bar(k), err, k))
+    worst.sort(reverse=True)
+    assert len(worst) == 8 and worst[0][0] < 1.0, worst[:3]
+    return worst
+
+
+def test_gated_generator_cpu(cpu_ops, golden):
+    """SURVEY 8f-4, second half: InpaintSANet state_dict (keys, shapes, order: reference checkpoints load), its forward in both modes with
+    a non-zero attention gain (the score matrix is never materialised here: scaled_dot_product_attention with unit scale), and the
+    'gated' two-stage training step (models/model.py:1199-1256) against the reference's goldens"""
+    from ocflow_amd.models.model import TwoStageModelGC
+    from ocflow_amd.models.networks.gated_conv_inpainting_net import InpaintSANet, Self_Attn, get_pad
+    with open(os.path.join(GOLDEN, "state_dict_manifest_gated.json")) as f:
+        want = [(k, tuple(s)) for k, s in json.load(f)["inpaintsanet"]]
+    assert [(k, tuple(v.shape)) for k, v in InpaintSANet(img_size=(64, 96)).state_dict().items()] == want
+    assert get_pad((64, 96), 4, 2) == (1, 1) and get_pad(24, 3, 1, 16) == 16 and get_pad((33, 50), 5, 1) == (2, 2)
+    g = golden("gated")
+    check_gated_net(g)
+    check_gated_step(TwoStageModelGC(dict(GATED_HP)), g)
+    # the two evaluation orders of the attention block agree, and with_attn returns a row-stochastic map
+    torch.manual_seed(0)
+    a = Self_Attn(16, with_attn=True)
+    with torch.no_grad():
+        a.gamma.fill_(0.7)
+    xx = torch.randn(2, 16, 5, 7)
+    out, attn = a(xx)
+    a.with_attn = False
+    assert torch.allclose(a(xx), out, atol=1e-5) and torch.allclose(attn.sum(-1), torch.ones(2, 35), atol=1e-5)

@@ -260,3 +260,17 @@ def test_two_stage_gc_step_on_hip_kernels(golden):
     print("two-stage gradients, worst error / bar:", [(round(w[0], 3), f"{w[1]:.2e}", w[2]) for w in worst[:3]])
     for k in ("warp_fwd", "photo_fwd", "photo_bwd", "smooth_fwd", "smooth_bwd"):
         assert k in calls, (k, sorted(set(calls)))
+
+
+def test_gated_generator_and_step_on_the_gpu(golden):
+    """InpaintSANet (BatchNorm + LeakyReLU(0.2) of its gated layers through the HIP BatchNorm kernels on channels_last tensors, attention
+    through scaled_dot_product_attention) and the 'gated' two-stage step on the GPU against the reference's goldens (same checks as the
+    CPU test)"""
+    from test_host_models import GATED_HP, check_gated_net, check_gated_step
+    from ocflow_amd.models.model import TwoStageModelGC
+    g = golden("gated")
+    print("InpaintSANet worst abs error:", check_gated_net(g, DEV))
+    # 5 x the reference's own fp32 noise: the scalar gain of the attention block sums one product per feature value, and MIOpen's fp32
+    # convolutions add in another order than the CPU's (measured 2.1 % of its scale at a reference noise of 0.66 %)
+    worst = check_gated_step(TwoStageModelGC(dict(GATED_HP)), g, DEV, noise_mult=5.0)
+    print("gated step gradients, worst error / bar:", [(round(w[0], 3), f"{w[1]:.2e}", w[2]) for w in worst[:3]])
