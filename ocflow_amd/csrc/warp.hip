@@ -11,6 +11,14 @@
 
 namespace ocf {
 
+// FULL (host-checked: 16-byte aligned pixels, C a whole number of units): one vector load, no per-channel tail path.  load_unit_f's
+// vector-or-tail branch ends in a wait, so several of them in a row are dependent round trips however the source orders them.
+template <typename T, int VEC, bool FULL>
+__device__ __forceinline__ void load_unit_sel(const T4& t, long pix_off, int c0, int C, float* f) {
+  if (FULL) unit_to_f<T>(*(const u32x4*)(t.p + (pix_off + c0) * (long)sizeof(T)), f);
+  else load_unit_f<T, VEC>(t, pix_off, c0, C, f);
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void warp_fwd_kernel(T4 img, T4 flow, T4 out, int B, int C, int H, int W, float fs,
                                                        WarpGeom wg, long npix) {
@@ -55,7 +63,9 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(T4 img, T4 flow, T4 out, 
 // bilinear neighbour (coalesced) and the channel loop of warp_fwd_kernel becomes lane parallelism: 49 -> ~12 us at level 2
 // (8 x 32 x 109 x 256) and the small levels leave their sequential-latency regime (26 us for 8 x 196 x 7 x 16).
 // VEC = 16 / 8 as in load_unit_full (8: pixels that are a multiple of 8 bytes; the last unit may be a half unit).
-template <typename T, int VEC>
+// FULL: C is a whole number of units with VEC = 16 (host-checked): the loads have no per-channel tail path -- with it every tap is a
+// vector-or-tail branch that ends in a wait, i.e. the four taps are four dependent round trips however they are written
+template <typename T, int VEC, bool FULL = false>
 __global__ __launch_bounds__(256) void warp_fwd_cl_kernel(T4 img, T4 flow, T4 out, int B, int C, int H, int W, float fs, WarpGeom wg,
                                                           long total, int upp) {
   constexpr int U = Unit<T>::U;
@@ -69,23 +79,31 @@ __global__ __launch_bounds__(256) void warp_fwd_cl_kernel(T4 img, T4 flow, T4 ou
     const long fo = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
     const float uu = fl[fo] * fs, vv = fl[fo + flow.sc] * fs;
     const Bilin s = bilin_setup(((float)x + uu) * wg.ax + wg.bx, ((float)y + vv) * wg.ay + wg.by, H, W);
+    // all four neighbour loads are issued before the first use: a tap outside the image loads the output pixel's own position (always
+    // valid) and is skipped by a SELECT on the accumulator -- a branch per tap made the four loads four dependent round trips
+    const long own = (long)b * img.sb + (long)y * img.sh + (long)x * img.sw;
+    float f[4][U];
+    bool ok[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int ddx = n & 1, ddy = n >> 1;
+      ok[n] = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
+      const long off = ok[n] ? (long)b * img.sb + (long)(s.y0 + ddy) * img.sh + (long)(s.x0 + ddx) * img.sw : own;
+      if (FULL) unit_to_f<T>(*(const u32x4*)(img.p + (off + c0) * (long)sizeof(T)), f[n]);
+      else load_unit_f<T, VEC>(img, off, c0, C, f[n]);
+    }
     float a[U];
 #pragma unroll
     for (int j = 0; j < U; j++) a[j] = 0.f;
 #pragma unroll
     for (int n = 0; n < 4; n++) {
       const int ddx = n & 1, ddy = n >> 1;
-      const bool ok = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
-      if (ok) {
-        const float w = (ddx ? s.wx1 : 1.f - s.wx1) * (ddy ? s.wy1 : 1.f - s.wy1);
-        const long off = (long)b * img.sb + (long)(s.y0 + ddy) * img.sh + (long)(s.x0 + ddx) * img.sw;
-        float f[U];
-        load_unit_f<T, VEC>(img, off, c0, C, f);
+      const float w = (ddx ? s.wx1 : 1.f - s.wx1) * (ddy ? s.wy1 : 1.f - s.wy1);
 #pragma unroll
-        for (int j = 0; j < U; j++) a[j] = __builtin_fmaf(w, f[j], a[j]);
-      }
+      for (int j = 0; j < U; j++) a[j] = ok[n] ? __builtin_fmaf(w, f[n][j], a[j]) : a[j];
     }
-    store_unit_f<T, VEC>(out, (long)b * out.sb + (long)y * out.sh + (long)x * out.sw, c0, C, a);
+    if (FULL) *(u32x4*)(out.p + ((long)b * out.sb + (long)y * out.sh + (long)x * out.sw + c0) * (long)sizeof(T)) = f_to_unit<T>(a);
+    else store_unit_f<T, VEC>(out, (long)b * out.sb + (long)y * out.sh + (long)x * out.sw, c0, C, a);
   }
 }
 
@@ -319,8 +337,8 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(T4 flow, T4 gout, 
     float f0[NU][U], f1[NU][U];
 #pragma unroll
     for (int u = 0; u < NU; u++) {
-      gv.p = (char*)r0; load_unit_f<T, VEC>(gv, 0, u * U, C - c0, f0[u]);
-      gv.p = (char*)r1; load_unit_f<T, VEC>(gv, 0, u * U, C - c0, f1[u]);
+      gv.p = (char*)r0; load_unit_sel<T, VEC, false>(gv, 0, u * U, C - c0, f0[u]);
+      gv.p = (char*)r1; load_unit_sel<T, VEC, false>(gv, 0, u * U, C - c0, f1[u]);
     }
 #pragma unroll
     for (int u = 0; u < NU; u++)
@@ -433,7 +451,7 @@ __global__ __launch_bounds__(256) void warp_bwd_bin_kernel(T4 flow, int B, int H
     }
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool FULL = false>
 __global__ __launch_bounds__(256) void warp_bwd_gather_binned_kernel(T4 flow, T4 gout, T4 gimg, int B, int C, int H, int W, float fs,
                                                                      WarpGeom wg, int tiles_x, int tiles_y, const unsigned* cnt,
                                                                      const unsigned* bins) {
@@ -497,8 +515,8 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_binned_kernel(T4 flow, T4
     float f0[NU][U], f1[NU][U];
 #pragma unroll
     for (int u = 0; u < NU; u++) {
-      gv.p = (char*)r0; load_unit_f<T, VEC>(gv, 0, u * U, C - c0, f0[u]);
-      gv.p = (char*)r1; load_unit_f<T, VEC>(gv, 0, u * U, C - c0, f1[u]);
+      gv.p = (char*)r0; load_unit_sel<T, VEC, FULL>(gv, 0, u * U, C - c0, f0[u]);
+      gv.p = (char*)r1; load_unit_sel<T, VEC, FULL>(gv, 0, u * U, C - c0, f1[u]);
     }
 #pragma unroll
     for (int u = 0; u < NU; u++)
@@ -521,7 +539,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_binned_kernel(T4 flow, T4
 }
 
 // kernel B: lanes = (source pixel, 16-byte channel unit).  UPP = units per pixel (a power of two <= 64 so that a pixel's lanes share a wave)
-template <typename T, int VEC>
+template <typename T, int VEC, bool FULL = false>
 __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(T4 img, T4 flow, T4 gout, T4 gimg, T4 gflow, int B, int C, int H, int W, float fs,
                                                             WarpGeom wg, long total, int upp, int upp_pad, const unsigned* ovf_cnt,
                                                             const unsigned* ovf, int tiles_x, int tiles_y) {
@@ -542,18 +560,19 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(T4 img, T4 flow, T4 
   const Bilin s = bilin_setup(((float)x + uu) * wg.ax + wg.bx, ((float)y + vv) * wg.ay + wg.by, H, W);
   if (on) {
     float g[U], v[4][U];
-    load_unit_f<T, VEC>(gout, (long)b * gout.sb + (long)y * gout.sh + (long)x * gout.sw, c0, C, g);
+    bool ok[4];
+    load_unit_sel<T, VEC, FULL>(gout, (long)b * gout.sb + (long)y * gout.sh + (long)x * gout.sw, c0, C, g);
 #pragma unroll
-    for (int n = 0; n < 4; n++) {
+    for (int n = 0; n < 4; n++) {  // (all five loads in flight before the first use: the masks are applied afterwards)
       const int ddx = n & 1, ddy = n >> 1;
-      const bool ok = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
+      ok[n] = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
       const int xc = min(max(s.x0 + ddx, 0), W - 1), yc = min(max(s.y0 + ddy, 0), H - 1);
-      load_unit_f<T, VEC>(img, (long)b * img.sb + (long)yc * img.sh + (long)xc * img.sw, c0, C, v[n]);
-      if (!ok) {
-#pragma unroll
-        for (int k = 0; k < U; k++) v[n][k] = 0.f;
-      }
+      load_unit_sel<T, VEC, FULL>(img, (long)b * img.sb + (long)yc * img.sh + (long)xc * img.sw, c0, C, v[n]);
     }
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+      for (int k = 0; k < U; k++) v[n][k] = ok[n] ? v[n][k] : 0.f;
 #pragma unroll
     for (int k = 0; k < U; k++) {
       gx = __builtin_fmaf(g[k], (1.f - s.wy1) * (v[1][k] - v[0][k]) + s.wy1 * (v[3][k] - v[2][k]), gx);
@@ -662,7 +681,9 @@ static int warp_fwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
     const long total = npix * upp;
     const dim3 g2(grid_for(total)), b2(256);
     LaunchProf lp;
-    if (vec == 16)
+    if (vec == 16 && C % Unit<T>::U == 0)
+      lp.launch(true, warp_fwd_cl_kernel<T, 16, true>, g2, b2, 0, st, mk(img), mk(flow), mk(out), B, C, H, W, fs, wg, total, upp);
+    else if (vec == 16)
       lp.launch(true, warp_fwd_cl_kernel<T, 16>, g2, b2, 0, st, mk(img), mk(flow), mk(out), B, C, H, W, fs, wg, total, upp);
     else
       lp.launch(true, warp_fwd_cl_kernel<T, 8>, g2, b2, 0, st, mk(img), mk(flow), mk(out), B, C, H, W, fs, wg, total, upp);
@@ -735,13 +756,20 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
         if (hipMemsetAsync(cnt, 0, (size_t)warp_ws_counters(tiles) * 4, st) != hipSuccess) return OCF_ELAUNCH;
         LaunchProf lp;
         lp.launch(false, warp_bwd_bin_kernel, dim3((unsigned)tiles), dim3(256), 0, st, mk(flow), B, H, W, fs, wg, tx, ty, cnt, bins, ovf, npix);
-        if (vec == 16)
+        const bool full32 = vec == 16 && C % 32 == 0, full = vec == 16 && C % Unit<T>::U == 0;  // (see load_unit_sel)
+        if (full32)
+          lp.launch(false, warp_bwd_gather_binned_kernel<T, 16, true>, dim3((unsigned)tiles, (unsigned)(C / 32)), dim3(256), 0, st, mk(flow),
+                    mk(gout), mk(gimg), B, C, H, W, fs, wg, tx, ty, (const unsigned*)cnt, (const unsigned*)bins);
+        else if (vec == 16)
           lp.launch(false, warp_bwd_gather_binned_kernel<T, 16>, dim3((unsigned)tiles, (unsigned)((C + 31) / 32)), dim3(256), 0, st, mk(flow),
                     mk(gout), mk(gimg), B, C, H, W, fs, wg, tx, ty, (const unsigned*)cnt, (const unsigned*)bins);
         else
           lp.launch(false, warp_bwd_gather_binned_kernel<T, 8>, dim3((unsigned)tiles, (unsigned)((C + 31) / 32)), dim3(256), 0, st, mk(flow),
                     mk(gout), mk(gimg), B, C, H, W, fs, wg, tx, ty, (const unsigned*)cnt, (const unsigned*)bins);
-        if (vec == 16)
+        if (full)
+          lp.launch(true, warp_bwd_flow_kernel<T, 16, true>, gb, dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, fs,
+                    wg, totalb, upp, upp_pad, (const unsigned*)(cnt + tiles), (const unsigned*)ovf, tx, ty);
+        else if (vec == 16)
           lp.launch(true, warp_bwd_flow_kernel<T, 16>, gb, dim3(256), 0, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, fs, wg,
                     totalb, upp, upp_pad, (const unsigned*)(cnt + tiles), (const unsigned*)ovf, tx, ty);
         else
