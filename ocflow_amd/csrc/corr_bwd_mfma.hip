@@ -465,6 +465,10 @@ __device__ __forceinline__ Item item_of(int it, int tiles_x, int tiles_y, int cb
 }
 
 // halo tile of the other operand (w2 for g1, f1 for g2): chunk tid of every halo row, then chunks 256..319 (wave w: rows w, w + 4, w + 8)
+// (The issue functions only LOAD -- raw values, clamped addresses; validity masks, the tail-chunk shift and the occlusion product are
+// applied by the commit functions, which recompute the conditions.  With the mask applied right after each load the compiler kept
+// program order and put an `s_waitcnt vmcnt(0)` behind every one of the twelve window loads of the g2 pass: twelve dependent round
+// trips instead of one.)
 template <bool OCC>
 __device__ __forceinline__ void issue_other(const Lane& L, const Item& t, const T4& other, const T4& occ, int C, int H, int W, u32x2* sv, float* so) {
   const int osh = (int)other.sh, osw = (int)other.sw;
@@ -473,7 +477,6 @@ __device__ __forceinline__ void issue_other(const Lane& L, const Item& t, const 
   const int c0c = c0 < C ? c0 : 0;
   const int pA = L.tid >> 3, pB = 32 + ((L.tid & 63) >> 3);
   const int gxA = t.tx0 - D + pA, gxB = t.tx0 - D + pB;
-  const bool okA = gxA >= 0 && gxA < W && c0 < C, okB = gxB >= 0 && gxB < W && c0 < C;
   const int gxAc = gxA < 0 ? 0 : (gxA >= W ? W - 1 : gxA), gxBc = gxB >= W ? W - 1 : gxB;
   const int offA = (gxAc * osw + c0c) * 2, offB = (gxBc * osw + c0c) * 2;
   const float* occb = OCC ? (const float*)occ.p + (long)t.b * occ.sb : nullptr;
@@ -483,20 +486,23 @@ __device__ __forceinline__ void issue_other(const Lane& L, const Item& t, const 
     const int hr = r < HR ? r : L.w + 4 * (r - HR);
     const int gy = t.ty0 - D + hr;
     const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
-    const u32x2 ld = *(const u32x2*)(obase + (unsigned)(gyc * osh * 2 + (r < HR ? offA : offB)));
-    const unsigned m = ((r < HR ? okA : okB) && gy >= 0 && gy < H) ? 0xffffffffu : 0u;
-    sv[r] = u32x2{ld[0] & m, ld[1] & m};
+    sv[r] = *(const u32x2*)(obase + (unsigned)(gyc * osh * 2 + (r < HR ? offA : offB)));
     if (OCC) so[r] = occb[(unsigned)(gyc * csh + (r < HR ? gxAc : gxBc))];
   }
 }
 
 template <bool OCC, int FP>
-__device__ __forceinline__ void commit_other(const Lane& L, char* s_f, const u32x2* sv, const float* so) {
-  const int u8 = L.tid & 7;
+__device__ __forceinline__ void commit_other(const Lane& L, const Item& t, char* s_f, const u32x2* sv, const float* so, int C, int H, int W) {
+  const int u8 = L.tid & 7, c0 = t.cbase + 4 * u8;
   const int pA = L.tid >> 3, pB = 32 + ((L.tid & 63) >> 3);
+  const int gxA = t.tx0 - D + pA, gxB = t.tx0 - D + pB;
+  const bool okA = gxA >= 0 && gxA < W && c0 < C, okB = gxB >= 0 && gxB < W && c0 < C;
 #pragma unroll
   for (int r = 0; r < HR + 3; r++) {
-    u32x2 v = sv[r];
+    const int hr = r < HR ? r : L.w + 4 * (r - HR);
+    const int gy = t.ty0 - D + hr;
+    const unsigned m = ((r < HR ? okA : okB) && gy >= 0 && gy < H) ? 0xffffffffu : 0u;
+    u32x2 v = u32x2{sv[r][0] & m, sv[r][1] & m};
     if (OCC) {  // rounded like the materialised product w2 * occ
       const float o = so[r];
       const float f0 = __builtin_bit_cast(float, v[0] << 16) * o, f1 = __builtin_bit_cast(float, v[0] & 0xffff0000u) * o;
@@ -504,7 +510,6 @@ __device__ __forceinline__ void commit_other(const Lane& L, char* s_f, const u32
       const bf16x2 lo2 = {(bf16)f0, (bf16)f1}, hi2 = {(bf16)f2, (bf16)f3};
       v = u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
     }
-    const int hr = r < HR ? r : L.w + 4 * (r - HR);
     *(u32x2*)(s_f + (hr * HWP + (r < HR ? pA : pB)) * FP + u8 * 8) = v;
   }
 }
@@ -515,28 +520,28 @@ __device__ __forceinline__ void commit_other(const Lane& L, char* s_f, const u32
 __device__ __forceinline__ void issue_g1(const Lane& L, const Item& t, const T4& g, int H, int W, u32x2* gi) {
   const char* gbase = g.p + (long)t.b * g.sb * 2;
   const int p0 = L.tid / GI_CH, ch = L.tid - p0 * GI_CH;
-  const bool tail = ch == GI_CH - 1;
-  const int coff = tail ? NK * 2 - 8 : ch * 8;
+  const int coff = ch == GI_CH - 1 ? NK * 2 - 8 : ch * 8;
 #pragma unroll
   for (int k = 0; k < GIT; k++) {
     const int px = p0 + GPX * k;
     const int pr = px >> 5, pc = px & 31;  // (TW == 32)
     const int gy = t.ty0 + pr, gx = t.tx0 + pc;
     const bool ok = L.tid < GPX * GI_CH && px < TH * TW && gy < H && gx < W;
-    const char* src = gbase + (unsigned)(((ok ? gy : 0) * L.gsh + (ok ? gx : 0) * L.gsw) * 2 + coff);
-    u32x2 v = ((const U8B*)src)->v;
-    if (tail) v = u32x2{v[1] >> 16, 0u};
-    const unsigned m = ok ? 0xffffffffu : 0u;
-    gi[k] = u32x2{v[0] & m, v[1] & m};
+    gi[k] = ((const U8B*)(gbase + (unsigned)(((ok ? gy : 0) * L.gsh + (ok ? gx : 0) * L.gsw) * 2 + coff)))->v;
   }
 }
 
-__device__ __forceinline__ void commit_g1(const Lane& L, char* s_g, const u32x2* gi) {
+__device__ __forceinline__ void commit_g1(const Lane& L, const Item& t, char* s_g, const u32x2* gi, int H, int W) {
   const int p0 = L.tid / GI_CH, ch = L.tid - p0 * GI_CH;
+  const bool tail = ch == GI_CH - 1;
 #pragma unroll
   for (int k = 0; k < GIT; k++) {
     const int px = p0 + GPX * k;
-    if (L.tid < GPX * GI_CH && px < TH * TW) *(u32x2*)(s_g + GI_FRONT + px * GIP + ch * 8) = gi[k];
+    const int pr = px >> 5, pc = px & 31;
+    const bool ok = t.ty0 + pr < H && t.tx0 + pc < W;
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    const u32x2 v = tail ? u32x2{(gi[k][1] >> 16) & m, 0u} : u32x2{gi[k][0] & m, gi[k][1] & m};
+    if (L.tid < GPX * GI_CH && px < TH * TW) *(u32x2*)(s_g + GI_FRONT + px * GIP + ch * 8) = v;
   }
 }
 
@@ -545,16 +550,13 @@ __device__ __forceinline__ void issue_g2(const Lane& L, const Item& t, const T4&
   const char* gbase = g.p + (long)t.b * g.sb * 2;
   const int pA = L.tid / WCH, cA = L.tid - pA * WCH;
   const int gxA = t.tx0 - D + pA;
-  const bool okA = gxA >= 0 && gxA < W;
   const int offA = (gxA < 0 ? 0 : (gxA >= W ? W - 1 : gxA)) * L.gsw * 2 + cA * 8;
 #pragma unroll
   for (int r = 0; r < HR; r++) {
     const int gy = t.ty0 - D + r;
     const int ws = 8 - r < 0 ? 0 : (8 - r > 5 ? 5 : 8 - r);
     const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
-    const u32x2 ld = ((const U8B*)(gbase + (unsigned)(gyc * L.gsh * 2 + ws * (N * 2) + offA)))->v;
-    const unsigned m = (okA && gy >= 0 && gy < H) ? 0xffffffffu : 0u;
-    va[r] = u32x2{ld[0] & m, ld[1] & m};
+    va[r] = ((const U8B*)(gbase + (unsigned)(gyc * L.gsh * 2 + ws * (N * 2) + offA)))->v;
   }
 #pragma unroll
   for (int j = 0; j < WSB; j++) {
@@ -565,22 +567,28 @@ __device__ __forceinline__ void issue_g2(const Lane& L, const Item& t, const T4&
     const int gy = t.ty0 - D + r, gx = t.tx0 - D + px;
     const int ws = 8 - r < 0 ? 0 : (8 - r > 5 ? 5 : 8 - r);
     const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-    const u32x2 ld = ((const U8B*)(gbase + (unsigned)((gyc * L.gsh + gxc * L.gsw + ws * N) * 2 + c * 8)))->v;
-    const unsigned m = (it < WNB && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xffffffffu : 0u;
-    vb[j] = u32x2{ld[0] & m, ld[1] & m};
+    vb[j] = ((const U8B*)(gbase + (unsigned)((gyc * L.gsh + gxc * L.gsw + ws * N) * 2 + c * 8)))->v;
   }
 }
 
-__device__ __forceinline__ void commit_g2(const Lane& L, char* s_g, const u32x2* va, const u32x2* vb) {
+__device__ __forceinline__ void commit_g2(const Lane& L, const Item& t, char* s_g, const u32x2* va, const u32x2* vb, int H, int W) {
   const int pA = L.tid / WCH, cA = L.tid - pA * WCH;
+  const int gxA = t.tx0 - D + pA;
+  const bool okA = gxA >= 0 && gxA < W;
 #pragma unroll
-  for (int r = 0; r < HR; r++) *(u32x2*)(s_g + r * (HWP * GP) + pA * GP + cA * 8) = va[r];
+  for (int r = 0; r < HR; r++) {
+    const int gy = t.ty0 - D + r;
+    const unsigned m = (okA && gy >= 0 && gy < H) ? 0xffffffffu : 0u;
+    *(u32x2*)(s_g + r * (HWP * GP) + pA * GP + cA * 8) = u32x2{va[r][0] & m, va[r][1] & m};
+  }
 #pragma unroll
   for (int j = 0; j < WSB; j++) {
     const int it = L.tid + 256 * j;
     const int r = it / (WRC - 256), chn = 256 + it - r * (WRC - 256);
     const int px = chn / WCH, c = chn - px * WCH;
-    if (it < WNB) *(u32x2*)(s_g + (r * HWP + px) * GP + c * 8) = vb[j];
+    const int gy = t.ty0 - D + r, gx = t.tx0 - D + px;
+    const unsigned m = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xffffffffu : 0u;
+    if (it < WNB) *(u32x2*)(s_g + (r * HWP + px) * GP + c * 8) = u32x2{vb[j][0] & m, vb[j][1] & m};
   }
 }
 
@@ -652,6 +660,23 @@ __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const c
   for (int s = 0; s < 2; s++)
 #pragma unroll
     for (int nb = 0; nb < 2; nb++) acc[s][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the epilogue's own operands (this pixel's mask value, this lane's four channels of the warped features for d/docc) are requested
+  // BEFORE the matrix-core loop: loaded inside the epilogue they were four dependent round trips after the last MFMA
+  float oo[2] = {1.f, 1.f};
+  u32x2 wv[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int x = t.tx0 + 16 * s + i;
+    const int yc = y < H ? y : H - 1, xc = x < W ? x : W - 1;
+    if (OCC) oo[s] = ((const float*)occ.p)[(long)t.b * occ.sb + (unsigned)(yc * (int)occ.sh + xc * (int)occ.sw)];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+      const int c0 = t.cbase + 16 * nb + 4 * G;
+      wv[s][nb] = u32x2{0u, 0u};  // (raw, from a clamped address: the epilogue only uses it for live pixels / channels)
+      if (OCC && gocc.p)
+        wv[s][nb] = *(const u32x2*)(w2own.p + (long)t.b * w2own.sb * 2 + (unsigned)((yc * (int)w2own.sh + xc * (int)w2own.sw + (c0 < C ? c0 : 0)) * 2));
+    }
+  }
   unsigned gm[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -686,13 +711,23 @@ __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const c
       }
     }
   }
+  // the prefetched epilogue operands are CONSUMED here, while no store is outstanding: the stores below are conditional, the compiler
+  // cannot count them, and a wait for these loads placed after the first store becomes `vmcnt(0)` = wait for the stores as well
+  if (OCC) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      asm volatile("" : "+v"(oo[s]));
+#pragma unroll
+      for (int nb = 0; nb < 2; nb++) asm volatile("" : "+v"(wv[s][nb][0]), "+v"(wv[s][nb][1]));
+    }
+  }
   const float invC = 1.f / (float)C;
 #pragma unroll
   for (int s = 0; s < 2; s++) {
     const int x = t.tx0 + 16 * s + i;
     const bool inimg = y < H && x < W;
-    float o = 1.f, part = 0.f;
-    if (OCC && inimg) o = ((const float*)occ.p)[(long)t.b * occ.sb + y * (int)occ.sh + x * (int)occ.sw];
+    const float o = oo[s];
+    float part = 0.f;
 #pragma unroll
     for (int nb = 0; nb < 2; nb++) {
       const int c0 = t.cbase + 16 * nb + 4 * G;
@@ -702,11 +737,11 @@ __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const c
       for (int r = 0; r < 4; r++) v[r] = acc[s][nb][r] * invC;
       if (OCC) {
         if (gocc.p && live) {  // the reference chain rounds the gradient w.r.t. (w2*occ) to the feature dtype before this product
-          const u32x2 wv = *(const u32x2*)(w2own.p + (long)t.b * w2own.sb * 2 + (y * (int)w2own.sh + x * (int)w2own.sw + c0) * 2);
-          part = __builtin_fmaf((float)(bf16)v[0], __builtin_bit_cast(float, wv[0] << 16), part);
-          part = __builtin_fmaf((float)(bf16)v[1], __builtin_bit_cast(float, wv[0] & 0xffff0000u), part);
-          part = __builtin_fmaf((float)(bf16)v[2], __builtin_bit_cast(float, wv[1] << 16), part);
-          part = __builtin_fmaf((float)(bf16)v[3], __builtin_bit_cast(float, wv[1] & 0xffff0000u), part);
+          const u32x2 w4 = wv[s][nb];
+          part = __builtin_fmaf((float)(bf16)v[0], __builtin_bit_cast(float, w4[0] << 16), part);
+          part = __builtin_fmaf((float)(bf16)v[1], __builtin_bit_cast(float, w4[0] & 0xffff0000u), part);
+          part = __builtin_fmaf((float)(bf16)v[2], __builtin_bit_cast(float, w4[1] << 16), part);
+          part = __builtin_fmaf((float)(bf16)v[3], __builtin_bit_cast(float, w4[1] & 0xffff0000u), part);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] = (float)(bf16)v[r] * o;
@@ -746,16 +781,16 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_mfma_par_lds(T4 f1, T4 w2, T4
     R1 r1;
     issue_g1(L, t, g, H, W, r1.gi);
     issue_other<OCC>(L, t, w2, occ, C, H, W, r1.sv, r1.so);
-    commit_g1(L, smem + SF1, r1.gi);
-    commit_other<OCC, FP1>(L, smem, r1.sv, r1.so);
+    commit_g1(L, t, smem + SF1, r1.gi, H, W);
+    commit_other<OCC, FP1>(L, t, smem, r1.sv, r1.so, C, H, W);
     __syncthreads();
     compute_g1(L, t, smem, smem + SF1, g1, C, H, W);
   } else {
     R2 r2;
     issue_g2(L, t, g, H, W, r2.va, r2.vb);
     issue_other<false>(L, t, f1, occ, C, H, W, r2.sv, nullptr);
-    commit_g2(L, smem + SF2, r2.va, r2.vb);
-    commit_other<false, FP2>(L, smem, r2.sv, nullptr);
+    commit_g2(L, t, smem + SF2, r2.va, r2.vb, H, W);
+    commit_other<false, FP2>(L, t, smem, r2.sv, nullptr, C, H, W);
     __syncthreads();
     compute_g2<OCC>(L, t, smem, smem + SF2, g2, occ, w2, gocc, C, H, W);
   }
