@@ -20,11 +20,10 @@ FlyingChairs (`*.ppm` pairs + `*.flo`, datasets.py:465-530) and FlyingChairs2 (`
 :587-669 -- the dataset of the reference's shipped `config/unsupervised_config.yml`) share the sample rules; only the file pairing differs."""
 from __future__ import annotations
 
-import os
 from glob import glob
 from math import ceil
 from os.path import isfile, join, splitext
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
