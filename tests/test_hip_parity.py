@@ -290,6 +290,40 @@ def test_losses_strided_views(ops):
     close(torch.autograd.grad(L, fl)[0], gref, 1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 2, 3), (2, 5, 70), (1, 9, 64), (1, 33, 129), (3, 8, 65), (1, 17, 2)])
+@pytest.mark.parametrize("layout", ["nchw", "pair_cl"])
+def test_loss_kernels_odd_shapes(ops, shape, layout):
+    """the column-walking smoothness kernels (8-row strips of 64 columns, register window, one-row lookahead), the photometric kernels and
+    the fixed-point range map at shapes with partial strips, fewer rows / columns than the window, one-pixel maps -- both image layouts --
+    against the oracle: losses, flow gradients, range map"""
+    B_, H, W = shape
+    gen = torch.Generator().manual_seed(H * 131 + W)
+    img1, img2 = torch.rand((B_, 3, H, W), generator=gen) * 2 - 1, torch.rand((B_, 3, H, W), generator=gen) * 2 - 1
+    flow = torch.randn((B_, 2, H, W), generator=gen) * 1.5
+    occ = (torch.rand((B_, 1, H, W), generator=gen) < 0.3).float()
+    fr = flow.clone().requires_grad_()
+    s1r, s2r = O.first_order_smoothness_loss(img1, fr), O.second_order_smoothness_loss(img1, fr)
+    pr = O.photometric_error(O.warp(img2, fr, True), img1, occ)
+    d1, d2 = img1.to(DEV), img2.to(DEV)
+    if layout == "pair_cl":
+        pair = torch.cat((d1, d2), 1).contiguous(memory_format=torch.channels_last)
+        d1, d2 = pair[:, 0:3], pair[:, 3:6]
+    fd = flow.to(DEV).requires_grad_()
+    s1, s2 = ops.smoothness_losses(d1, fd)
+    p = ops.warp_photometric_error(d1, d2, fd, occ.to(DEV))
+    for got, ref in ((s1, s1r), (s2, s2r), (p, pr)):
+        if torch.isnan(ref):  # the mean over an empty set of differences (one-pixel axis): nan in the reference too
+            assert torch.isnan(got.cpu())
+        else:
+            close(got, ref, 2e-5)
+    terms = [(a, b) for a, b in ((s1, s1r), (s2, s2r), (p, pr)) if not torch.isnan(b)]
+    if terms:
+        (gd,) = torch.autograd.grad(sum(a for a, _ in terms), fd)
+        (gr,) = torch.autograd.grad(sum(b for _, b in terms), fr)
+        close(gd, gr, 5e-5)
+    close(ops.compute_range_map(flow.to(DEV)), O.compute_range_map(flow), 1e-5)
+
+
 # --------------------------------------------------------------------------------------------- range map
 @pytest.mark.parametrize("tag", ["a", "b", "zero"])
 def test_range_map_golden(ops, golden, tag):
