@@ -68,8 +68,10 @@ __global__ __launch_bounds__(LB) void photo_fwd_kernel(T4 img1, T4 img2, T4 flow
     const int x = idx % W;
     long r = idx / W;
     const int y = r % H, b = r / H;
-    const float vis = occ.p ? 1.f - ((const float*)occ.p)[(long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw] : 1.f;
+    // (the mask value is loaded from an always-valid address and selected afterwards: a load inside the `occ.p ?` branch is waited for at
+    // the join, which made it a round trip of its own in front of the flow -> taps chain)
     const long o1 = (long)b * img1.sb + (long)y * img1.sh + (long)x * img1.sw;
+    const float occ_raw = *(occ.p ? (const float*)occ.p + ((long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw) : i1 + o1);
     float e = 0.f;
     if (CT == 3 && flow.p && img1.sc == 1 && img2.sc == 1) {
       // channels_last RGB (in the model: the two halves of a six-channel image pair): a tap is ONE 12-byte load instead of three 4-byte
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(LB) void photo_fwd_kernel(T4 img1, T4 img2, T4 flow
       const long o2 = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
       OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) e += charb(i2[o2 + (long)c * img2.sc] - i1[o1 + (long)c * img1.sc]);
     }
+    const float vis = occ.p ? 1.f - occ_raw : 1.f;
     part[0] = __builtin_fmaf(e, vis, part[0]);
     part[1] += vis;
   }
@@ -121,9 +124,10 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
     const int x = idx % W;
     long r = idx / W;
     const int y = r % H, b = r / H;
-    const float vis = occ.p ? 1.f - ((const float*)occ.p)[(long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw] : 1.f;
+    // (the mask value is loaded from an always-valid address and selected afterwards: a load inside the `occ.p ?` branch is waited for at
+    // the join, which made it a round trip of its own in front of the flow -> taps chain)
     const long o1 = (long)b * img1.sb + (long)y * img1.sh + (long)x * img1.sw;
-    const float k = sc * vis;
+    const float occ_raw = *(occ.p ? (const float*)occ.p + ((long)b * occ.sb + (long)y * occ.sh + (long)x * occ.sw) : i1 + o1);
     if (CT == 3 && flow.p && img1.sc == 1 && img2.sc == 1) {  // channels_last RGB: packed 12-byte loads (see photo_fwd_kernel)
       const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
       const long own = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
 #pragma unroll
       for (int n = 0; n < 4; n++) t[n] = *(const F3*)(i2 + (p.off[n] >= 0 ? p.off[n] : own));
       const F3 a = *(const F3*)(i1 + o1);
+      const float k = sc * (occ.p ? 1.f - occ_raw : 1.f);
       float gx = 0.f, gy = 0.f;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
       }
     } else if (flow.p) {
       const PhotoPix p = photo_setup(img2, flow, b, y, x, H, W, wg);
+      const float k = sc * (occ.p ? 1.f - occ_raw : 1.f);
       float gx = 0.f, gy = 0.f;
       OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) {
         float nb[4];
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(LB) void photo_bwd_kernel(T4 img1, T4 img2, T4 flow
       const long o2 = (long)b * img2.sb + (long)y * img2.sh + (long)x * img2.sw;
       float* gp = (float*)gpred.p;
       const long og = (long)b * gpred.sb + (long)y * gpred.sh + (long)x * gpred.sw;
+      const float k = sc * (occ.p ? 1.f - occ_raw : 1.f);
       OCF_UNROLL_CT for (int c = 0; c < (CT ? CT : C); c++) {
         const float dlt = i2[o2 + (long)c * img2.sc] - i1[o1 + (long)c * img1.sc];
         gp[og + (long)c * gpred.sc] = k * dlt / charb(dlt);
