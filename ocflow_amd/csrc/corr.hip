@@ -651,9 +651,9 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
                       const ocf_tensor4* g2, int B, int C, int H, int W, int d, int policy, hipStream_t st, const ocf_tensor4* occ = nullptr,
                       const ocf_tensor4* gocc = nullptr) {
   constexpr int U = Unit<T>::U;
-  if (gocc && hipMemsetAsync(gocc->data, 0, sizeof(float) * (size_t)B * H * W, st) != hipSuccess) return OCF_ELAUNCH;
   if (sizeof(T) == 2 && corr_bwd_mfma_eligible(f1, w2, g, g1, g2, B, C, H, W, d, policy))
-    return corr_bwd_bf16_mfma(f1, w2, g, g1, g2, B, C, H, W, st, occ, gocc);
+    return corr_bwd_bf16_mfma(f1, w2, g, g1, g2, B, C, H, W, st, occ, gocc);  // (zeroes d/docc itself where its kernel accumulates into it)
+  if (gocc && hipMemsetAsync(gocc->data, 0, sizeof(float) * (size_t)B * H * W, st) != hipSuccess) return OCF_ELAUNCH;
   bool vec = vec_ok<T>(f1) && vec_ok<T>(w2);
   if (g1) vec = vec && vec_ok<T>(g1);
   if (g2) vec = vec && vec_ok<T>(g2);

@@ -755,7 +755,11 @@ __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const c
     if (OCC && gocc.p) {  // one fp32 atomic per pixel and channel block (the four lane groups reduced by shuffle)
       part += __shfl_xor(part, 16, 64);
       part += __shfl_xor(part, 32, 64);
-      if (inimg && G == 0) atomicAdd((float*)gocc.p + (long)t.b * gocc.sb + (y * (int)gocc.sh + x * (int)gocc.sw), part);
+      if (inimg && G == 0) {
+        float* go = (float*)gocc.p + (long)t.b * gocc.sb + (y * (int)gocc.sh + x * (int)gocc.sw);
+        if (gridDim.y == 1) *go = part;  // (one channel block: this lane owns the pixel's value; the launcher did not zero the tensor)
+        else atomicAdd(go, part);
+      }
     }
   }
 }
@@ -822,7 +826,6 @@ int corr_bwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_t
 #else
   constexpr int ablate = 0;
 #endif
-  LaunchProf lp;
   // the gradient through LDS when it arrives as a slice of a wider tensor (pixel pitch != 81 elements): see the note above the kernel
   bool g1_lds = g->sw != NK;
 #ifdef OCF_TUNING_BUILD
@@ -841,6 +844,11 @@ int corr_bwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_t
 #else
   constexpr bool par_phase = true;
 #endif
+  // d/docc: with ONE channel block every pixel's value is written by exactly one lane of the phase-function kernel (plain store, no
+  // zero-fill launch); with several channel blocks -- and in the other kernels -- it is accumulated with float atomics into zeroed memory
+  const bool gocc_store = par && g1_lds && par_phase && C <= 32;
+  if (gocc && gocc->data && !gocc_store && hipMemsetAsync(gocc->data, 0, sizeof(float) * (size_t)B * H * W, st) != hipSuccess) return OCF_ELAUNCH;
+  LaunchProf lp;
   if (par) {
     const dim3 grid2((unsigned)(B * tx * ty), (unsigned)((C + 31) / 32), 2u);
     const bool has_occ = occ && occ->data;
