@@ -95,18 +95,34 @@ def _padded_shape_is_known(n: int, c: int, h: int, w: int) -> bool:
     return (n, c, h, w) in _DB_INPUTS
 
 
+_WZEROS = {}  # (device, dtype, shape, channels_last) -> read-only zero block appended to weights of that shape
+
+
+def _zero_weight_block(weight, shape, cl):
+    key = (weight.device, weight.dtype, tuple(shape), cl)
+    z = _WZEROS.get(key)
+    if z is None:
+        z = weight.new_zeros(shape)
+        if cl:
+            z = z.contiguous(memory_format=torch.channels_last)
+        if not (weight.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _WZEROS[key] = z
+    return z
+
+
 class _PadInChannels(torch.autograd.Function):
-    """weight with zero input channels appended, in the weight's own memory format: one fill + one copy forward, one copy backward
-    (F.pad + .contiguous(channels_last) and their autograd took 5-6 launches per layer and step)"""
+    """weight with zero input channels appended, in the weight's own memory format: ONE launch forward (a concatenation with a shared
+    read-only zero block), one copy backward (F.pad + .contiguous(channels_last) and their autograd took 5-6 launches per layer and step)"""
 
     @staticmethod
     def forward(ctx, weight, cin, dim):
         shape = list(weight.shape)
-        shape[dim] = cin
+        shape[dim] = cin - weight.shape[dim]
         cl = weight.dim() == 4 and weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous()
         fmt = torch.channels_last if cl else torch.contiguous_format
-        out = torch.empty(shape, dtype=weight.dtype, device=weight.device, memory_format=fmt).zero_()
-        out.narrow(dim, 0, weight.shape[dim]).copy_(weight)
+        out = torch.cat((weight, _zero_weight_block(weight, shape, cl)), dim)
+        if not out.is_contiguous(memory_format=fmt):
+            out = out.contiguous(memory_format=fmt)
         ctx.cfg = (dim, weight.shape[dim], fmt)
         return out
 

@@ -273,4 +273,3 @@ def test_gated_generator_and_step_on_the_gpu(golden):
     # 5 x the reference's own fp32 noise: the scalar gain of the attention block sums one product per feature value, and MIOpen's fp32
     # convolutions add in another order than the CPU's (measured 2.1 % of its scale at a reference noise of 0.66 %)
     worst = check_gated_step(TwoStageModelGC(dict(GATED_HP)), g, DEV, noise_mult=5.0)
-    print("gated step gradients, worst error / bar:", [(round(w[0], 3), f"{w[1]:.2e}", w[2]) for w in worst[:3]])
