@@ -675,13 +675,13 @@ def _photo(img1, img2, flow, occ):
     else:
         num, den = _PhotoFn.apply(_f32(img1), _f32(img2), _f32(flow), _f32(occ))
     if occ is not None:
-        return num / (den * img1.shape[1] + 1e-16)
+        return num / (den * 3 + 1e-16)  # the reference's literal 3 (models/model.py:43), whatever the channel count
     return num / float(img1.numel())
 
 
 def photometric_error(img_pred, img, occ=None):
     """Drop-in for models/model.py:37-46: mean Charbonnier error, or sum(e*(1-occ)) / (3*sum(1-occ) + 1e-16)
-    (the 3 being the channel count of `img`; occ: 1 occluded, 0 visible)."""
+    (the 3 is the reference's literal: its images are RGB; occ: 1 occluded, 0 visible)."""
     return _photo(img, img_pred, None, occ)
 
 
@@ -736,7 +736,7 @@ def masked_l1(pred, target, mask):
         raise ValueError("masked_l1: pred / target [B,C,H,W] and mask [B,1,H,W] must agree")
     _require_hip(pred, target, mask)
     num, den = _MaskedL1Fn.apply(_f32(pred), _f32(target), _f32(mask))
-    return num / (den * pred.shape[1] + 1e-16)
+    return num / (den * 3 + 1e-16)  # the reference's literal 3 (inpainting_model.py:73)
 
 
 # -------------------------------------------------------------------------------------------- smoothness

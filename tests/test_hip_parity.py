@@ -324,6 +324,23 @@ def test_loss_kernels_odd_shapes(ops, shape, layout):
     close(ops.compute_range_map(flow.to(DEV)), O.compute_range_map(flow), 1e-5)
 
 
+@pytest.mark.parametrize("C_", [1, 2, 5])
+def test_loss_kernels_other_channel_counts(ops, C_):
+    """images that are not RGB take the generic (runtime channel count) photometric and smoothness kernels"""
+    gen = torch.Generator().manual_seed(40 + C_)
+    img1, img2 = torch.rand((2, C_, 19, 37), generator=gen) * 2 - 1, torch.rand((2, C_, 19, 37), generator=gen) * 2 - 1
+    flow = torch.randn((2, 2, 19, 37), generator=gen) * 1.5
+    occ = (torch.rand((2, 1, 19, 37), generator=gen) < 0.3).float()
+    fr = flow.clone().requires_grad_()
+    ref = O.first_order_smoothness_loss(img1, fr) + O.second_order_smoothness_loss(img1, fr) + O.photometric_error(O.warp(img2, fr, True), img1, occ)
+    (gr,) = torch.autograd.grad(ref, fr)
+    fd = flow.to(DEV).requires_grad_()
+    s1, s2 = ops.smoothness_losses(img1.to(DEV), fd)
+    got = s1 + s2 + ops.warp_photometric_error(img1.to(DEV), img2.to(DEV), fd, occ.to(DEV))
+    close(got, ref, 2e-5)
+    close(torch.autograd.grad(got, fd)[0], gr, 5e-5)
+
+
 # --------------------------------------------------------------------------------------------- range map
 @pytest.mark.parametrize("tag", ["a", "b", "zero"])
 def test_range_map_golden(ops, golden, tag):
