@@ -571,11 +571,32 @@ class _NormalizeFn(Function):
         return tuple(grads)
 
 
+def _normalize_flags(feats, normalize, center, across_channels, across_images):
+    """the non-default flag combinations of correlation_layer.py:42-82: per-(sample[, channel]) biased moments, optionally averaged over
+    maps and batch; centre and / or scale.  No call site of the reference reaches this; plain tensor operations (fp32 statistics)."""
+    for f in feats:
+        _check4(f, "feature")
+    _require_hip(*feats)
+    dim = (1, 2, 3) if across_channels else (2, 3)
+    moments = [torch.var_mean(f.float(), dim=dim, keepdim=True, unbiased=False) for f in feats]
+    means, variances = [m for _, m in moments], [v for v, _ in moments]
+    if across_images:
+        means = [torch.stack(means).mean()] * len(feats)
+        variances = [torch.stack(variances).mean()] * len(feats)
+    out = [f.float() for f in feats]
+    if center:
+        out = [f - m for f, m in zip(out, means)]
+    if normalize:
+        out = [f / torch.sqrt(v + 1e-16) for f, v in zip(out, variances)]
+    return [o.to(f.dtype) for o, f in zip(out, feats)]
+
+
 def normalize_features(feature_list: Sequence[torch.Tensor], normalize=True, center=True, moments_across_channels=True,
                        moments_across_images=True) -> List[torch.Tensor]:
-    """Drop-in for models/networks/correlation_layer.py:42-82 (defaults only, as every call site uses them)."""
+    """Drop-in for models/networks/correlation_layer.py:42-82.  The defaults -- what every call site of the reference uses -- run on the
+    HIP kernels (csrc/norm.hip); the other flag combinations are composed from framework reductions on the same device."""
     if not (normalize and center and moments_across_channels and moments_across_images):
-        raise NotImplementedError("normalize_features: only the reference defaults are implemented")
+        return _normalize_flags(list(feature_list), normalize, center, moments_across_channels, moments_across_images)
     feats = list(feature_list)
     for f in feats:
         _check4(f, "feature")

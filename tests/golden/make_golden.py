@@ -147,6 +147,17 @@ def gold_corr():
 
 
 # ------------------------------------------------------------ 2. feature normalise (a3)
+NORM_FLAG_CASES = {
+    "per_image": dict(moments_across_images=False),
+    "per_channel": dict(moments_across_channels=False),
+    "per_channel_image": dict(moments_across_channels=False, moments_across_images=False),
+    "center_only": dict(normalize=False),
+    "scale_only": dict(center=False),
+    "scale_only_per_image": dict(center=False, moments_across_images=False),
+    "identity": dict(normalize=False, center=False),
+}
+
+
 def gold_norm():
     f1 = (torch.randn((2, 16, 5, 6), generator=g(21)) * 2 + 0.3).requires_grad_()
     f2 = (torch.randn((2, 16, 5, 6), generator=g(22)) * 0.5 - 1.0).requires_grad_()
@@ -155,6 +166,15 @@ def gold_norm():
     c2 = torch.randn(n2.shape, generator=g(24))
     gf1, gf2 = torch.autograd.grad((n1 * c1).sum() + (n2 * c2).sum(), (f1, f2))
     save("norm", f1=f1, f2=f2, n1=n1, n2=n2, c1=c1, c2=c2, gf1=gf1, gf2=gf2)
+    # the non-default flag combinations of correlation_layer.py:42-82 (no call site of the reference uses them; the operator accepts them)
+    arrs = dict(f1=f1.detach(), f2=f2.detach(), c1=c1, c2=c2)
+    for tag, kw in NORM_FLAG_CASES.items():
+        a, b = f1.detach().clone().requires_grad_(), f2.detach().clone().requires_grad_()
+        m1, m2 = normalize_features([a, b], **kw)
+        ga, gb = torch.autograd.grad((m1 * c1).sum() + (m2 * c2).sum(), (a, b), allow_unused=True)
+        arrs.update({f"{tag}_n1": m1, f"{tag}_n2": m2, f"{tag}_gf1": ga if ga is not None else torch.zeros_like(a),
+                     f"{tag}_gf2": gb if gb is not None else torch.zeros_like(b)})
+    save("norm_flags", **arrs)
 
 
 # ------------------------------------------------------------------- 3. warps (a4, a5)
@@ -739,6 +759,9 @@ def gold_gated():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "norm":
+        gold_norm()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gated":
         gold_gated()
         sys.exit(0)

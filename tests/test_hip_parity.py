@@ -387,6 +387,23 @@ def test_normalize_golden(ops, golden, form, monkeypatch):
     close(gf2, g["gf2"], 5e-5)
 
 
+@pytest.mark.parametrize("tag,kw", [("per_image", dict(moments_across_images=False)), ("per_channel", dict(moments_across_channels=False)),
+                                    ("per_channel_image", dict(moments_across_channels=False, moments_across_images=False)),
+                                    ("center_only", dict(normalize=False)), ("scale_only", dict(center=False)),
+                                    ("scale_only_per_image", dict(center=False, moments_across_images=False)),
+                                    ("identity", dict(normalize=False, center=False))])
+def test_normalize_flag_combinations(ops, golden, tag, kw):
+    """normalize_features with the non-default flags of correlation_layer.py:42-82 against the reference's goldens (values, gradients)"""
+    g = golden("norm_flags")
+    a, b = dev(g["f1"], True), dev(g["f2"], True)
+    n1, n2 = ops.normalize_features([a, b], **kw)
+    close(n1, g[f"{tag}_n1"], 1e-5)
+    close(n2, g[f"{tag}_n2"], 1e-5)
+    ga, gb = torch.autograd.grad((n1 * dev(g["c1"])).sum() + (n2 * dev(g["c2"])).sum(), (a, b), allow_unused=True)
+    close(ga, g[f"{tag}_gf1"], 1e-4)
+    close(gb, g[f"{tag}_gf2"], 1e-4)
+
+
 def test_normalize_kernels_bf16_and_batch_coupling(ops):
     """bf16 maps at a PWC pyramid shape: kernel pair vs the fp32 oracle on the same bf16-rounded inputs (forward to bf16 resolution,
     gradients to 2e-2 of their scale), and the batch coupling of F6 (ONE mean / variance for both maps and all samples)"""
