@@ -324,6 +324,42 @@ def test_loss_kernels_odd_shapes(ops, shape, layout):
     close(ops.compute_range_map(flow.to(DEV)), O.compute_range_map(flow), 1e-5)
 
 
+def test_range_map_and_warp_at_exact_boundaries(ops):
+    """targets exactly on pixel centres, on the last row / column, one pixel outside on every side, half a pixel outside, and non-finite
+    flows: the range map (floor + four taps, taps outside the image dropped: models/model.py:223-305) and both warps (zeros padding)
+    against the oracle"""
+    H, W = 9, 13
+    flow = torch.zeros((1, 2, H, W))
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    flow[0, 0] = (W - 1) - xs            # every pixel of a row lands exactly on the last column
+    flow[0, 1, 0] = -1.0                 # first row: one pixel above the image
+    flow[0, 1, 1] = float(H - 1) - 1.0   # second row: exactly the last row
+    flow[0, 1, 2] = float(H) - 2.0       # third row: one pixel below the image
+    flow[0, 1, 3] = -0.5 - 3.0           # fourth row: half a pixel above row 0
+    flow[0, 0, 4] = -xs[4] - 0.5         # fifth row: half a pixel left of column 0
+    flow[0, 0, 5] = -xs[5] - 1.0         # sixth row: exactly one pixel left
+    flow[0, 0, 6] = 0.0
+    flow[0, 1, 6] = 0.0                  # seventh row: identity
+    flow[0, 0, 7] = 1e6                  # far outside
+    close(ops.compute_range_map(flow.to(DEV)), O.compute_range_map(flow), 1e-6)
+    img = torch.rand((1, 5, H, W), generator=torch.Generator().manual_seed(2))
+    cot = torch.randn((1, 5, H, W), generator=torch.Generator().manual_seed(3))
+    for ac in (False, True):
+        close(ops.warp(img.to(DEV), flow.to(DEV), align_corners=ac), O.warp(img, flow, ac), 1e-5)
+        # gradients at the same positions (integer sample coordinates: the one-sided derivative grid_sample takes)
+        ir, fr = img.clone().requires_grad_(), flow.clone().requires_grad_()
+        gi_ref, gf_ref = torch.autograd.grad(O.warp(ir, fr, ac), (ir, fr), cot)
+        idv, fdv = img.to(DEV).requires_grad_(), flow.to(DEV).requires_grad_()
+        gi, gf = torch.autograd.grad(ops.warp(idv, fdv, align_corners=ac), (idv, fdv), cot.to(DEV))
+        close(gi, gi_ref, 1e-5)
+        close(gf, gf_ref, 1e-4)
+    nf = flow.clone()
+    nf[0, 0, 8, 3] = float("nan")
+    nf[0, 1, 8, 5] = float("inf")
+    got, ref = ops.compute_range_map(nf.to(DEV)).cpu(), O.compute_range_map(nf)
+    assert torch.isfinite(got).all() and torch.allclose(got, ref, atol=1e-6)  # non-finite sources contribute nothing (floor of nan / inf is dropped)
+
+
 @pytest.mark.parametrize("C_", [1, 2, 5])
 def test_loss_kernels_other_channel_counts(ops, C_):
     """images that are not RGB take the generic (runtime channel count) photometric and smoothness kernels"""
