@@ -324,6 +324,28 @@ def test_loss_kernels_odd_shapes(ops, shape, layout):
     close(ops.compute_range_map(flow.to(DEV)), O.compute_range_map(flow), 1e-5)
 
 
+def test_loss_arguments_off_their_defaults(ops):
+    """edge-weight exponent `alpha` other than 100, a mask that occludes everything (the 1e-16 of the denominator decides), a mask that
+    occludes nothing, fractional mask values"""
+    gen = torch.Generator().manual_seed(77)
+    img1, img2 = torch.rand((2, 3, 20, 31), generator=gen) * 2 - 1, torch.rand((2, 3, 20, 31), generator=gen) * 2 - 1
+    flow = torch.randn((2, 2, 20, 31), generator=gen)
+    for alpha in (10.0, 1.0, 250.0):
+        fr, fd = flow.clone().requires_grad_(), flow.to(DEV).requires_grad_()
+        ref = O.first_order_smoothness_loss(img1, fr, alpha) + 0.5 * O.second_order_smoothness_loss(img1, fr, alpha)
+        s1, s2 = ops.smoothness_losses(img1.to(DEV), fd, alpha)
+        close(s1 + 0.5 * s2, ref, 2e-5)
+        close(torch.autograd.grad(s1 + 0.5 * s2, fd)[0], torch.autograd.grad(ref, fr)[0], 5e-5)
+        close(ops.first_order_smoothness_loss(img1.to(DEV), flow.to(DEV), alpha), O.first_order_smoothness_loss(img1, flow, alpha), 2e-5)
+    for occ in (torch.ones((2, 1, 20, 31)), torch.zeros((2, 1, 20, 31)), torch.rand((2, 1, 20, 31), generator=gen)):
+        fr, fd = flow.clone().requires_grad_(), flow.to(DEV).requires_grad_()
+        ref = O.photometric_error(O.warp(img2, fr, True), img1, occ)
+        got = ops.warp_photometric_error(img1.to(DEV), img2.to(DEV), fd, occ.to(DEV))
+        close(got, ref, 2e-5)
+        close(torch.autograd.grad(got, fd)[0], torch.autograd.grad(ref, fr)[0], 5e-5)
+        close(ops.photometric_error(img2.to(DEV), img1.to(DEV), occ.to(DEV)), O.photometric_error(img2, img1, occ), 2e-5)
+
+
 def test_range_map_and_warp_at_exact_boundaries(ops):
     """targets exactly on pixel centres, on the last row / column, one pixel outside on every side, half a pixel outside, and non-finite
     flows: the range map (floor + four taps, taps outside the image dropped: models/model.py:223-305) and both warps (zeros padding)
