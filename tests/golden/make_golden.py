@@ -757,8 +757,32 @@ def gold_gated():
     with open(os.path.join(HERE, "state_dict_manifest_gated.json"), "w") as f:
         json.dump({"inpaintsanet": manifest}, f)
 
+# ------------------------------------------- 16. the third step variant of FlowStageModel: photometric term masked by the GROUND-TRUTH occlusion
+def gold_stage_gtocc():
+    """FlowStageModel('pwc', with_occ=True, occ_aware=False): general_step_occ (models/model.py:343-364) on the inputs of the other two
+    stage fixtures (nets.npz: stage_x / stage_gt_flow / stage_gt_occ, regenerated here from the same seeds)"""
+    hp = dict(learning_rate=1e-5, model="pwc", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0, with_occ=True,
+              occ_aware=False)
+    xs = torch.from_numpy(smooth_field((2, 6, 64, 128), seed=66, amp=1.0)).float().clamp(-1, 1)
+    gt_flow2 = torch.randn((2, 2, 64, 128), generator=g(67)) * 2
+    gt_occ2 = (torch.rand((2, 1, 64, 128), generator=g(68)) < 0.3).float()
+    m = ref_model.FlowStageModel(dict(hp))
+    rngfree_fill(m)
+    m.train()
+    m.logger = None
+    m.global_step = 1
+    res = m.general_step_occ((xs, gt_flow2, gt_occ2), 0, "train")
+    loss = hp["photo_weight"] * res[0] + hp["smooth1_weight"] * res[1] + hp["smooth2_weight"] * res[2]
+    loss.backward()
+    save("stage_gtocc", scalars=torch.stack([r.detach() for r in res]), loss=loss,
+         grad_predict_flow2=m.flow_pred.predict_flow2.weight.grad[:, :16], grad_conv1a=m.flow_pred.conv1a[0].weight.grad,
+         x_absmean=xs.abs().mean(), occ_mean=gt_occ2.mean())
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "stage_gtocc":
+        gold_stage_gtocc()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "norm":
         gold_norm()
         sys.exit(0)
@@ -800,3 +824,4 @@ if __name__ == "__main__":
     gold_train_fpn()
     gold_two_stage()
     gold_gated()
+    gold_stage_gtocc()

@@ -423,3 +423,22 @@ def test_gated_generator_cpu(cpu_ops, golden):
     out, attn = a(xx)
     a.with_attn = False
     assert torch.allclose(a(xx), out, atol=1e-5) and torch.allclose(attn.sum(-1), torch.ones(2, 35), atol=1e-5)
+
+
+def test_unsupervised_stage_step_with_ground_truth_occlusion(cpu_ops, golden):
+    """FlowStageModel(with_occ=True, occ_aware=False): `general_step_occ` (models/model.py:343-364), the photometric term masked by the
+    batch's occlusion label -- scalars, training_step's total, two gradients against the reference's golden"""
+    from ocflow_amd.models.model import FlowStageModel
+    g, gn = golden("stage_gtocc"), golden("nets")
+    hp = dict(learning_rate=1e-5, model="pwc", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0, with_occ=True,
+              occ_aware=False)
+    m = rngfree_fill(FlowStageModel(hp))
+    batch = (T(gn["stage_x"]), T(gn["stage_gt_flow"]), T(gn["stage_gt_occ"]))
+    assert abs(float(batch[0].abs().mean()) - float(g["x_absmean"])) < 1e-6 and abs(float(batch[2].mean()) - float(g["occ_mean"])) < 1e-7
+    res = m.general_step_occ(batch, 0, "train")
+    close(torch.stack([r.detach() for r in res]), g["scalars"], 2e-5)
+    loss = m.training_step(batch, 0)
+    close(loss, g["loss"], 2e-5)
+    loss.backward()
+    close(m.flow_pred.predict_flow2.weight.grad[:, :16], g["grad_predict_flow2"], 5e-5)
+    close(m.flow_pred.conv1a[0].weight.grad, g["grad_conv1a"], 5e-4)

@@ -95,6 +95,23 @@ def test_unsupervised_stage_step(golden, occ_aware, tag):
     close(m.flow_pred.predict_flow2.weight.grad[:, :16], g[f"stage_{tag}_grad_predict_flow2"], 1e-3)
 
 
+def test_unsupervised_stage_step_with_ground_truth_occlusion(golden):
+    """`general_step_occ` (with_occ=True: the photometric kernel masked by the batch's occlusion label, models/model.py:343-364) on the HIP
+    kernels against the reference's golden"""
+    from ocflow_amd.models.model import FlowStageModel
+    g, gn = golden("stage_gtocc"), golden("nets")
+    hp = dict(learning_rate=1e-5, model="pwc", displacement=4, photo_weight=4.0, smooth1_weight=0.5, smooth2_weight=0.0, with_occ=True,
+              occ_aware=False)
+    m = rngfree_fill(FlowStageModel(hp)).to(DEV)
+    batch = (d(gn["stage_x"]), d(gn["stage_gt_flow"]), d(gn["stage_gt_occ"]))
+    res = m.general_step_occ(batch, 0, "train")
+    close(torch.stack([r.detach() for r in res]), g["scalars"], 1e-4)
+    loss = m.training_step(batch, 0)
+    close(loss, g["loss"], 1e-4)
+    loss.backward()
+    close(m.flow_pred.predict_flow2.weight.grad[:, :16], g["grad_predict_flow2"], 1e-3)  # (bar: see test_unsupervised_stage_step)
+
+
 def test_ssim_photo_mode_step():
     """photo_mode='ssim' (SURVEY 8f-2): the unsupervised step with 1 - SSIM(warp(img2, flow), img1) as the photometric term equals the
     same expression built from the oracle's SSIM and warp on the model's own predicted flow, and its gradient reaches the network"""
