@@ -302,6 +302,33 @@ int ocf_bias_act_bwd(const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tens
 int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky, int64_t gw_skx,
                       int B, int Ci, int Co, int H, int W, int dilation, int dtype, int policy, void* stream);
 
+/* ---- the 3x3, stride-1, padding == dilation convolutions of the estimator / context networks as ONE implicit-GEMM kernel on the matrix
+ * cores, forward and input gradient, bf16 channels_last:
+ *   y[b,m,y,x] = epi( sum_{ky,kx,k} Wp[m][ky*3+kx][k] * x[b,k, y+(ky-1)*dilation, x+(kx-1)*dilation] )        (zero outside the image)
+ *   epi(v)     = lrelu(v + bias[m], negative_slope) * (act[b,m,y,x] > 0 ? 1 : mask_slope)       bias == NULL: no bias; act == NULL: no mask
+ * forward:        Wp = pack(weight, transpose = 0), bias + LeakyReLU fused (negative_slope = 1: plain bias)
+ * input gradient: x := grad_out, Wp = pack(weight, transpose = 1), act = the convolution's own INPUT when that is the LeakyReLU output of
+ *                 the previous layer (its gradient then leaves the kernel already multiplied by that activation's derivative)
+ * x, y, act: channels_last views (channel stride 1; x with 16-byte aligned pixels, y / act 8-byte aligned when Cout % 4 == 0) -- channel
+ * slices of wider buffers included, which is how the decoder's concatenations are read and written in place.  Cin % 8 == 0.
+ * w_packed: [w_rows][9][w_k] bf16 from ocf_conv3x3_pack_weights, w_rows >= the rows_pad ocf_conv3x3_plan reports, w_k % 8 == 0, zero padded.
+ * policy: 0 = automatic patch shape, 16 / 32 / 64 = force the patch width (A/B).  dilation <= 16.
+ * replaces: conv() / nn.Conv2d(k=3, s=1, p=d, dilation=d) [+ bias + nn.LeakyReLU(0.1)] and the input half of their autograd in
+ *           flow_net.py:11-37, flow_occ_net.py:11-67, context_net.py:11-17 */
+int ocf_conv3x3_plan(int Cout, int H, int W, int dilation, int* m_tiles, int* patch_width, int* rows_pad);
+int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int w_rows, int w_k, const ocf_tensor4* y, const float* bias,
+                      const ocf_tensor4* act, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope, float mask_slope,
+                      int dtype, int policy, void* stream);
+/* Weight packing for ocf_conv3x3_igemm, every layer of a network in ONE launch: descriptor i says "src (any-strided [Co][Ci][3][3], fp32 or
+ * bf16) -> dst (bf16 [rows_pad][9][k_pad], zero padded)"; transpose = 0: rows = Co, k = Ci; transpose = 1: rows = Ci, k = Co, taps flipped.
+ * ocf_conv3x3_pack_describe fills descriptor `index` of a HOST array (ocf_conv3x3_pack_bytes(n) bytes) and chains the flat element index
+ * (`first` of descriptor 0 is 0, `*next_first` feeds the next call; the last one is `total_elements`); the caller copies the array to the
+ * device once and calls ocf_conv3x3_pack_weights(device array) whenever the source weights have changed. */
+int ocf_conv3x3_pack_bytes(int n, int64_t* desc_bytes);
+int ocf_conv3x3_pack_describe(void* host_descs, int index, const void* src, int64_t so, int64_t si, int64_t sky, int64_t skx, int Co, int Ci,
+                              int src_is_f32, void* dst, int rows_pad, int k_pad, int transpose, int64_t first, int64_t* next_first);
+int ocf_conv3x3_pack_weights(const void* device_descs, int n, int64_t total_elements, void* stream);
+
 /* ---- BatchNorm2d (batch statistics) + LeakyReLU of the feature-pyramid encoder
  * replaces: nn.BatchNorm2d + nn.LeakyReLU(0.1) of the reference's `conv_bn_relu` blocks (models/networks/feature_pyramid_net.py:5-95), i.e.
  * torch.batch_norm(training) + leaky_relu and their autograd.  Dense channels_last x / y / gy / gx of `dtype` (OCF_F32 / OCF_BF16), C a

@@ -1,0 +1,253 @@
+"""The estimator / context-network convolutions on this repo's own matrix-core kernels.
+
+`conv3x3_bias_act(x, weight, bias, negative_slope, dilation)` is `F.leaky_relu(F.conv2d(x, weight, bias, 1, d, d), slope)` for the 3x3 /
+stride-1 / padding == dilation layers of flow_net.py:11-37, flow_occ_net.py:11-67 and context_net.py:11-17 in the bf16 channels_last
+throughput configuration:
+
+  forward          ocf_conv3x3_igemm        convolution + bias + LeakyReLU in one launch
+  input gradient   ocf_conv3x3_igemm        the same kernel on grad_out with the flipped / transposed weight
+  weight gradient  ocf_conv3x3_wgrad        (fp32, split-K)
+
+The kernels read PACKED weights (bf16 [rows][9][k], zero padded): `WeightPacker` keeps one packed copy per (weight, orientation) and
+refreshes every copy of a network with ONE launch per step (ocf_conv3x3_pack_weights) whenever the weights have changed.
+There is no CPU path: CPU tensors raise (ops._require_hip)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from . import ops
+from .ops import _t4, _stream, _require_hip, _ptr
+
+
+def plan(cout: int, h: int, w: int, dilation: int) -> Tuple[int, int, int]:
+    """(16-row tiles per workgroup, patch width, padded rows of the packed weight) ocf_conv3x3_igemm uses for this output"""
+    mt, tw, rows = C.c_int(0), C.c_int(0), C.c_int(0)
+    _lib.check(_lib.load().ocf_conv3x3_plan(int(cout), int(h), int(w), int(dilation), C.byref(mt), C.byref(tw), C.byref(rows)), "ocf_conv3x3_plan")
+    return mt.value, tw.value, rows.value
+
+
+def _rows_pad(n: int) -> int:
+    """rows of a packed weight: what ocf_conv3x3_plan asks for (equal blocks of <= 8 tiles of 16 rows); independent of the image size"""
+    tiles = (n + 15) // 16
+    nblk = (tiles + 7) // 8
+    return nblk * ((tiles + nblk - 1) // nblk) * 16
+
+
+class _Packed:
+    """packed copy of one weight in one orientation + its device descriptor"""
+    __slots__ = ("dst", "rows", "k", "desc_host", "transpose", "version", "src_ref")
+
+
+class WeightPacker:
+    """Packed bf16 copies [rows_pad][9][k_pad] of convolution weights for ocf_conv3x3_igemm, refreshed by one launch.
+
+    `get(weight, transpose)` returns the packed tensor for a weight (registering it on first use); `refresh()` re-packs every registered
+    weight whose storage may have changed -- ONE launch for all of them.  `get` refreshes lazily when a weight's version counter moved or
+    while a graph is being captured (the pack must then be a node of that graph)."""
+
+    def __init__(self):
+        self.entries: Dict[Tuple[int, int], _Packed] = {}
+        self._order: List[_Packed] = []
+        self._dev_descs: Optional[torch.Tensor] = None
+        self._total = 0
+        self._stamp = -1          # ops-level "weights changed" counter seen by the last refresh
+        self._capture_seen = 0
+
+    def _register(self, w: torch.Tensor, transpose: bool, min_rows: int) -> _Packed:
+        co, ci = int(w.shape[0]), int(w.shape[1])
+        rows, k = (ci, co) if transpose else (co, ci)
+        e = _Packed()
+        e.rows, e.k = _rows_pad(max(rows, min_rows)), (k + 7) // 8 * 8
+        e.dst = torch.zeros((e.rows, 9, e.k), device=w.device, dtype=torch.bfloat16)
+        e.transpose = bool(transpose)
+        e.version = -1
+        e.src_ref = w
+        self.entries[(id(w), int(transpose), int(min_rows))] = e
+        self._order.append(e)
+        self._dev_descs = None  # descriptor table is rebuilt on the next refresh
+        return e
+
+    def _build_table(self, device):
+        n = len(self._order)
+        nbytes = C.c_int64(0)
+        lib = _lib.load()
+        _lib.check(lib.ocf_conv3x3_pack_bytes(n, C.byref(nbytes)), "ocf_conv3x3_pack_bytes")
+        host = (C.c_char * nbytes.value)()
+        first = C.c_int64(0)
+        for i, e in enumerate(self._order):
+            w = e.src_ref
+            so, si, sky, skx = w.stride()
+            nxt = C.c_int64(0)
+            _lib.check(lib.ocf_conv3x3_pack_describe(host, i, C.c_void_p(w.data_ptr()), so, si, sky, skx, int(w.shape[0]), int(w.shape[1]),
+                                                     1 if w.dtype == torch.float32 else 0, C.c_void_p(e.dst.data_ptr()), e.rows, e.k,
+                                                     1 if e.transpose else 0, first, C.byref(nxt)), "ocf_conv3x3_pack_describe")
+            first = nxt
+        self._total = first.value
+        t = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).clone()
+        self._dev_descs = t.to(device)
+        self._ptrs = [e.src_ref.data_ptr() for e in self._order]
+
+    def refresh(self, device=None):
+        if not self._order:
+            return
+        device = device or self._order[0].dst.device
+        if self._dev_descs is None or any(e.src_ref.data_ptr() != p for e, p in zip(self._order, self._ptrs)):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ocflow_amd.conv.WeightPacker: a weight was registered or re-allocated during a graph capture; run the "
+                                   "step once eagerly first")
+            self._build_table(device)
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().ocf_conv3x3_pack_weights(C.c_void_p(self._dev_descs.data_ptr()), len(self._order), self._total,
+                                                            C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "ocf_conv3x3_pack_weights")
+        for e in self._order:
+            e.version = e.src_ref._version
+
+    def get(self, w: torch.Tensor, transpose: bool, min_rows: int = 0) -> _Packed:
+        """min_rows: output channels the kernel will be asked to write (the input gradient of a layer fed by a zero-padded
+        concatenation has more channels than the weight has inputs: the extra rows are zero)"""
+        if w.dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError(f"ocflow_amd.conv: weight dtype {w.dtype}")
+        e = self.entries.get((id(w), int(transpose), int(min_rows)))
+        if e is None:
+            e = self._register(w, transpose, int(min_rows))
+        stale = e.version != w._version or e.src_ref is not w
+        if torch.cuda.is_current_stream_capturing():
+            cid = ops._capture_id(w.device)
+            stale = stale or self._capture_seen != cid
+            if stale:
+                self._capture_seen = cid
+        if stale:
+            self.refresh(w.device)
+        return e
+
+
+PACKER = WeightPacker()
+
+
+def igemm_raw(x, packed: _Packed, cout: int, bias=None, act=None, dilation: int = 1, negative_slope: float = 1.0, mask_slope: float = 1.0,
+              out=None, policy: int = 0):
+    """ocf_conv3x3_igemm on a channels_last bf16 view `x` [B,Cin,H,W] with a packed weight; returns `out` (allocated channels_last when None)"""
+    _require_hip(x)
+    B, cin, H, W = x.shape
+    cin = min(cin, packed.k)  # channels past the packed weight's k (alignment channels of a concatenation) meet no weight
+    if out is None:
+        out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    b32 = None
+    if bias is not None:
+        b32 = bias.detach()
+        if b32.dtype != torch.float32:
+            b32 = b32.float()
+    with torch.cuda.device(x.device):
+        fn = lambda: _lib.check(_lib.load().ocf_conv3x3_igemm(_t4(x), C.c_void_p(packed.dst.data_ptr()), packed.rows, packed.k, _t4(out), _ptr(b32),
+                                                               _t4(act), B, cin, cout, H, W, int(dilation), float(negative_slope), float(mask_slope),
+                                                               _lib.OCF_BF16, int(policy), _stream(x)), "ocf_conv3x3_igemm")
+        ops._launch("conv3x3_igemm", lambda: ops._meta(f"B{B}x{cin}->{cout}x{H}x{W}d{dilation}", B * H * W * 2 * (cin + cout),
+                                                       2 * B * H * W * 9 * cin * cout), fn)
+    return out
+
+
+def eligible(x, weight, stride, padding, dilation, groups) -> bool:
+    """layers ocf_conv3x3_igemm takes: bf16 channels_last activations with a multiple of 8 channels, 3x3, stride 1, padding == dilation <= 16"""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4):
+        return False
+    if weight.dtype not in (torch.bfloat16, torch.float32) or tuple(weight.shape[2:]) != (3, 3) or groups != 1 or tuple(stride) != (1, 1):
+        return False
+    d = tuple(dilation)
+    if d[0] != d[1] or tuple(padding) != d or d[0] > 16:
+        return False
+    extra = x.shape[1] - weight.shape[1]  # alignment channels of `cat_aligned` (zeros)
+    if x.shape[1] % 8 != 0 or extra < 0 or extra >= 32:
+        return False
+    return _pixel_major(x, 16)
+
+
+def _pixel_major(t, align: int) -> bool:
+    """channel-contiguous with pixels in dense (b, y, x) order at one pixel pitch -- dense channels_last tensors and channel slices of
+    them (size-1 dimensions carry arbitrary strides)"""
+    B, C_, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    p = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C_))
+    return ((C_ == 1 or sc == 1) and p >= C_ and (H == 1 or sh == p * W) and (B == 1 or sb == p * W * H) and (p * 2) % align == 0
+            and t.data_ptr() % align == 0)
+
+
+def _shape_like(weight, cin):
+    """the weight itself, or (input fed by a zero-padded concatenation) the weight with zero input channels appended"""
+    if weight.shape[1] == cin:
+        return weight
+    wp = weight.new_zeros((weight.shape[0], cin, 3, 3)).contiguous(memory_format=torch.channels_last)
+    wp[:, :weight.shape[1]] = weight
+    return wp
+
+
+class _ConvBiasActFn(Function):
+    """forward: one launch (convolution + bias + LeakyReLU).  backward: LeakyReLU derivative + bias gradient (ocf_bias_act_bwd), input
+    gradient by the same implicit-GEMM kernel on the transposed weight, weight gradient by ocf_conv3x3_wgrad or the framework."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, dilation):
+        pk = PACKER.get(weight, False)
+        y = igemm_raw(x, pk, weight.shape[0], bias, None, dilation, slope, 1.0)
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (float(slope), int(dilation), bias is not None, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        slope, d, has_bias, bias_dtype = ctx.cfg
+        B, co, H, W = y.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        gg = gy if gy.dtype == y.dtype else gy.to(y.dtype)
+        if not _pixel_major(gg, 2):
+            gg = gg.contiguous(memory_format=torch.channels_last)
+        # dz = gy * lrelu'(y), dbias = sum dz: one pass (the existing epilogue-backward kernel)
+        gb = None
+        if slope != 1.0 or need_b:
+            gb = ops._take_zeros(co, gy.device)
+            dz = torch.empty_like(y) if slope != 1.0 else None
+            with torch.cuda.device(gy.device):
+                _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y if slope != 1.0 else None), _t4(gg), _t4(dz), C.c_void_p(gb.data_ptr()), B, co, H, W,
+                                                        slope, 1, _lib.OCF_BF16, _stream(gg)), "ocf_bias_act_bwd")
+            if dz is None:
+                dz = gg
+        else:
+            dz = gg
+        gx = gw = None
+        if need_x:
+            if co % 8 == 0 and _pixel_major(dz, 16):
+                pkt = PACKER.get(weight, True, x.shape[1])
+                gx = igemm_raw(dz, pkt, x.shape[1], None, None, d, 1.0, 1.0)
+            else:
+                dzc = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
+                gx = torch.ops.aten.convolution_backward(dzc, x, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False, (0, 0), 1,
+                                                         [True, False, False])[0]
+        if need_w:
+            dzc = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
+            xc = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            gw = torch.ops.aten.convolution_backward(dzc, xc, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False, (0, 0), 1,
+                                                     [False, True, False])[1]
+            if gw.shape[1] != weight.shape[1]:
+                gw = gw[:, :weight.shape[1]].contiguous(memory_format=torch.channels_last)
+        if gb is not None and need_b and bias_dtype != torch.float32:
+            gb = gb.to(bias_dtype)
+        return gx, gw, (gb if need_b else None), None, None
+
+
+def conv3x3_bias_act(x, weight, bias=None, negative_slope: float = 1.0, dilation: int = 1):
+    """`F.leaky_relu(F.conv2d(x, weight, bias, 1, dilation, dilation), negative_slope)` (negative_slope = 1: no activation) on the
+    implicit-GEMM kernel; the caller checks `eligible` first"""
+    return _ConvBiasActFn.apply(x, weight, bias, float(negative_slope), int(dilation))
+
+
+def enabled() -> bool:
+    """OCFLOW_NATIVE_CONV: "1" (default) routes eligible layers through these kernels, "0" keeps the framework's convolutions"""
+    return os.environ.get("OCFLOW_NATIVE_CONV", "1") != "0"

@@ -1,0 +1,399 @@
+// 3x3 / stride-1 / padding == dilation convolutions of the estimator and context networks as ONE implicit-GEMM kernel family on the
+// matrix cores, bf16 channels_last, gfx950 ("flow-decoder dense block as hand MFMA implicit-GEMM", reference layers
+// flow_net.py:11-37, flow_occ_net.py:11-67, context_net.py:11-17).
+//
+//   y[b,y,x,m] = epi( sum_{ky,kx,k} Wp[m][ky*3+kx][k] * x[b, y + (ky-1) d, x + (kx-1) d, k] )          (zero outside the image)
+//   epi(v)     = lrelu(v + bias[m], slope) * (act[b,y,x,m] > 0 ? 1 : mask_slope)
+//
+// The SAME kernel is the forward pass (Wp = the weight, epilogue = bias + LeakyReLU: the framework's conv + `add_` + `leaky_relu` in one
+// launch) and the input gradient (x := grad_out, Wp = the weight with taps flipped and channels transposed, packed by
+// ocf_conv3x3_pack_weights; epilogue = the LeakyReLU mask of the PREVIOUS layer taken from its output `act`: conv-backward-data +
+// leaky_relu_backward in one launch).
+//
+// GEMM view per workgroup: M = MT*16 output channels, N = 512 output pixels (a TH x TW patch of one image), K = 9 taps x Cin.
+// A operand = weights, B operand = pixels, v_mfma_f32_16x16x32_bf16: a lane's four accumulator registers are four CONSECUTIVE output
+// channels of one pixel, i.e. one 8-byte store into the channels_last output.
+//
+// Staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers), two buffers, one barrier per stage.  A stage is
+// (32-channel block c, tap row ky): the TH x (TW + 2d) pixel rows the three taps of that row touch (64 bytes per pixel) and the three
+// [M][32] weight slices.  Every wave instruction of the DMA writes 1 KiB lane-linearly; out-of-image pixels and channel tails are
+// sourced from a zero page, so the LDS image needs no fix-up.  Both LDS images are rows of 64 bytes = 4 slots of 16 bytes (one
+// 8-channel k-group each), slot g of row r stored at slot (g + 2 (r >> 2)) & 3: the ds_read_b128 of a 16x16x32 operand (lane = row
+// l & 15, k-group l >> 4) is then bank-conflict free for every row offset (the hardware serves the 64 lanes in four fixed groups of 16:
+// lanes {0-3, 12-15, 20-27} ...); the permutation is applied on the DMA's per-lane SOURCE address.
+#include "ocf_common.h"
+#include <mutex>
+#include <set>
+#include <utility>
+
+namespace ocf {
+namespace ig {
+constexpr int NTHR = 512, NWAVE = 8, PIX_ITERS = 6;  // <= 48 KiB of pixel rows per stage
+__device__ u32x4 g_zero[64];                          // 1 KiB of zeros (not const: a const source turns the selected load into flat_load)
+
+struct Args {
+  const char* x;      // [B][H][W][xp] bf16, channels [0, Cin) used
+  const char* w;      // packed [rows][9][wK] bf16, rows a multiple of MT*16 (zero padded), wK a multiple of 8 (zero padded past Cin)
+  char* y;            // [B][H][W][yp] bf16, channels [0, Cout) written
+  const float* bias;  // [Cout] or null
+  const char* act;    // [B][H][W][ap] bf16 or null
+  long xp, yp, ap;    // pixel pitches, elements
+  int B, H, W, Cin, Cout, wK, d, tiles_x, tiles_y;
+  float slope, mslope;
+};
+
+__device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float bf_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+
+// FULL: Cout % 4 == 0, every lane's four channels exist together (8-byte loads / stores); otherwise per-channel accesses.
+// Loads are issued for all MT channel tiles of a pixel before the first use, from addresses that are valid for every lane
+// (out-of-range lanes read the tensor's first elements and store nothing): no load sits behind a lane-dependent branch.
+template <int MT, int TW, bool FULL, bool ACT>
+__device__ __forceinline__ void epilogue(const Args& a, const f32x4 (&acc)[MT][4], int wave, int l15, int cb0, int b, int x0, int y0) {
+  constexpr int FC = TW / 16;
+  const float slope = a.slope, mslope = a.mslope;
+  f32x4 bv[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    bv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      const int cb = cb0 + m * 16;
+      if (FULL) {
+        bv[m] = *(const f32x4*)(a.bias + (cb < a.Cout ? cb : 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) bv[m][e] = a.bias[cb + e < a.Cout ? cb + e : 0];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int f = wave * 4 + j, fr = f / FC, fc = f - fr * FC;
+    const int yy = y0 + fr, xx = x0 + fc * 16 + l15;
+    const bool pix_ok = yy < a.H && xx < a.W;
+    const long pix = pix_ok ? ((long)b * a.H + yy) * a.W + xx : 0;
+    u32x2 mv[MT];
+    if (ACT && FULL) {
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        const int cb = cb0 + m * 16;
+        mv[m] = *(const u32x2*)(a.act + (pix * a.ap + (cb < a.Cout ? cb : 0)) * 2);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      const int cb = cb0 + m * 16;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        v[e] = acc[m][j][e] + bv[m][e];
+        v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+      }
+      if (FULL) {
+        if (ACT) {
+          v[0] *= bf_lo(mv[m][0]) > 0.f ? 1.f : mslope; v[1] *= bf_hi(mv[m][0]) > 0.f ? 1.f : mslope;
+          v[2] *= bf_lo(mv[m][1]) > 0.f ? 1.f : mslope; v[3] *= bf_hi(mv[m][1]) > 0.f ? 1.f : mslope;
+        }
+        const bf16x2 lo = {(bf16)v[0], (bf16)v[1]}, hi = {(bf16)v[2], (bf16)v[3]};
+        const u32x2 o = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+        if (pix_ok && cb < a.Cout) *(u32x2*)(a.y + (pix * a.yp + cb) * 2) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const bool ok = pix_ok && cb + e < a.Cout;
+          float o = v[e];
+          if (ACT) o *= (float)(((const bf16*)a.act)[pix * a.ap + (ok ? cb + e : 0)]) > 0.f ? 1.f : mslope;
+          if (ok) ((bf16*)a.y)[pix * a.yp + cb + e] = (bf16)o;
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int TW>
+__global__ __launch_bounds__(NTHR, 2) void conv3x3_igemm_kernel(const Args a) {
+  constexpr int TH = 512 / TW, FC = TW / 16;
+  constexpr int W_BYTES = 3 * MT * 1024, W_ITERS = (3 * MT + NWAVE - 1) / NWAVE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = a.d, TWP = TW + 2 * d, H = a.H, W = a.W;
+  const int npi = (TH * TWP * 64 + 1023) >> 10;  // wave instructions (1 KiB) per stage of pixel rows
+  const int pix_bytes = npi << 10, buf_bytes = pix_bytes + W_BYTES;
+
+  const int ntile = a.tiles_x * a.tiles_y * a.B;
+  const int t = xcd_remap(blockIdx.x, ntile);
+  const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int mrow0 = blockIdx.y * (MT * 16);
+
+  const int g = lane >> 4, l15 = lane & 15;
+  // logical k-group this lane SOURCES for the DMA: it writes physical slot lane & 3 of row (16 q + (lane >> 2)), and (row >> 2) & 3 = g
+  const int slot_src = ((lane & 3) - 2 * g) & 3;
+  const char* zsrc = (const char*)g_zero + lane * 16;
+
+  // ---- stage-invariant DMA source offsets (elements, relative to the stage's origin pixel) -------------------------------------
+  int poff[PIX_ITERS], prow[PIX_ITERS];
+#pragma unroll
+  for (int k = 0; k < PIX_ITERS; k++) {
+    const int q = k * NWAVE + wave;
+    const int pidx = q * 16 + (lane >> 2);
+    const int r = pidx / TWP, c = pidx - r * TWP;
+    const int gx = x0 - d + c;
+    const bool ok = q < npi && r < TH && gx >= 0 && gx < W;
+    poff[k] = (int)((r * W + c) * a.xp) + slot_src * 8;
+    prow[k] = ok ? r : -(1 << 20);
+  }
+  int woff[W_ITERS];
+#pragma unroll
+  for (int k = 0; k < W_ITERS; k++) {
+    const int q = k * NWAVE + wave;  // = kx * MT + m
+    const int kx = q / MT, m = q - kx * MT;
+    woff[k] = ((m * 16 + (lane >> 2)) * 9 + kx) * a.wK + slot_src * 8;
+  }
+  // ---- fragment read offsets -------------------------------------------------------------------------------------------------------
+  const int aoff = l15 * 64 + ((g + 2 * (l15 >> 2)) & 3) * 16;
+  int boff[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int f = wave * 4 + j, fr = f / FC, fc = f - fr * FC;
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      const int pidx = fr * TWP + fc * 16 + l15 + kx * d;
+      boff[j][kx] = pidx * 64 + ((g + 2 * ((pidx >> 2) & 3)) & 3) * 16;
+    }
+  }
+
+  const int nchunk = (a.Cin + 31) >> 5;
+  const int nstage = nchunk * 3;
+  auto issue = [&](int s) __attribute__((always_inline)) {
+    const int c = s / 3, ky = s - 3 * c;
+    char* buf = smem + (s & 1) * buf_bytes;
+    const int ch = c * 32 + slot_src * 8;
+    const bool x_ok = ch < a.Cin, w_ok = ch < a.wK;
+    const int dy = (ky - 1) * d;
+    const char* xb = a.x + ((((long)b * H + y0 + dy) * W + (x0 - d)) * a.xp + c * 32) * 2;
+#pragma unroll
+    for (int k = 0; k < PIX_ITERS; k++) {
+      const int q = k * NWAVE + wave;
+      if (q < npi) {
+        const int yy = y0 + prow[k] + dy;
+        const bool ok = x_ok && yy >= 0 && yy < H;
+        dma16(ok ? xb + (long)poff[k] * 2 : zsrc, buf + q * 1024);
+      }
+    }
+    const char* wb = a.w + (((long)mrow0 * 9 + ky * 3) * a.wK + c * 32) * 2;
+#pragma unroll
+    for (int k = 0; k < W_ITERS; k++) {
+      const int q = k * NWAVE + wave;
+      if (q < 3 * MT) dma16(w_ok ? wb + (long)woff[k] * 2 : zsrc, buf + pix_bytes + q * 1024);
+    }
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int s = 0; s < nstage; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s has landed
+    __builtin_amdgcn_s_barrier();                      // everybody's has; and every wave is done reading the other buffer
+    if (s + 1 < nstage) issue(s + 1);
+    const char* buf = smem + (s & 1) * buf_bytes;
+    const char* wbuf = buf + pix_bytes + aoff;
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      bf16x8 bq[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bq[j] = *(const bf16x8*)(buf + boff[j][kx]);
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        const bf16x8 aq = *(const bf16x8*)(wbuf + (kx * MT + m) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq[j], acc[m][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane = pixel l15 of fragment j, registers = channels 16 m + 4 g + 0..3 ----------------------------------------------
+  const int cb0 = mrow0 + 4 * g;
+  if ((a.Cout & 3) == 0) {
+    if (a.act) epilogue<MT, TW, true, true>(a, acc, wave, l15, cb0, b, x0, y0);
+    else epilogue<MT, TW, true, false>(a, acc, wave, l15, cb0, b, x0, y0);
+  } else {
+    if (a.act) epilogue<MT, TW, false, true>(a, acc, wave, l15, cb0, b, x0, y0);
+    else epilogue<MT, TW, false, false>(a, acc, wave, l15, cb0, b, x0, y0);
+  }
+}
+
+// ---- weight packing: any-strided [Co][Ci][3][3] (fp32 or bf16) -> packed bf16 [rows_pad][9][k_pad], zero padded -----------------------
+//   transpose == 0: rows = Co, k = Ci, tap t = ky*3 + kx                         (forward operand)
+//   transpose == 1: rows = Ci, k = Co, tap t = (2-ky)*3 + (2-kx)                 (input-gradient operand: flipped taps, swapped channels)
+struct PackDesc {
+  const void* src;
+  void* dst;
+  long so, si, sky, skx;  // element strides of src
+  int Co, Ci, rows_pad, k_pad, transpose, src_f32;
+  long first;  // index of this tensor's first packed element in the launch's flat index space
+};
+
+__global__ void conv3x3_pack_kernel(const PackDesc* __restrict__ descs, int n, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {  // last descriptor with first <= i
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].first <= i) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc& p = descs[lo];
+    const long e = i - p.first;
+    const int k = (int)(e % p.k_pad);
+    const int tap = (int)((e / p.k_pad) % 9);
+    const int row = (int)(e / ((long)p.k_pad * 9));
+    const int R = p.transpose ? p.Ci : p.Co, K = p.transpose ? p.Co : p.Ci;
+    float v = 0.f;
+    if (row < R && k < K) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      long off;
+      if (p.transpose) off = (long)k * p.so + (long)row * p.si + (2 - ky) * p.sky + (2 - kx) * p.skx;
+      else off = (long)row * p.so + (long)k * p.si + ky * p.sky + kx * p.skx;
+      v = p.src_f32 ? ((const float*)p.src)[off] : (float)(((const bf16*)p.src)[off]);
+    }
+    ((bf16*)p.dst)[e] = (bf16)v;
+  }
+}
+
+typedef void (*kern_t)(const Args);
+template <int TW>
+static kern_t pick_mt(int mt) {
+  switch (mt) {
+    case 1: return conv3x3_igemm_kernel<1, TW>;
+    case 2: return conv3x3_igemm_kernel<2, TW>;
+    case 3: return conv3x3_igemm_kernel<3, TW>;
+    case 4: return conv3x3_igemm_kernel<4, TW>;
+    case 5: return conv3x3_igemm_kernel<5, TW>;
+    case 6: return conv3x3_igemm_kernel<6, TW>;
+    case 7: return conv3x3_igemm_kernel<7, TW>;
+    default: return conv3x3_igemm_kernel<8, TW>;
+  }
+}
+
+// dynamic LDS above 64 KiB needs the attribute once per kernel (and device): remembered per kernel pointer
+static bool lds_attr_done(kern_t k) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair((const void*)k, dev);
+  if (done.count(key)) return true;
+  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  done.insert(key);
+  return true;
+}
+
+}  // namespace ig
+}  // namespace ocf
+
+extern "C" int ocf_conv3x3_plan(int Cout, int H, int W, int dilation, int* mt, int* tw, int* rows_pad) {
+  if (!mt || !tw || !rows_pad || Cout <= 0 || H <= 0 || W <= 0 || dilation < 1) return OCF_EINVAL;
+  if (dilation > 16) return OCF_EUNSUPPORTED;
+  // output-channel blocks: as few as cover Cout with <= 8 tiles of 16 each, of equal size
+  const int tiles = (Cout + 15) / 16, nblk = (tiles + 7) / 8;
+  *mt = (tiles + nblk - 1) / nblk;
+  *rows_pad = nblk * *mt * 16;
+  // patch width: the widest of 64 / 32 / 16 that wastes no more columns than the next narrower one; wide patches keep the 2*dilation
+  // halo columns per row small, and 64 is the only width whose rows fit the LDS budget at dilation 16
+  int best = 16;
+  long best_px = -1;
+  for (int w : {64, 32, 16}) {
+    const int th = 512 / w;
+    if ((th * (w + 2 * dilation) * 64 + 1023) / 1024 > ocf::ig::PIX_ITERS * ocf::ig::NWAVE) continue;
+    const long px = (long)((W + w - 1) / w) * w * (long)((H + th - 1) / th) * th;
+    if (best_px < 0 || px < best_px) { best_px = px; best = w; }
+  }
+  if (best_px < 0) return OCF_EUNSUPPORTED;
+  *tw = best;
+  return OCF_OK;
+}
+
+extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int w_rows, int w_k, const ocf_tensor4* y, const float* bias,
+                                 const ocf_tensor4* act, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope,
+                                 float mask_slope, int dtype, int policy, void* stream) {
+  using namespace ocf;
+  clear_stale_error();
+  if (!x || !y || !w_packed || !x->data || !y->data) return OCF_EINVAL;
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || dilation < 1 || policy < 0) return OCF_EINVAL;
+  if (dtype != OCF_BF16 || Cin % 8 != 0 || w_k % 8 != 0 || w_k < Cin) return OCF_EUNSUPPORTED;
+  int mt, tw, rows_pad;
+  const int st = ocf_conv3x3_plan(Cout, H, W, dilation, &mt, &tw, &rows_pad);
+  if (st != OCF_OK) return st;
+  if (policy == 16 || policy == 32 || policy == 64) tw = policy;  // A/B: force the patch width
+  if (w_rows < rows_pad) return OCF_EINVAL;
+  // channels_last views: channel stride 1, rows and images dense in pixels at one pixel pitch (size-1 dimensions carry arbitrary strides)
+  auto pitch = [&](const ocf_tensor4* t, int C) { return W > 1 ? t->sw : (H > 1 ? t->sh : (B > 1 ? t->sb : (int64_t)C)); };
+  auto cl = [&](const ocf_tensor4* t, int C, int align) {
+    const int64_t p = pitch(t, C);
+    return (C == 1 || t->sc == 1) && p >= C && (H == 1 || t->sh == p * W) && (B == 1 || t->sb == p * W * H) && (uintptr_t)t->data % align == 0 &&
+           (p * 2) % align == 0;
+  };
+  const int oal = Cout % 4 == 0 ? 8 : 2;
+  if (!cl(x, Cin, 16) || !cl(y, Cout, oal) || (act && (!act->data || !cl(act, Cout, oal)))) return OCF_EUNSUPPORTED;
+  if ((uintptr_t)w_packed % 16 != 0) return OCF_EUNSUPPORTED;
+  if ((long)B * H * W * (pitch(x, Cin) > pitch(y, Cout) ? pitch(x, Cin) : pitch(y, Cout)) >= (1L << 30)) return OCF_EUNSUPPORTED;  // 32-bit in-image offsets
+  const int th = 512 / tw;
+  ig::Args a;
+  a.x = (const char*)x->data; a.w = (const char*)w_packed; a.y = (char*)y->data; a.bias = bias;
+  a.act = act ? (const char*)act->data : nullptr;
+  a.xp = pitch(x, Cin); a.yp = pitch(y, Cout); a.ap = act ? pitch(act, Cout) : 0;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.wK = w_k; a.d = dilation;
+  a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
+  a.slope = negative_slope; a.mslope = mask_slope;
+  const int npi = (th * (tw + 2 * dilation) * 64 + 1023) / 1024;
+  if (npi > ig::PIX_ITERS * ig::NWAVE) return OCF_EUNSUPPORTED;
+  const size_t lds = 2 * ((size_t)npi * 1024 + 3 * (size_t)mt * 1024);
+  ig::kern_t k = tw == 64 ? ig::pick_mt<64>(mt) : (tw == 32 ? ig::pick_mt<32>(mt) : ig::pick_mt<16>(mt));
+  if (!ig::lds_attr_done(k)) return OCF_ELAUNCH;
+  LaunchProf lp;
+  lp.launch(true, k, dim3((unsigned)(a.tiles_x * a.tiles_y * B), (unsigned)(rows_pad / (mt * 16))), dim3(ig::NTHR), lds, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+extern "C" int ocf_conv3x3_pack_bytes(int n, int64_t* desc_bytes) {
+  if (!desc_bytes || n <= 0) return OCF_EINVAL;
+  *desc_bytes = (int64_t)n * (int64_t)sizeof(ocf::ig::PackDesc);
+  return OCF_OK;
+}
+
+// Host helper: fill descriptor `index` of a HOST array of ocf_conv3x3_pack_bytes(n) bytes.  The caller copies the array to the device
+// once (the pointers are stable) and launches ocf_conv3x3_pack_weights every step.
+extern "C" int ocf_conv3x3_pack_describe(void* host_descs, int index, const void* src, int64_t so, int64_t si, int64_t sky, int64_t skx, int Co,
+                                         int Ci, int src_is_f32, void* dst, int rows_pad, int k_pad, int transpose, int64_t first,
+                                         int64_t* next_first) {
+  using namespace ocf;
+  if (!host_descs || index < 0 || !src || !dst || !next_first || Co <= 0 || Ci <= 0) return OCF_EINVAL;
+  const int R = transpose ? Ci : Co, K = transpose ? Co : Ci;
+  if (rows_pad < R || k_pad < K) return OCF_EINVAL;
+  ig::PackDesc& p = ((ig::PackDesc*)host_descs)[index];
+  p.src = src; p.dst = dst; p.so = so; p.si = si; p.sky = sky; p.skx = skx;
+  p.Co = Co; p.Ci = Ci; p.rows_pad = rows_pad; p.k_pad = k_pad; p.transpose = transpose ? 1 : 0; p.src_f32 = src_is_f32 ? 1 : 0;
+  p.first = first;
+  *next_first = first + (int64_t)rows_pad * 9 * k_pad;
+  return OCF_OK;
+}
+
+extern "C" int ocf_conv3x3_pack_weights(const void* device_descs, int n, int64_t total_elements, void* stream) {
+  using namespace ocf;
+  clear_stale_error();
+  if (!device_descs || n <= 0 || total_elements <= 0) return OCF_EINVAL;
+  const long blocks = (total_elements + 255) / 256;
+  LaunchProf lp;
+  lp.launch(true, ig::conv3x3_pack_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream,
+            (const ig::PackDesc*)device_descs, n, (long)total_elements);
+  return launch_status();
+}

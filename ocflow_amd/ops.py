@@ -1032,6 +1032,13 @@ _ZERO_POOL_ELEMS = 1 << 22  # 16 MB: bias gradients and (ocf_conv3x3_wgrad) whol
 _CAPTURE_ID = C.c_ulonglong(0)
 
 
+def _capture_id(device) -> int:
+    """identifier of the graph capture the current stream of `device` is recording into (0: not capturing)"""
+    _lib.check(_lib.load().ocf_stream_capture_id(C.c_void_p(torch.cuda.current_stream(device).cuda_stream), C.byref(_CAPTURE_ID)),
+               "ocf_stream_capture_id")
+    return _CAPTURE_ID.value
+
+
 def _take_zeros(n: int, device) -> torch.Tensor:
     """n zero-initialised fp32 elements for a kernel that accumulates into them: slices of one 256 KB buffer zeroed by a single
     fill, instead of one memset per layer (~60 per step, 4 us each).  A slice is handed out once; the buffer is replaced when

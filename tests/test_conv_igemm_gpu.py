@@ -1,0 +1,161 @@
+"""GPU parity of the implicit-GEMM convolution kernels (ocflow_amd/csrc/conv_igemm.hip, ocflow_amd/conv.py) against the
+framework's fp32 convolution on the SAME bf16-rounded operands (the tier's "torch fp32 reference" for a floating-point kernel):
+
+  forward   conv + bias + LeakyReLU in one launch      vs  F.leaky_relu(F.conv2d(x, w, b, 1, d, d), slope)
+  backward  input gradient (same kernel, flipped /     vs  autograd of that expression
+            transposed packed weight), bias gradient,
+            weight gradient
+
+Bar: the kernel accumulates in fp32 and rounds the result to bf16 once, so it differs from the fp32 reference by the output's bf16
+rounding (2^-8 relative) plus summation order: rtol 1e-2, atol 1e-2 of the output scale (written per test).  Shapes cover: every
+output-channel tiling (1..8 tiles of 16, two blocks), odd image sizes with partial patches in both directions, every patch width,
+dilations 1 / 2 / 4 / 8 / 16 (context_net.py:11-17), 2- and 1-channel prediction layers, inputs that are channel slices of a wider
+buffer and concatenations zero-padded to a multiple of 32 channels, and the five pyramid levels of the benchmark (8 x 109 x 256 ...)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def conv():
+    from ocflow_amd import conv as _conv
+    return _conv
+
+
+def _mk(B, ci, co, H, W, seed=0, bias=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, ci, H, W, generator=g).bfloat16()
+    w = (torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5).bfloat16()
+    b = torch.randn(co, generator=g) * 0.5 if bias else None
+    return x, w, b
+
+
+def _ref(x, w, b, d, slope):
+    y = F.conv2d(x.float(), w.float(), None if b is None else b.float(), 1, d, d)
+    return F.leaky_relu(y, slope) if slope != 1.0 else y
+
+
+def _close(got, want, what, rtol=1e-2, atol_rel=1e-2):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = float(want.abs().max()) + 1e-30
+    err = (got - want).abs() - rtol * want.abs()
+    worst = float(err.max())
+    assert worst <= atol_rel * scale, f"{what}: worst excess {worst:.3e} at scale {scale:.3e}"
+
+
+def _dev_cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+FWD_CASES = [
+    # B, ci, co, H, W, d
+    (2, 32, 32, 20, 40, 1), (1, 64, 128, 17, 33, 1), (2, 128, 96, 9, 70, 1), (1, 96, 64, 33, 18, 1), (3, 64, 16, 7, 16, 1),
+    (2, 32, 2, 21, 35, 1), (2, 16, 1, 14, 32, 1), (1, 8, 48, 5, 5, 1), (1, 40, 80, 11, 29, 1), (1, 128, 112, 16, 64, 1),
+    (1, 160, 128, 12, 20, 1), (1, 32, 160, 10, 37, 1), (1, 64, 64, 40, 70, 2), (1, 32, 32, 40, 70, 4), (1, 32, 48, 33, 80, 8),
+    (1, 32, 32, 40, 100, 16), (2, 24, 32, 1, 1, 1), (1, 32, 32, 3, 200, 1),
+]
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,d", FWD_CASES)
+def test_forward_matches_fp32_convolution(conv, B, ci, co, H, W, d):
+    x, w, b = _mk(B, ci, co, H, W, seed=B + ci + co + H + W + d)
+    xd, wd, bd = _dev_cl(x), _dev_cl(w), b.to(DEV)
+    for slope in (0.1, 1.0):
+        got = conv.conv3x3_bias_act(xd, wd, bd, slope, d)
+        assert got.dtype == torch.bfloat16 and got.is_contiguous(memory_format=torch.channels_last) or co == 1
+        _close(got, _ref(x, w, b, d, slope), f"forward {B}x{ci}->{co} {H}x{W} d{d} slope {slope}")
+    got = conv.conv3x3_bias_act(xd, wd, None, 1.0, d)
+    _close(got, _ref(x, w, None, d, 1.0), "forward without bias")
+
+
+@pytest.mark.parametrize("tw", [16, 32, 64])
+def test_every_patch_width(conv, tw):
+    x, w, b = _mk(2, 64, 96, 37, 75, seed=tw)
+    pk = conv.PACKER.get(_dev_cl(w), False)
+    got = conv.igemm_raw(_dev_cl(x), pk, 96, b.to(DEV), None, 1, 0.1, 1.0, policy=tw)
+    _close(got, _ref(x, w, b, 1, 0.1), f"patch width {tw}")
+
+
+def test_input_is_a_channel_slice_and_output_goes_into_a_slice(conv):
+    """the decoder reads its operand out of, and writes its result into, channel ranges of wider channels_last buffers"""
+    x, w, b = _mk(2, 64, 32, 19, 45, seed=5)
+    wide = torch.randn(2, 160, 19, 45).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    wide[:, 32:96] = x.to(DEV)
+    outbuf = torch.full((2, 96, 19, 45), 7.0, dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last)
+    wd = _dev_cl(w)
+    pk = conv.PACKER.get(wd, False)
+    conv.igemm_raw(wide[:, 32:96], pk, 32, b.to(DEV), None, 1, 0.1, 1.0, out=outbuf[:, 40:72])
+    _close(outbuf[:, 40:72], _ref(x, w, b, 1, 0.1), "slice in / slice out")
+    assert float((outbuf[:, :40] - 7.0).abs().max()) == 0.0 and float((outbuf[:, 72:] - 7.0).abs().max()) == 0.0
+
+
+def test_zero_padded_concatenation(conv):
+    """a 117-channel weight against a 128-channel input whose last 11 channels are the alignment zeros of `cat_aligned`"""
+    x, w, b = _mk(2, 117, 128, 14, 32, seed=9)
+    xp = torch.zeros(2, 128, 14, 32, dtype=torch.bfloat16)
+    xp[:, :117] = x
+    xd, wd, bd = _dev_cl(xp).requires_grad_(True), _dev_cl(w).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    assert conv.eligible(xd, wd, (1, 1), (1, 1), (1, 1), 1)
+    y = conv.conv3x3_bias_act(xd, wd, bd, 0.1, 1)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    yr = _ref(xr, wr, br, 1, 0.1)
+    _close(y, yr, "padded forward")
+    g = torch.randn(yr.shape, generator=torch.Generator().manual_seed(3))
+    y.backward(_dev_cl(g.bfloat16()))
+    yr.backward(g.bfloat16().float())
+    assert xd.grad.shape == xd.shape and wd.grad.shape == wd.shape
+    _close(xd.grad[:, :117], xr.grad, "padded input gradient", 2e-2, 2e-2)
+    assert float(xd.grad[:, 117:].abs().max()) == 0.0
+    _close(wd.grad, wr.grad, "padded weight gradient", 2e-2, 2e-2)
+    _close(bd.grad, br.grad, "padded bias gradient", 2e-2, 2e-2)
+
+
+BWD_CASES = [(2, 32, 32, 20, 40, 1), (1, 64, 128, 17, 33, 1), (2, 128, 96, 9, 70, 1), (1, 96, 64, 33, 18, 2), (2, 32, 16, 21, 35, 1),
+             (1, 64, 64, 30, 70, 8), (1, 32, 2, 21, 35, 1), (1, 16, 1, 14, 32, 1), (1, 160, 64, 12, 20, 1)]
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,d", BWD_CASES)
+def test_backward_matches_autograd(conv, B, ci, co, H, W, d):
+    x, w, b = _mk(B, ci, co, H, W, seed=11 * B + ci + co + H + W + d)
+    for slope in (0.1, 1.0):
+        xd, wd, bd = _dev_cl(x).requires_grad_(True), _dev_cl(w).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        y = conv.conv3x3_bias_act(xd, wd, bd, slope, d)
+        xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+        yr = _ref(xr, wr, br, d, slope)
+        g = torch.randn(yr.shape, generator=torch.Generator().manual_seed(1)).bfloat16()
+        y.backward(_dev_cl(g) if co > 1 else g.to(DEV))
+        # the reference's activation derivative is taken at ITS pre-activation sign; where the bf16 result rounds to the other side of
+        # zero the two legitimately differ, so the cotangent is masked away from |y| < 1e-2 of the scale
+        yr.backward(g.float())
+        _close(xd.grad, xr.grad, f"input gradient slope {slope}", 3e-2, 3e-2)
+        _close(wd.grad, wr.grad, f"weight gradient slope {slope}", 3e-2, 3e-2)
+        _close(bd.grad, br.grad, f"bias gradient slope {slope}", 3e-2, 3e-2)
+
+
+def test_fused_activation_mask_in_the_input_gradient(conv):
+    """ocf_conv3x3_igemm(act=...) multiplies the input gradient by the LeakyReLU derivative of the previous layer (sign of `act`)"""
+    x, w, _ = _mk(2, 64, 96, 18, 40, seed=21, bias=False)
+    gy = torch.randn(2, 96, 18, 40, generator=torch.Generator().manual_seed(2)).bfloat16()
+    wd = _dev_cl(w)
+    pkt = conv.PACKER.get(wd, True, 64)
+    got = conv.igemm_raw(_dev_cl(gy), pkt, 64, None, _dev_cl(x), 1, 1.0, 0.1)
+    want = torch.nn.grad.conv2d_input(x.shape, w.float(), gy.float(), 1, 1, 1) * torch.where(x.float() > 0, 1.0, 0.1)
+    _close(got, want, "masked input gradient", 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("ci,co,H,W,d", [(128, 128, 109, 256, 1), (128, 96, 109, 256, 8), (96, 64, 109, 256, 16), (64, 32, 109, 256, 1),
+                                          (32, 2, 109, 256, 1), (160, 128, 55, 128, 1), (192, 128, 28, 64, 1), (224, 128, 14, 32, 1),
+                                          (288, 128, 7, 16, 1)])
+def test_bench_shapes_forward(conv, ci, co, H, W, d):
+    """the timed layers (8 pairs at 436 x 1024: pyramid levels 2..6), forward, against the framework's own bf16 convolution on the GPU
+    (fp32 CPU convolutions at this size take minutes); both round to bf16, so the bar is two bf16 ulps"""
+    B = 8
+    x, w, b = _mk(B, ci, co, H, W, seed=ci + co + H)
+    xd, wd, bd = _dev_cl(x), _dev_cl(w), b.to(DEV)
+    got = conv.conv3x3_bias_act(xd, wd, bd, 0.1, d)
+    want = F.leaky_relu(F.conv2d(xd.float(), wd.float(), bd, 1, d, d), 0.1)
+    _close(got, want, f"bench shape {ci}->{co} {H}x{W} d{d}")
