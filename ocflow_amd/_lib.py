@@ -72,7 +72,7 @@ SIGNATURES = {
     "ocf_ssim_bwd": [_T4P, _T4P, _vp, _T4P, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_sqdiff": [_T4P, _T4P, _vp, _i, _i, _i, _i, _vp],
     "ocf_conv3x3_wgrad": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "ocf_conv3x3_plan": [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "ocf_conv3x3_plan": [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "ocf_conv3x3_igemm": [_T4P, _vp, _i, _i, _T4P, _vp, _T4P, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp],
     "ocf_conv3x3_pack_bytes": [_i, C.POINTER(C.c_int64)],
     "ocf_conv3x3_pack_describe": [_vp, _i, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _vp, _i, _i, _i, C.c_int64,

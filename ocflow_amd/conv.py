@@ -26,18 +26,18 @@ from . import ops
 from .ops import _t4, _stream, _require_hip, _ptr
 
 
-def plan(cout: int, h: int, w: int, dilation: int) -> Tuple[int, int, int]:
-    """(16-row tiles per workgroup, patch width, padded rows of the packed weight) ocf_conv3x3_igemm uses for this output"""
+def plan(cout: int, b: int, h: int, w: int, dilation: int) -> Tuple[int, int, int]:
+    """(16-row tiles per workgroup, patch width, rows of the packed weight it reads) ocf_conv3x3_igemm uses for this output"""
     mt, tw, rows = C.c_int(0), C.c_int(0), C.c_int(0)
-    _lib.check(_lib.load().ocf_conv3x3_plan(int(cout), int(h), int(w), int(dilation), C.byref(mt), C.byref(tw), C.byref(rows)), "ocf_conv3x3_plan")
+    _lib.check(_lib.load().ocf_conv3x3_plan(int(cout), int(b), int(h), int(w), int(dilation), C.byref(mt), C.byref(tw), C.byref(rows)),
+               "ocf_conv3x3_plan")
     return mt.value, tw.value, rows.value
 
 
 def _rows_pad(n: int) -> int:
-    """rows of a packed weight: what ocf_conv3x3_plan asks for (equal blocks of <= 8 tiles of 16 rows); independent of the image size"""
-    tiles = (n + 15) // 16
-    nblk = (tiles + 7) // 8
-    return nblk * ((tiles + nblk - 1) // nblk) * 16
+    """rows of a packed weight: enough for every split of the output channels into equal blocks of <= 8 tiles of 16 rows that
+    ocf_conv3x3_plan may choose (it depends on the image size; the packed copy does not)"""
+    return ((n + 15) // 16 + 7) * 16
 
 
 class _Packed:

@@ -300,16 +300,12 @@ static bool lds_attr_done(kern_t k) {
 }  // namespace ig
 }  // namespace ocf
 
-extern "C" int ocf_conv3x3_plan(int Cout, int H, int W, int dilation, int* mt, int* tw, int* rows_pad) {
-  if (!mt || !tw || !rows_pad || Cout <= 0 || H <= 0 || W <= 0 || dilation < 1) return OCF_EINVAL;
+extern "C" int ocf_conv3x3_plan(int Cout, int B, int H, int W, int dilation, int* mt, int* tw, int* rows_needed) {
+  if (!mt || !tw || !rows_needed || Cout <= 0 || B <= 0 || H <= 0 || W <= 0 || dilation < 1) return OCF_EINVAL;
   if (dilation > 16) return OCF_EUNSUPPORTED;
-  // output-channel blocks: as few as cover Cout with <= 8 tiles of 16 each, of equal size
-  const int tiles = (Cout + 15) / 16, nblk = (tiles + 7) / 8;
-  *mt = (tiles + nblk - 1) / nblk;
-  *rows_pad = nblk * *mt * 16;
-  // patch width: the widest of 64 / 32 / 16 that wastes no more columns than the next narrower one; wide patches keep the 2*dilation
-  // halo columns per row small, and 64 is the only width whose rows fit the LDS budget at dilation 16
-  int best = 16;
+  // patch width: the one of 64 / 32 / 16 that covers the image with the fewest patch pixels (ties: the widest -- wide patches keep the
+  // 2 * dilation halo columns per row small, and 64 is the only width whose rows fit the LDS budget at dilation 16)
+  int best = 0;
   long best_px = -1;
   for (int w : {64, 32, 16}) {
     const int th = 512 / w;
@@ -319,6 +315,18 @@ extern "C" int ocf_conv3x3_plan(int Cout, int H, int W, int dilation, int* mt, i
   }
   if (best_px < 0) return OCF_EUNSUPPORTED;
   *tw = best;
+  // output-channel blocks: as few equal blocks of <= 8 tiles of 16 channels as cover Cout; more of them while the launch would leave
+  // most of the chip idle (a pyramid level of 8 x 55 x 128 pixels is 112 patches for 256 compute units)
+  const long patches = best_px / 512 * B;
+  const int tiles = (Cout + 15) / 16;
+  int nblk = (tiles + 7) / 8, m = (tiles + nblk - 1) / nblk;
+  while (patches * nblk < 192 && m > 2) {
+    nblk++;
+    m = (tiles + nblk - 1) / nblk;
+  }
+  nblk = (tiles + m - 1) / m;
+  *mt = m;
+  *rows_needed = nblk * m * 16;
   return OCF_OK;
 }
 
@@ -331,7 +339,7 @@ extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || dilation < 1 || policy < 0) return OCF_EINVAL;
   if (dtype != OCF_BF16 || Cin % 8 != 0 || w_k % 8 != 0 || w_k < Cin) return OCF_EUNSUPPORTED;
   int mt, tw, rows_pad;
-  const int st = ocf_conv3x3_plan(Cout, H, W, dilation, &mt, &tw, &rows_pad);
+  const int st = ocf_conv3x3_plan(Cout, B, H, W, dilation, &mt, &tw, &rows_pad);
   if (st != OCF_OK) return st;
   if (policy == 16 || policy == 32 || policy == 64) tw = policy;  // A/B: force the patch width
   if (w_rows < rows_pad) return OCF_EINVAL;

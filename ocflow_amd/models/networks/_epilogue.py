@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ocflow_amd import conv as nconv
 from ocflow_amd import ops
 
 CHANNEL_ALIGN = 32  # channels; see cat_aligned
@@ -164,10 +165,23 @@ def _native_wgrad() -> str:
     return "" if v == "0" else v
 
 
+NATIVE_MIN_PIXELS = int(os.environ.get("OCFLOW_NATIVE_CONV_MIN_PIXELS", "32768"))
+
+
+def _native(conv: nn.Conv2d, x) -> bool:
+    """does this layer run on the repo's implicit-GEMM kernel (ocflow_amd.conv)?  3x3 / stride-1 / padding == dilation layers on bf16
+    channels_last inputs of at least NATIVE_MIN_PIXELS pixels: below that a launch has fewer patches than the chip has compute units and
+    the framework's kernels are ahead (profiles/r4_b_bench_conv.txt: ahead at 8 x 109 x 256 and 8 x 55 x 128, behind from 8 x 28 x 64 down)"""
+    return (nconv.enabled() and conv.padding_mode == "zeros" and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] >= NATIVE_MIN_PIXELS
+            and nconv.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups))
+
+
 def conv_lrelu(conv: nn.Conv2d, x, negative_slope: float = 0.1):
     # OCFLOW_UNFUSED_EPILOGUE=1: the reference's own op chain (A/B switch for measurements and bisecting, not a fallback)
     if conv.bias is None or conv.padding_mode != "zeros" or _unfused():
         return F.leaky_relu(_conv_module(conv, x), negative_slope)
+    if _native(conv, x):
+        return nconv.conv3x3_bias_act(x, conv.weight, conv.bias, negative_slope, conv.dilation[0])
     return ops.bias_leaky_relu(_conv_nobias(conv, x), conv.bias, negative_slope)
 
 
@@ -188,6 +202,8 @@ def conv_bias(conv: nn.Conv2d, x):
     """nn.Conv2d(bias=True) without activation (prediction layers): bias-free convolution + in-place bias kernel"""
     if conv.bias is None or conv.padding_mode != "zeros" or _unfused():
         return _conv_module(conv, x)
+    if _native(conv, x):
+        return nconv.conv3x3_bias_act(x, conv.weight, conv.bias, 1.0, conv.dilation[0])
     return ops.bias_add(_conv_nobias(conv, x), conv.bias)
 
 
