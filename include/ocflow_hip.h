@@ -329,6 +329,18 @@ int ocf_conv3x3_pack_describe(void* host_descs, int index, const void* src, int6
                               int src_is_f32, void* dst, int rows_pad, int k_pad, int transpose, int64_t first, int64_t* next_first);
 int ocf_conv3x3_pack_weights(const void* device_descs, int n, int64_t total_elements, void* stream);
 
+/* Weight AND bias gradient of the same layers in one launch, accumulated (float atomics) into the caller's zeroed fp32 buffers:
+ *   gw[co][ci][ky][kx] += sum_{b,y,x} dz[b,co,y,x] * x[b,ci, y+(ky-1)*dilation, x+(kx-1)*dilation]      gbias[co] += sum dz[b,co,y,x]
+ * dz = the gradient w.r.t. the convolution's OUTPUT before bias / after the activation's derivative has been applied (what
+ * ocf_conv3x3_igemm's `act` epilogue or ocf_bias_act_bwd produce).  x, dz: channels_last views with 16-byte aligned pixels (channel
+ * slices of wider buffers included) whose pixel pitch covers the channel count rounded up to 8, dilation <= 16; gw any element strides (the flat fp32 gradient buffer of a
+ * training step, in the parameter's own layout); gbias may be NULL.  policy: 0 = automatic; otherwise
+ * chunks + 1000 * ci_waves + 10000 * co_waves (tuning).  Third version of the kernel: one tap row per workgroup, one row segment of each
+ * operand per stage, pixel slices summed through LDS before the atomics (csrc/conv_wgrad3.hip).
+ * replaces: the weight and bias halves of autograd's convolution_backward + sum((0,2,3)) for the layers listed above. */
+int ocf_conv3x3_wgrad_bias(const ocf_tensor4* x, const ocf_tensor4* dz, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky, int64_t gw_skx,
+                           float* gbias, int B, int Ci, int Co, int H, int W, int dilation, int dtype, int policy, void* stream);
+
 /* ---- BatchNorm2d (batch statistics) + LeakyReLU of the feature-pyramid encoder
  * replaces: nn.BatchNorm2d + nn.LeakyReLU(0.1) of the reference's `conv_bn_relu` blocks (models/networks/feature_pyramid_net.py:5-95), i.e.
  * torch.batch_norm(training) + leaky_relu and their autograd.  Dense channels_last x / y / gy / gx of `dtype` (OCF_F32 / OCF_BF16), C a

@@ -153,6 +153,32 @@ def igemm_raw(x, packed: _Packed, cout: int, bias=None, act=None, dilation: int 
     return out
 
 
+def wgrad_bias_raw(x, dz, gw, gbias=None, dilation: int = 1, policy: int = 0):
+    """ocf_conv3x3_wgrad_bias: gw (fp32 [Co,Ci,3,3], any strides) += dW, gbias (fp32 [Co] or None) += sum dz; both must be zeroed by the caller"""
+    _require_hip(x, dz)
+    B, _, H, W = x.shape
+    co, ci = int(gw.shape[0]), int(gw.shape[1])
+    so, si, sky, skx = gw.stride()
+    with torch.cuda.device(x.device):
+        fn = lambda: _lib.check(_lib.load().ocf_conv3x3_wgrad_bias(_t4(x), _t4(dz), C.c_void_p(gw.data_ptr()), so, si, sky, skx, _ptr(gbias), B, ci, co,
+                                                                    H, W, int(dilation), _lib.OCF_BF16, int(policy), _stream(x)),
+                                "ocf_conv3x3_wgrad_bias")
+        ops._launch("conv3x3_wgrad", lambda: ops._meta(f"B{B}x{ci}->{co}x{H}x{W}d{dilation}", B * H * W * 2 * (ci + co), 2 * B * H * W * 9 * ci * co), fn)
+    return gw
+
+
+def wgrad_eligible(x, dz, ci: int, co: int) -> bool:
+    """operands ocf_conv3x3_wgrad_bias takes: bf16 pixel-major views with 16-byte aligned pixels that hold the channel counts rounded up to 8"""
+    if not (x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and _pixel_major(x, 16) and _pixel_major(dz, 16)):
+        return False
+
+    def pitch(t):
+        B, C_, H, W = t.shape
+        sb, sc, sh, sw = t.stride()
+        return sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C_))
+    return pitch(x) >= (ci + 7) // 8 * 8 and pitch(dz) >= (co + 7) // 8 * 8
+
+
 def eligible(x, weight, stride, padding, dilation, groups) -> bool:
     """layers ocf_conv3x3_igemm takes: bf16 channels_last activations with a multiple of 8 channels, 3x3, stride 1, padding == dilation <= 16"""
     if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4):
@@ -209,9 +235,11 @@ class _ConvBiasActFn(Function):
         gg = gy if gy.dtype == y.dtype else gy.to(y.dtype)
         if not _pixel_major(gg, 2):
             gg = gg.contiguous(memory_format=torch.channels_last)
-        # dz = gy * lrelu'(y), dbias = sum dz: one pass (the existing epilogue-backward kernel)
+        # dz = gy * lrelu'(y): one elementwise pass (ocf_bias_act_bwd, which also reduces the bias gradient); a layer without activation
+        # needs no pass at all when the weight-gradient kernel takes the bias gradient along
+        use_wg3 = need_w and _native_wgrad() and wgrad_eligible(x, gg, weight.shape[1], co)
         gb = None
-        if slope != 1.0 or need_b:
+        if slope != 1.0 or (need_b and not use_wg3):
             gb = ops._take_zeros(co, gy.device)
             dz = torch.empty_like(y) if slope != 1.0 else None
             with torch.cuda.device(gy.device):
@@ -230,13 +258,21 @@ class _ConvBiasActFn(Function):
                 dzc = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
                 gx = torch.ops.aten.convolution_backward(dzc, x, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False, (0, 0), 1,
                                                          [True, False, False])[0]
-        if need_w:
+        if need_w and use_wg3 and wgrad_eligible(x, dz, weight.shape[1], co):
+            acc = ops._take_zeros(weight.numel(), gy.device).as_strided(weight.shape, weight.stride())
+            gb2 = None
+            if need_b and gb is None:
+                gb2 = gb = ops._take_zeros(co, gy.device)
+            gw = wgrad_bias_raw(x, dz, acc, gb2, d)
+        elif need_w:
             dzc = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
             xc = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
             gw = torch.ops.aten.convolution_backward(dzc, xc, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False, (0, 0), 1,
                                                      [False, True, False])[1]
             if gw.shape[1] != weight.shape[1]:
                 gw = gw[:, :weight.shape[1]].contiguous(memory_format=torch.channels_last)
+        if need_b and gb is None:
+            gb = dz.float().sum((0, 2, 3))
         if gb is not None and need_b and bias_dtype != torch.float32:
             gb = gb.to(bias_dtype)
         return gx, gw, (gb if need_b else None), None, None
@@ -246,6 +282,11 @@ def conv3x3_bias_act(x, weight, bias=None, negative_slope: float = 1.0, dilation
     """`F.leaky_relu(F.conv2d(x, weight, bias, 1, dilation, dilation), negative_slope)` (negative_slope = 1: no activation) on the
     implicit-GEMM kernel; the caller checks `eligible` first"""
     return _ConvBiasActFn.apply(x, weight, bias, float(negative_slope), int(dilation))
+
+
+def _native_wgrad() -> bool:
+    """OCFLOW_NATIVE_WGRAD3: "1" (default) takes the weight gradient from ocf_conv3x3_wgrad_bias, "0" from the framework"""
+    return os.environ.get("OCFLOW_NATIVE_WGRAD3", "1") != "0"
 
 
 def enabled() -> bool:

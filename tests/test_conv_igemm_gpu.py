@@ -159,3 +159,51 @@ def test_bench_shapes_forward(conv, ci, co, H, W, d):
     got = conv.conv3x3_bias_act(xd, wd, bd, 0.1, d)
     want = F.leaky_relu(F.conv2d(xd.float(), wd.float(), bd, 1, d, d), 0.1)
     _close(got, want, f"bench shape {ci}->{co} {H}x{W} d{d}")
+
+
+WG_CASES = [
+    # B, ci, co, H, W, d  -- every (co waves, ci waves) configuration of the kernel, partial segments, channel tails, several chunks
+    (2, 128, 128, 20, 70, 1), (1, 64, 128, 17, 33, 1), (2, 128, 64, 9, 70, 2), (1, 64, 64, 33, 40, 1), (2, 128, 32, 21, 35, 1),
+    (2, 64, 32, 19, 37, 1), (1, 96, 96, 12, 64, 4), (1, 160, 128, 12, 20, 1), (1, 32, 16, 14, 32, 1), (1, 64, 96, 30, 100, 16),
+    (2, 256, 128, 7, 16, 1), (1, 24, 40, 5, 9, 1), (8, 64, 32, 28, 64, 1),
+]
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,d", WG_CASES)
+def test_weight_and_bias_gradient_kernel(conv, B, ci, co, H, W, d):
+    """ocf_conv3x3_wgrad_bias against autograd of the fp32 convolution on the same bf16-rounded operands (fp32 accumulation in both:
+    the bar is summation order + the atomics' arrival order, 2e-3 of the gradient's scale)"""
+    g = torch.Generator().manual_seed(ci + co + H + W + d)
+    x = torch.randn(B, ci, H, W, generator=g).bfloat16()
+    dz = torch.randn(B, co, H, W, generator=g).bfloat16()
+    w = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    bz = torch.zeros(co, requires_grad=True)
+    F.conv2d(x.float(), w, bz, 1, d, d).backward(dz.float())
+    gw = torch.zeros(co, ci, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    gb = torch.zeros(co, device=DEV)
+    conv.wgrad_bias_raw(_dev_cl(x), _dev_cl(dz), gw, gb, d)
+    _close(gw, w.grad, "weight gradient", 2e-3, 2e-3)
+    _close(gb, bz.grad, "bias gradient", 2e-3, 2e-3)
+    # accumulation: a second launch doubles the sums; NCHW-strided gradient buffer
+    gw2 = torch.zeros(co, ci, 3, 3, device=DEV)
+    conv.wgrad_bias_raw(_dev_cl(x), _dev_cl(dz), gw2, None, d)
+    conv.wgrad_bias_raw(_dev_cl(x), _dev_cl(dz), gw2, None, d)
+    _close(gw2, 2 * w.grad, "accumulated weight gradient", 2e-3, 2e-3)
+
+
+def test_weight_gradient_of_a_padded_concatenation_and_sliced_operands(conv):
+    """117 real input channels inside a 128-channel buffer; dz a channel slice of a wider gradient buffer"""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 117, 14, 40, generator=g).bfloat16()
+    dz = torch.randn(2, 96, 14, 40, generator=g).bfloat16()
+    xp = torch.zeros(2, 128, 14, 40, dtype=torch.bfloat16)
+    xp[:, :117] = x
+    xp[:, 117:] = 3.0  # whatever sits in the alignment channels must not reach the gradient
+    wide = torch.randn(2, 160, 14, 40).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    wide[:, 32:128] = dz.to(DEV)
+    w = torch.zeros(96, 117, 3, 3, requires_grad=True)
+    F.conv2d(x.float(), w, None, 1, 1, 1).backward(dz.float())
+    gw = torch.zeros(96, 117, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    assert conv.wgrad_eligible(_dev_cl(xp), wide[:, 32:128], 117, 96)
+    conv.wgrad_bias_raw(_dev_cl(xp), wide[:, 32:128], gw, None, 1)
+    _close(gw, w.grad, "weight gradient, padded input / sliced gradient", 2e-3, 2e-3)
