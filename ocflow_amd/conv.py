@@ -278,6 +278,96 @@ class _ConvBiasActFn(Function):
         return gx, gw, (gb if need_b else None), None, None
 
 
+class _ConvChainFn(Function):
+    """conv -> bias -> LeakyReLU, n times, the output of each layer feeding only the next (the estimators' conv1..conv5, the context
+    network's conv1..conv6: flow_net.py:25-37, flow_occ_net.py:33-45, context_net.py:20-27) as ONE autograd node.
+    forward : n launches of ocf_conv3x3_igemm (bias + activation fused).
+    backward: per layer ONE ocf_conv3x3_wgrad_bias (weight + bias gradient into fp32) and ONE ocf_conv3x3_igemm whose epilogue applies the
+    PREVIOUS layer's LeakyReLU derivative (`act` = that layer's saved output) -- the elementwise leaky_relu_backward / bias-sum pass
+    of the per-layer form runs once per chain (for the last layer, whose output has other consumers) instead of once per layer."""
+
+    @staticmethod
+    def forward(ctx, x, slopes, dils, *params):
+        n = len(slopes)
+        ws, bs = params[:n], params[n:]
+        ys = []
+        h = x
+        for i in range(n):
+            h = igemm_raw(h, PACKER.get(ws[i], False), ws[i].shape[0], bs[i], None, dils[i], slopes[i], 1.0)
+            ys.append(h)
+        ctx.save_for_backward(x, *ws, *ys)
+        ctx.cfg = (tuple(slopes), tuple(dils), tuple(b.dtype for b in bs))
+        return h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        slopes, dils, bias_dtypes = ctx.cfg
+        n = len(slopes)
+        saved = ctx.saved_tensors
+        x, ws, ys = saved[0], saved[1:1 + n], saved[1 + n:]
+        dev = gy.device
+        B, _, H, W = x.shape
+        gg = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
+        if not _pixel_major(gg, 16):
+            gg = gg.contiguous(memory_format=torch.channels_last)
+        gws, gbs = [None] * n, [None] * n
+        # the last layer's activation derivative: the one elementwise pass of the chain (it also reduces that layer's bias gradient)
+        if slopes[-1] != 1.0:
+            y = ys[-1]
+            co = y.shape[1]
+            dz = torch.empty_like(y)
+            gbs[-1] = ops._take_zeros(co, dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y), _t4(gg), _t4(dz), C.c_void_p(gbs[-1].data_ptr()), B, co, H, W, slopes[-1], 1,
+                                                        _lib.OCF_BF16, _stream(gg)), "ocf_bias_act_bwd")
+        else:
+            dz = gg
+        gx = None
+        for i in range(n - 1, -1, -1):
+            xin = ys[i - 1] if i > 0 else x
+            w = ws[i]
+            if ctx.needs_input_grad[3 + i] or ctx.needs_input_grad[3 + n + i]:
+                gws[i] = ops._take_zeros(w.numel(), dev).as_strided(w.shape, w.stride())
+                gb = None
+                if gbs[i] is None and ctx.needs_input_grad[3 + n + i]:
+                    gb = gbs[i] = ops._take_zeros(w.shape[0], dev)
+                wgrad_bias_raw(xin, dz, gws[i], gb, dils[i])
+            if i > 0:
+                masked = slopes[i - 1] != 1.0
+                dz = igemm_raw(dz, PACKER.get(w, True, xin.shape[1]), xin.shape[1], None, xin if masked else None, dils[i], 1.0,
+                               slopes[i - 1] if masked else 1.0)
+            elif ctx.needs_input_grad[0]:
+                gx = igemm_raw(dz, PACKER.get(w, True, x.shape[1]), x.shape[1], None, None, dils[i], 1.0, 1.0)
+        gbs = [g if (g is None or dt == torch.float32) else g.to(dt) for g, dt in zip(gbs, bias_dtypes)]
+        return (gx, None, None, *gws, *gbs)
+
+
+def conv3x3_chain(x, weights, biases, slopes, dilations):
+    """n x (3x3 convolution + bias + LeakyReLU) as one autograd node; the caller checks `chain_eligible` first"""
+    return _ConvChainFn.apply(x, tuple(float(s) for s in slopes), tuple(int(d) for d in dilations), *weights, *biases)
+
+
+def chain_eligible(x, convs) -> bool:
+    """every layer of the chain runs on the implicit-GEMM kernels forward AND backward: `eligible` inputs, output channels a multiple of 8
+    (the next layer's input and this layer's gradient operand), biases present"""
+    if not (enabled() and _native_wgrad()):
+        return False
+    cin = x.shape[1]
+    for k, c in enumerate(convs):
+        w = c.weight
+        if c.bias is None or c.padding_mode != "zeros" or w.shape[0] % 8 != 0 or tuple(w.shape[2:]) != (3, 3) or c.groups != 1 \
+                or tuple(c.stride) != (1, 1) or c.dilation[0] != c.dilation[1] or tuple(c.padding) != tuple(c.dilation) or c.dilation[0] > 16:
+            return False
+        if k == 0:
+            if not eligible(x, w, c.stride, c.padding, c.dilation, c.groups):
+                return False
+        elif w.shape[1] != cin:
+            return False
+        cin = w.shape[0]
+    return True
+
+
 def conv3x3_bias_act(x, weight, bias=None, negative_slope: float = 1.0, dilation: int = 1):
     """`F.leaky_relu(F.conv2d(x, weight, bias, 1, dilation, dilation), negative_slope)` (negative_slope = 1: no activation) on the
     implicit-GEMM kernel; the caller checks `eligible` first"""

@@ -244,18 +244,15 @@ struct PackDesc {
 };
 
 __global__ void conv3x3_pack_kernel(const PackDesc* __restrict__ descs, int n, long total) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {  // last descriptor with first <= i
-      const int mid = (lo + hi + 1) >> 1;
-      if (descs[mid].first <= i) lo = mid; else hi = mid - 1;
-    }
-    const PackDesc& p = descs[lo];
-    const long e = i - p.first;
+  // blockIdx.y = tensor, blockIdx.x strides over its packed elements (the first version searched the descriptor of every element:
+  // 59 us for the 150 tensors of a step)
+  const PackDesc p = descs[blockIdx.y];
+  const long count = (long)p.rows_pad * 9 * p.k_pad;
+  const int R = p.transpose ? p.Ci : p.Co, K = p.transpose ? p.Co : p.Ci;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
     const int k = (int)(e % p.k_pad);
-    const int tap = (int)((e / p.k_pad) % 9);
-    const int row = (int)(e / ((long)p.k_pad * 9));
-    const int R = p.transpose ? p.Ci : p.Co, K = p.transpose ? p.Co : p.Ci;
+    const int rt = (int)(e / p.k_pad);
+    const int tap = rt % 9, row = rt / 9;
     float v = 0.f;
     if (row < R && k < K) {
       const int ky = tap / 3, kx = tap - 3 * ky;
@@ -399,9 +396,9 @@ extern "C" int ocf_conv3x3_pack_weights(const void* device_descs, int n, int64_t
   using namespace ocf;
   clear_stale_error();
   if (!device_descs || n <= 0 || total_elements <= 0) return OCF_EINVAL;
-  const long blocks = (total_elements + 255) / 256;
+  if (n > 65535) return OCF_EUNSUPPORTED;
   LaunchProf lp;
-  lp.launch(true, ig::conv3x3_pack_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream,
+  lp.launch(true, ig::conv3x3_pack_kernel, dim3(16, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
             (const ig::PackDesc*)device_descs, n, (long)total_elements);
   return launch_status();
 }

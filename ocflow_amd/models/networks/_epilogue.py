@@ -185,6 +185,21 @@ def conv_lrelu(conv: nn.Conv2d, x, negative_slope: float = 0.1):
     return ops.bias_leaky_relu(_conv_nobias(conv, x), conv.bias, negative_slope)
 
 
+def conv_lrelu_chain(convs, x, negative_slope: float = 0.1):
+    """`for conv in convs: x = F.leaky_relu(conv(x), negative_slope)` for layers whose outputs feed only the next one (conv1..conv5 of the
+    estimators, flow_net.py:25-37 / flow_occ_net.py:33-45; conv1..conv6 of the context network, context_net.py:20-27).  On the
+    implicit-GEMM kernels the chain is ONE autograd node (ocflow_amd.conv.conv3x3_chain): the activation derivative of every inner
+    layer is applied in the epilogue of the next layer's input-gradient kernel.  Anything else: layer by layer."""
+    convs = list(convs)
+    if not _unfused() and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] >= NATIVE_MIN_PIXELS and len(convs) > 1 \
+            and nconv.chain_eligible(x, convs):
+        return nconv.conv3x3_chain(x, [c.weight for c in convs], [c.bias for c in convs], [negative_slope] * len(convs),
+                                   [c.dilation[0] for c in convs])
+    for c in convs:
+        x = conv_lrelu(c, x, negative_slope)
+    return x
+
+
 def _conv_module(conv: nn.Conv2d, x):
     """conv(x) with the module's own bias / padding mode, for an input that may carry the alignment channels of `cat_aligned`"""
     if x.shape[1] == conv.weight.shape[1] or conv.groups != 1:

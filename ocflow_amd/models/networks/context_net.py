@@ -2,7 +2,7 @@
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._epilogue import conv_bias, conv_lrelu
+from ._epilogue import conv_bias, conv_lrelu_chain
 
 _PLAN = ((128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (2, 1))  # (out channels, dilation)
 
@@ -16,6 +16,5 @@ class ContextNetwork(nn.Module):
             cin = cout
 
     def forward(self, x):
-        for i in range(1, len(_PLAN)):
-            x = conv_lrelu(getattr(self, f"conv{i}"), x, 0.1)
+        x = conv_lrelu_chain([getattr(self, f"conv{i}") for i in range(1, len(_PLAN))], x, 0.1)
         return conv_bias(getattr(self, f"conv{len(_PLAN)}"), x)

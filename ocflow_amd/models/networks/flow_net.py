@@ -6,7 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ocflow_amd import ops
-from ._epilogue import cat_aligned, conv_bias, conv_lrelu, deconv_bias
+from ._epilogue import cat_aligned, conv_bias, conv_lrelu, conv_lrelu_chain, deconv_bias
 from .context_net import ContextNetwork
 from .feature_pyramid_net import FeaturePyramidNet
 
@@ -40,8 +40,7 @@ class OpticalFlowEstimator(nn.Module):
         self.upconv2 = nn.ConvTranspose2d(32, 2, 3, 2, 1)
 
     def forward(self, x, h_up=None, w_up=None):
-        for i in range(1, 6):
-            x = conv_lrelu(getattr(self, f"conv{i}"), x, 0.1)
+        x = conv_lrelu_chain([getattr(self, f"conv{i}") for i in range(1, 6)], x, 0.1)
         flow = conv_bias(self.conv6, x)
         if self.highest_res:
             return flow, x

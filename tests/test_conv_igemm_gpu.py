@@ -207,3 +207,56 @@ def test_weight_gradient_of_a_padded_concatenation_and_sliced_operands(conv):
     assert conv.wgrad_eligible(_dev_cl(xp), wide[:, 32:128], 117, 96)
     conv.wgrad_bias_raw(_dev_cl(xp), wide[:, 32:128], gw, None, 1)
     _close(gw, w.grad, "weight gradient, padded input / sliced gradient", 2e-3, 2e-3)
+
+
+def _l2(got, want):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    return float((got - want).norm() / (want.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("dils", [(1, 1, 1, 1, 1), (1, 2, 4)])
+def test_chain_matches_layer_by_layer_autograd(conv, dils):
+    """conv3x3_chain (one autograd node: the activation derivative of the inner layers fused into the input-gradient kernels, weight and
+    bias gradients from ocf_conv3x3_wgrad_bias) against
+    (1) the SAME layers run one autograd node each (conv3x3_bias_act, itself checked against fp32 autograd above): identical forward
+        values, gradients within two bf16 roundings of the hand-off between layers (1e-2 of the scale);
+    (2) fp32 autograd with every layer's output rounded to bf16.  A stack of LeakyReLU layers is ill-conditioned in its masks: the fp64
+        and the rounded fp32 reference of this very test differ by 7 % (L2) in the input gradient at depth 5, so the bar here is a relative
+        L2 error of 5e-2 (measured 2.3e-2 at depth 5, 3e-3 at depth 3), not a per-element one."""
+    torch.manual_seed(7)
+    widths = [40, 64, 96, 64, 32, 16][:len(dils) + 1]
+    B, H, W = 2, 23, 45
+    x = torch.randn(B, widths[0], H, W).bfloat16()
+    ws = [(torch.randn(co, ci, 3, 3) * (2.0 / (9 * ci)) ** 0.5).bfloat16() for ci, co in zip(widths[:-1], widths[1:])]
+    bs = [torch.randn(co) * 0.1 for co in widths[1:]]
+    g = torch.randn(B, widths[-1], H, W, generator=torch.Generator().manual_seed(5)).bfloat16()
+    runs = {}
+    for mode in ("chain", "layers"):
+        xd = _dev_cl(x).requires_grad_(True)
+        wd = [_dev_cl(w).requires_grad_(True) for w in ws]
+        bd = [b.to(DEV).requires_grad_(True) for b in bs]
+        if mode == "chain":
+            y = conv.conv3x3_chain(xd, wd, bd, [0.1] * len(dils), dils)
+        else:
+            y = xd
+            for w, b, d in zip(wd, bd, dils):
+                y = conv.conv3x3_bias_act(y, w, b, 0.1, d)
+        y.backward(_dev_cl(g))
+        runs[mode] = (y, xd.grad, [w.grad for w in wd], [b.grad for b in bd])
+    assert torch.equal(runs["chain"][0], runs["layers"][0])
+    _close(runs["chain"][1], runs["layers"][1], "chain vs layers: input gradient", 1e-2, 1e-2)
+    for i in range(len(dils)):
+        _close(runs["chain"][2][i], runs["layers"][2][i], f"chain vs layers: weight gradient {i}", 1e-2, 1e-2)
+        _close(runs["chain"][3][i], runs["layers"][3][i], f"chain vs layers: bias gradient {i}", 1e-2, 1e-2)
+    xr = x.float().requires_grad_(True)
+    wr = [w.float().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    h = xr
+    for w, b, d in zip(wr, br, dils):
+        h = F.leaky_relu(F.conv2d(h, w, b, 1, d, d), 0.1).bfloat16().float()
+    h.backward(g.float())
+    _close(runs["chain"][0], h, "chain forward", 1e-2, 1e-2)
+    assert _l2(runs["chain"][1], xr.grad) < 5e-2
+    for i in range(len(dils)):
+        assert _l2(runs["chain"][2][i], wr[i].grad) < 5e-2, i
+        assert _l2(runs["chain"][3][i], br[i].grad) < 5e-2, i
