@@ -312,7 +312,8 @@ int ocf_conv3x3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, in
  * x, y, act: channels_last views (channel stride 1; x with 16-byte aligned pixels, y / act 8-byte aligned when Cout % 4 == 0) -- channel
  * slices of wider buffers included, which is how the decoder's concatenations are read and written in place.  Cin % 8 == 0.
  * w_packed: [w_rows][9][w_k] bf16 from ocf_conv3x3_pack_weights, w_rows >= the rows_needed ocf_conv3x3_plan reports (at most 16 * (ceil(Cout / 16) + 7) for any image), w_k % 8 == 0, zero padded.
- * policy: 0 = automatic patch shape, 16 / 32 / 64 = force the patch width (A/B).  dilation <= 16.
+ * policy: 0 = automatic; 16 / 32 / 64 = force the staged kernel's patch width; + 256 = force the barrier-free small-map kernel
+ * (csrc/conv_direct.hip: automatic up to 4096 pixels), + 512 = forbid it (A/B).  dilation <= 16.
  * replaces: conv() / nn.Conv2d(k=3, s=1, p=d, dilation=d) [+ bias + nn.LeakyReLU(0.1)] and the input half of their autograd in
  *           flow_net.py:11-37, flow_occ_net.py:11-67, context_net.py:11-17 */
 int ocf_conv3x3_plan(int Cout, int B, int H, int W, int dilation, int* m_tiles, int* patch_width, int* rows_needed);

@@ -129,14 +129,19 @@ class WeightPacker:
 
 
 PACKER = WeightPacker()
+# kernel choice of ocf_conv3x3_igemm (include/ocflow_hip.h): 0 automatic, 256 force the barrier-free small-map kernel, 512 forbid it,
+# + 16 / 32 / 64 force the staged kernel's patch width.  Module default for whole-model A/B runs and for the parity tests.
+IGEMM_POLICY = int(os.environ.get("OCFLOW_CONV_POLICY", "0"))
 
 
 def igemm_raw(x, packed: _Packed, cout: int, bias=None, act=None, dilation: int = 1, negative_slope: float = 1.0, mask_slope: float = 1.0,
-              out=None, policy: int = 0):
+              out=None, policy: Optional[int] = None):
     """ocf_conv3x3_igemm on a channels_last bf16 view `x` [B,Cin,H,W] with a packed weight; returns `out` (allocated channels_last when None)"""
     _require_hip(x)
     B, cin, H, W = x.shape
     cin = min(cin, packed.k)  # channels past the packed weight's k (alignment channels of a concatenation) meet no weight
+    if policy is None:
+        policy = IGEMM_POLICY
     if out is None:
         out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
     b32 = None

@@ -327,6 +327,9 @@ extern "C" int ocf_conv3x3_plan(int Cout, int B, int H, int W, int dilation, int
   return OCF_OK;
 }
 
+int ocf_conv3x3_direct_launch(const void* x, long xp, const void* w_packed, int w_rows, int w_k, void* y, long yp, const float* bias, const void* act,
+                              long ap, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope, float mask_slope, void* stream);
+
 extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int w_rows, int w_k, const ocf_tensor4* y, const float* bias,
                                  const ocf_tensor4* act, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope,
                                  float mask_slope, int dtype, int policy, void* stream) {
@@ -338,8 +341,9 @@ extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int
   int mt, tw, rows_pad;
   const int st = ocf_conv3x3_plan(Cout, B, H, W, dilation, &mt, &tw, &rows_pad);
   if (st != OCF_OK) return st;
-  if (policy == 16 || policy == 32 || policy == 64) tw = policy;  // A/B: force the patch width
-  if (w_rows < rows_pad) return OCF_EINVAL;
+  const int pw = policy & 255;
+  if (pw == 16 || pw == 32 || pw == 64) tw = pw;  // A/B: force the patch width
+  else if (pw != 0) return OCF_EINVAL;
   // channels_last views: channel stride 1, rows and images dense in pixels at one pixel pitch (size-1 dimensions carry arbitrary strides)
   auto pitch = [&](const ocf_tensor4* t, int C) { return W > 1 ? t->sw : (H > 1 ? t->sh : (B > 1 ? t->sb : (int64_t)C)); };
   auto cl = [&](const ocf_tensor4* t, int C, int align) {
@@ -350,6 +354,14 @@ extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int
   const int oal = Cout % 4 == 0 ? 8 : 2;
   if (!cl(x, Cin, 16) || !cl(y, Cout, oal) || (act && (!act->data || !cl(act, Cout, oal)))) return OCF_EUNSUPPORTED;
   if ((uintptr_t)w_packed % 16 != 0) return OCF_EUNSUPPORTED;
+  // small maps (fewer than ~8 staged patches): the barrier-free kernel that loads its fragments straight from L2 (conv_direct.hip).
+  // Measured under graph replay (profiles/r4_h_bench_conv_small_maps.txt), 8 pairs: ahead of the staged kernel and of the library at
+  // 14 x 32 and 7 x 16, behind the staged kernel at 28 x 64 (28.5 vs 16.5 us for 128 -> 128)
+  const bool direct = (policy & 256) || (!(policy & 512) && (long)B * H * W <= 4096);
+  if (direct)
+    return ocf_conv3x3_direct_launch(x->data, pitch(x, Cin), w_packed, w_rows, w_k, y->data, pitch(y, Cout), bias, act ? act->data : nullptr,
+                                     act ? pitch(act, Cout) : 0, B, Cin, Cout, H, W, dilation, negative_slope, mask_slope, stream);
+  if (w_rows < rows_pad) return OCF_EINVAL;
   if ((long)B * H * W * (pitch(x, Cin) > pitch(y, Cout) ? pitch(x, Cin) : pitch(y, Cout)) >= (1L << 30)) return OCF_EUNSUPPORTED;  // 32-bit in-image offsets
   const int th = 512 / tw;
   ig::Args a;

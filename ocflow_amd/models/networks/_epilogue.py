@@ -165,13 +165,13 @@ def _native_wgrad() -> str:
     return "" if v == "0" else v
 
 
-NATIVE_MIN_PIXELS = int(os.environ.get("OCFLOW_NATIVE_CONV_MIN_PIXELS", "32768"))
+NATIVE_MIN_PIXELS = int(os.environ.get("OCFLOW_NATIVE_CONV_MIN_PIXELS", "0"))
 
 
 def _native(conv: nn.Conv2d, x) -> bool:
     """does this layer run on the repo's implicit-GEMM kernel (ocflow_amd.conv)?  3x3 / stride-1 / padding == dilation layers on bf16
-    channels_last inputs of at least NATIVE_MIN_PIXELS pixels: below that a launch has fewer patches than the chip has compute units and
-    the framework's kernels are ahead (profiles/r4_b_bench_conv.txt: ahead at 8 x 109 x 256 and 8 x 55 x 128, behind from 8 x 28 x 64 down)"""
+    channels_last inputs of at least NATIVE_MIN_PIXELS pixels (0: every pyramid level -- the launcher switches to its barrier-free
+    small-map kernel at the two coarsest levels; OCFLOW_NATIVE_CONV_MIN_PIXELS=32768 keeps the library there for A/B runs)"""
     return (nconv.enabled() and conv.padding_mode == "zeros" and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] >= NATIVE_MIN_PIXELS
             and nconv.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups))
 

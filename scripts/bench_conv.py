@@ -16,7 +16,7 @@ from ocflow_amd import conv, ops
 from ocflow_amd.runtime import use_repo_miopen_db
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--tw", type=int, default=0)
+ap.add_argument("--tw", type=int, default=0, help="policy of ocf_conv3x3_igemm: 0 auto, 16/32/64 patch width, +256 direct kernel, +512 staged kernel")
 ap.add_argument("--levels", default="2,3,4,5,6")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
@@ -40,11 +40,28 @@ for lvl in [int(v) for v in args.levels.split(",")]:
             layers.append((ci, co, d, H, W))
 
 
+_GRAPHS = {}
+
+
 def timeit(fn, n):
+    """n calls replayed from a hipGraph (the regime of the training step: no host launch path in the measurement)"""
+    g = _GRAPHS.get(fn)  # keyed by the function OBJECT (kept alive by the dict): an id() can be re-used by a later lambda, and
+    if g is None:        # replaying a graph whose tensors have been freed is a GPU memory fault
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                fn()
+        _GRAPHS[fn] = g
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
@@ -90,4 +107,6 @@ for ci, co, d, H, W in layers:
     for i in range(5):
         if best[i] == best[i]:
             tot[i] += best[i]
+    torch.cuda.synchronize()
+    _GRAPHS.clear()  # the graphs go before the tensors they were captured on
 print(f"{'sum':34s} | {tot[0]:7.1f} {tot[1]:7.1f} {tot[2]:7.1f}             | {tot[3]:7.1f} {tot[4]:7.1f}")

@@ -19,10 +19,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(scope="module")
-def conv():
+@pytest.fixture(scope="module", params=[512, 256], ids=["staged", "direct"])
+def conv(request):
+    """every test runs twice: with the staged (LDS-DMA) kernel and with the barrier-free small-map kernel forced (per-call policy of
+    ocf_conv3x3_igemm); the automatic choice between them is by pixel count only"""
     from ocflow_amd import conv as _conv
-    return _conv
+    old = _conv.IGEMM_POLICY
+    _conv.IGEMM_POLICY = request.param
+    yield _conv
+    _conv.IGEMM_POLICY = old
 
 
 def _mk(B, ci, co, H, W, seed=0, bias=True):
@@ -76,7 +81,7 @@ def test_forward_matches_fp32_convolution(conv, B, ci, co, H, W, d):
 def test_every_patch_width(conv, tw):
     x, w, b = _mk(2, 64, 96, 37, 75, seed=tw)
     pk = conv.PACKER.get(_dev_cl(w), False)
-    got = conv.igemm_raw(_dev_cl(x), pk, 96, b.to(DEV), None, 1, 0.1, 1.0, policy=tw)
+    got = conv.igemm_raw(_dev_cl(x), pk, 96, b.to(DEV), None, 1, 0.1, 1.0, policy=512 + tw)
     _close(got, _ref(x, w, b, 1, 0.1), f"patch width {tw}")
 
 
