@@ -321,7 +321,7 @@ int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int w_rows, in
                       const ocf_tensor4* act, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope, float mask_slope,
                       int dtype, int policy, void* stream);
 /* Weight packing for ocf_conv3x3_igemm, every layer of a network in ONE launch: descriptor i says "src (any-strided [Co][Ci][3][3], fp32 or
- * bf16) -> dst (bf16 [rows_pad][9][k_pad], zero padded)"; transpose = 0: rows = Co, k = Ci; transpose = 1: rows = Ci, k = Co, taps flipped.
+ * bf16) -> dst (bf16 [rows_pad][9][k_pad]; the kernel writes the valid region, the caller zeroes dst ONCE when it allocates it)"; transpose = 0: rows = Co, k = Ci; transpose = 1: rows = Ci, k = Co, taps flipped.
  * ocf_conv3x3_pack_describe fills descriptor `index` of a HOST array (ocf_conv3x3_pack_bytes(n) bytes) and chains the flat element index
  * (`first` of descriptor 0 is 0, `*next_first` feeds the next call; the last one is `total_elements`); the caller copies the array to the
  * device once and calls ocf_conv3x3_pack_weights(device array) whenever the source weights have changed. */

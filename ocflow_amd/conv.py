@@ -42,7 +42,7 @@ def _rows_pad(n: int) -> int:
 
 class _Packed:
     """packed copy of one weight in one orientation + its device descriptor"""
-    __slots__ = ("dst", "rows", "k", "desc_host", "transpose", "version", "src_ref")
+    __slots__ = ("dst", "rows", "k", "desc_host", "transpose", "version", "epoch", "src_ref")
 
 
 class WeightPacker:
@@ -68,6 +68,7 @@ class WeightPacker:
         e.dst = torch.zeros((e.rows, 9, e.k), device=w.device, dtype=torch.bfloat16)
         e.transpose = bool(transpose)
         e.version = -1
+        e.epoch = -1
         e.src_ref = w
         self.entries[(id(w), int(transpose), int(min_rows))] = e
         self._order.append(e)
@@ -108,6 +109,7 @@ class WeightPacker:
                                                             C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "ocf_conv3x3_pack_weights")
         for e in self._order:
             e.version = e.src_ref._version
+            e.epoch = _OPT_EPOCH[0]
 
     def get(self, w: torch.Tensor, transpose: bool, min_rows: int = 0) -> _Packed:
         """min_rows: output channels the kernel will be asked to write (the input gradient of a layer fed by a zero-padded
@@ -117,7 +119,10 @@ class WeightPacker:
         e = self.entries.get((id(w), int(transpose), int(min_rows)))
         if e is None:
             e = self._register(w, transpose, int(min_rows))
-        stale = e.version != w._version or e.src_ref is not w
+        # a weight changes (a) through in-place tensor ops, which move its version counter, or (b) under an optimizer step -- torch's FUSED
+        # Adam updates parameters WITHOUT touching the version counter (measured: three eager steps on three-step-old packed weights), so
+        # every optimizer.step() in the process moves an epoch (global post-step hook below)
+        stale = e.version != w._version or e.epoch != _OPT_EPOCH[0] or e.src_ref is not w
         if torch.cuda.is_current_stream_capturing():
             cid = ops._capture_id(w.device)
             stale = stale or self._capture_seen != cid
@@ -127,6 +132,25 @@ class WeightPacker:
             self.refresh(w.device)
         return e
 
+
+_OPT_EPOCH = [0]
+
+
+def _optimizer_stepped(*_args, **_kw):
+    _OPT_EPOCH[0] += 1
+
+
+def weights_changed():
+    """tell the packer that weights may have changed in a way it cannot see (a custom in-place update that bypasses both the tensor
+    version counter and torch.optim): the next use re-packs"""
+    _OPT_EPOCH[0] += 1
+
+
+try:  # torch >= 2.0
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
+    _reg_hook(_optimizer_stepped)
+except ImportError:  # pragma: no cover
+    pass
 
 PACKER = WeightPacker()
 # kernel choice of ocf_conv3x3_igemm (include/ocflow_hip.h): 0 automatic, 256 force the barrier-free small-map kernel, 512 forbid it,
@@ -156,6 +180,44 @@ def igemm_raw(x, packed: _Packed, cout: int, bias=None, act=None, dilation: int 
         ops._launch("conv3x3_igemm", lambda: ops._meta(f"B{B}x{cin}->{cout}x{H}x{W}d{dilation}", B * H * W * 2 * (cin + cout),
                                                        2 * B * H * W * 9 * cin * cout), fn)
     return out
+
+
+# ---- gradient sinks: a training loop that keeps ONE flat fp32 gradient buffer (runtime.TrainStepper) hands the views of that buffer in;
+# the weight / bias gradient kernels then accumulate straight into them and autograd sees no gradient for those parameters at all (no
+# bf16 round trip, no per-parameter copy into the flat buffer).  The owner zeroes the buffer at the start of every step.
+GRAD_SINK: Dict[int, torch.Tensor] = {}   # id(parameter) -> fp32 view with the parameter's shape and strides
+SEEN_NATIVE: set = set()                  # ids of the parameters whose gradients the kernels of this module produced (see record_native)
+_RECORD = [False]
+
+
+def record_native(flag: bool):
+    """while on, the backward passes note which parameters they serve (the stepper asks once, after its warm-up steps)"""
+    _RECORD[0] = bool(flag)
+    if flag:
+        SEEN_NATIVE.clear()
+
+
+def install_grad_sinks(params, views) -> set:
+    """register `views[i]` as the accumulation target of `params[i]` for every parameter seen by the native backward; returns their ids"""
+    GRAD_SINK.clear()
+    for p, v in zip(params, views):
+        if id(p) in SEEN_NATIVE and v.dtype == torch.float32 and v.shape == p.shape:
+            GRAD_SINK[id(p)] = v
+    return set(GRAD_SINK)
+
+
+def clear_grad_sinks():
+    GRAD_SINK.clear()
+
+
+def _grad_target(p, device):
+    """(fp32 tensor to accumulate the gradient of parameter `p` into, is_sink)"""
+    if _RECORD[0]:
+        SEEN_NATIVE.add(id(p))
+    sink = GRAD_SINK.get(id(p))
+    if sink is not None:
+        return sink, True
+    return ops._take_zeros(p.numel(), device).as_strided(p.shape, p.stride()), False
 
 
 def wgrad_bias_raw(x, dz, gw, gbias=None, dilation: int = 1, policy: int = 0):
@@ -209,11 +271,12 @@ def _pixel_major(t, align: int) -> bool:
             and t.data_ptr() % align == 0)
 
 
-def _shape_like(weight, cin):
-    """the weight itself, or (input fed by a zero-padded concatenation) the weight with zero input channels appended"""
+def _shape_like(weight, cin, dtype=torch.bfloat16):
+    """operand for the framework's convolution backward: the weight in the activations' dtype (plain autocast keeps fp32 weights) and, for
+    an input fed by a zero-padded concatenation, with zero input channels appended"""
     if weight.shape[1] == cin:
-        return weight
-    wp = weight.new_zeros((weight.shape[0], cin, 3, 3)).contiguous(memory_format=torch.channels_last)
+        return weight if weight.dtype == dtype else weight.to(dtype)
+    wp = weight.new_zeros((weight.shape[0], cin, 3, 3), dtype=dtype).contiguous(memory_format=torch.channels_last)
     wp[:, :weight.shape[1]] = weight
     return wp
 
@@ -226,15 +289,16 @@ class _ConvBiasActFn(Function):
     def forward(ctx, x, weight, bias, slope, dilation):
         pk = PACKER.get(weight, False)
         y = igemm_raw(x, pk, weight.shape[0], bias, None, dilation, slope, 1.0)
-        ctx.save_for_backward(x, weight, y)
+        ctx.save_for_backward(x, weight, y, *([bias] if bias is not None else []))
         ctx.cfg = (float(slope), int(dilation), bias is not None, None if bias is None else bias.dtype)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, weight, y = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors[:3]
         slope, d, has_bias, bias_dtype = ctx.cfg
+        bias = ctx.saved_tensors[3] if has_bias else None
         B, co, H, W = y.shape
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
         gg = gy if gy.dtype == y.dtype else gy.to(y.dtype)
@@ -263,12 +327,18 @@ class _ConvBiasActFn(Function):
                 dzc = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
                 gx = torch.ops.aten.convolution_backward(dzc, x, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False, (0, 0), 1,
                                                          [True, False, False])[0]
+        w_sink = b_sink = False
         if need_w and use_wg3 and wgrad_eligible(x, dz, weight.shape[1], co):
-            acc = ops._take_zeros(weight.numel(), gy.device).as_strided(weight.shape, weight.stride())
+            acc, w_sink = _grad_target(weight, gy.device)
             gb2 = None
             if need_b and gb is None:
-                gb2 = gb = ops._take_zeros(co, gy.device)
+                gb2, b_sink = _grad_target(bias, gy.device)
+                gb = gb2
             gw = wgrad_bias_raw(x, dz, acc, gb2, d)
+            if w_sink:
+                gw = None
+            if b_sink:
+                gb = None
         elif need_w:
             dzc = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
             xc = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
@@ -276,7 +346,9 @@ class _ConvBiasActFn(Function):
                                                      [False, True, False])[1]
             if gw.shape[1] != weight.shape[1]:
                 gw = gw[:, :weight.shape[1]].contiguous(memory_format=torch.channels_last)
-        if need_b and gb is None:
+            if gw.dtype != weight.dtype:
+                gw = gw.to(weight.dtype)
+        if need_b and gb is None and not b_sink:
             gb = dz.float().sum((0, 2, 3))
         if gb is not None and need_b and bias_dtype != torch.float32:
             gb = gb.to(bias_dtype)
@@ -300,51 +372,60 @@ class _ConvChainFn(Function):
         for i in range(n):
             h = igemm_raw(h, PACKER.get(ws[i], False), ws[i].shape[0], bs[i], None, dils[i], slopes[i], 1.0)
             ys.append(h)
-        ctx.save_for_backward(x, *ws, *ys)
-        ctx.cfg = (tuple(slopes), tuple(dils), tuple(b.dtype for b in bs))
+        ctx.save_for_backward(x, *ws, *bs, *ys)
+        ctx.cfg = (tuple(slopes), tuple(dils))
         return h
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        slopes, dils, bias_dtypes = ctx.cfg
+        slopes, dils = ctx.cfg
         n = len(slopes)
         saved = ctx.saved_tensors
-        x, ws, ys = saved[0], saved[1:1 + n], saved[1 + n:]
+        x, ws, bs, ys = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:]
         dev = gy.device
         B, _, H, W = x.shape
         gg = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
         if not _pixel_major(gg, 16):
             gg = gg.contiguous(memory_format=torch.channels_last)
         gws, gbs = [None] * n, [None] * n
+        need_w = [ctx.needs_input_grad[3 + i] for i in range(n)]
+        need_b = [ctx.needs_input_grad[3 + n + i] for i in range(n)]
+        last_bias_done = False
         # the last layer's activation derivative: the one elementwise pass of the chain (it also reduces that layer's bias gradient)
         if slopes[-1] != 1.0:
             y = ys[-1]
             co = y.shape[1]
             dz = torch.empty_like(y)
-            gbs[-1] = ops._take_zeros(co, dev)
+            gb_t, b_sink = _grad_target(bs[-1], dev) if need_b[-1] else (ops._take_zeros(co, dev), False)
             with torch.cuda.device(dev):
-                _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y), _t4(gg), _t4(dz), C.c_void_p(gbs[-1].data_ptr()), B, co, H, W, slopes[-1], 1,
+                _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y), _t4(gg), _t4(dz), C.c_void_p(gb_t.data_ptr()), B, co, H, W, slopes[-1], 1,
                                                         _lib.OCF_BF16, _stream(gg)), "ocf_bias_act_bwd")
+            if need_b[-1]:
+                gbs[-1] = None if b_sink else gb_t
+            last_bias_done = True
         else:
             dz = gg
         gx = None
         for i in range(n - 1, -1, -1):
             xin = ys[i - 1] if i > 0 else x
             w = ws[i]
-            if ctx.needs_input_grad[3 + i] or ctx.needs_input_grad[3 + n + i]:
-                gws[i] = ops._take_zeros(w.numel(), dev).as_strided(w.shape, w.stride())
-                gb = None
-                if gbs[i] is None and ctx.needs_input_grad[3 + n + i]:
-                    gb = gbs[i] = ops._take_zeros(w.shape[0], dev)
-                wgrad_bias_raw(xin, dz, gws[i], gb, dils[i])
+            if need_w[i] or need_b[i]:
+                gw_t, w_sink = _grad_target(w, dev)
+                gb_t, b_sink = None, False
+                if need_b[i] and not (i == n - 1 and last_bias_done):
+                    gb_t, b_sink = _grad_target(bs[i], dev)
+                wgrad_bias_raw(xin, dz, gw_t, gb_t, dils[i])
+                gws[i] = None if w_sink else gw_t
+                if gb_t is not None:
+                    gbs[i] = None if b_sink else gb_t
             if i > 0:
                 masked = slopes[i - 1] != 1.0
                 dz = igemm_raw(dz, PACKER.get(w, True, xin.shape[1]), xin.shape[1], None, xin if masked else None, dils[i], 1.0,
                                slopes[i - 1] if masked else 1.0)
             elif ctx.needs_input_grad[0]:
                 gx = igemm_raw(dz, PACKER.get(w, True, x.shape[1]), x.shape[1], None, None, dils[i], 1.0, 1.0)
-        gbs = [g if (g is None or dt == torch.float32) else g.to(dt) for g, dt in zip(gbs, bias_dtypes)]
+        gbs = [g if (g is None or g.dtype == b.dtype) else g.to(b.dtype) for g, b in zip(gbs, bs)]
         return (gx, None, None, *gws, *gbs)
 
 

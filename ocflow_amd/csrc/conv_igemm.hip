@@ -243,25 +243,42 @@ struct PackDesc {
   long first;  // index of this tensor's first packed element in the launch's flat index space
 };
 
-__global__ void conv3x3_pack_kernel(const PackDesc* __restrict__ descs, int n, long total) {
-  // blockIdx.y = tensor, blockIdx.x strides over its packed elements (the first version searched the descriptor of every element:
-  // 59 us for the 150 tensors of a step)
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const PackDesc* __restrict__ descs, int n, long total) {
+  // blockIdx.y = tensor; the blocks of a tensor walk its (tap, 32-row, 32-k) tiles of the VALID region only (the zero padding of the
+  // packed copy is written once, when it is allocated).  A tile goes through LDS so that both the read (contiguous along the source's
+  // fastest dimension) and the write (contiguous along k) are whole runs; the first versions looked up the descriptor of every
+  // element (59 us per step) / wrote the padding every step with two 64-bit divisions per element (100 us).
+  __shared__ float tile[32][33];
   const PackDesc p = descs[blockIdx.y];
-  const long count = (long)p.rows_pad * 9 * p.k_pad;
   const int R = p.transpose ? p.Ci : p.Co, K = p.transpose ? p.Co : p.Ci;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e % p.k_pad);
-    const int rt = (int)(e / p.k_pad);
-    const int tap = rt % 9, row = rt / 9;
-    float v = 0.f;
-    if (row < R && k < K) {
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      long off;
-      if (p.transpose) off = (long)k * p.so + (long)row * p.si + (2 - ky) * p.sky + (2 - kx) * p.skx;
-      else off = (long)row * p.so + (long)k * p.si + ky * p.sky + kx * p.skx;
-      v = p.src_f32 ? ((const float*)p.src)[off] : (float)(((const bf16*)p.src)[off]);
+  const int tr = (R + 31) >> 5, tk = (K + 31) >> 5, ntile = 9 * tr * tk;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  // source strides along the packed copy's row / k dimension, and which of them is the source's contiguous one
+  const long s_row = p.transpose ? p.si : p.so, s_k = p.transpose ? p.so : p.si;
+  const bool k_fast = s_k <= s_row;  // read with tx along k (no transpose needed) or along rows
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int tap = t / (tr * tk), rem = t - tap * (tr * tk);
+    const int r0 = (rem / tk) << 5, k0 = (rem % tk) << 5;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const long toff = p.transpose ? (2 - ky) * p.sky + (2 - kx) * p.skx : ky * p.sky + kx * p.skx;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int a8 = ty + 8 * i;
+      const int row = r0 + (k_fast ? a8 : tx), k = k0 + (k_fast ? tx : a8);
+      float v = 0.f;
+      if (row < R && k < K) {
+        const long off = (long)row * s_row + (long)k * s_k + toff;
+        v = p.src_f32 ? ((const float*)p.src)[off] : (float)(((const bf16*)p.src)[off]);
+      }
+      if (k_fast) tile[a8][tx] = v; else tile[tx][a8] = v;  // tile[row - r0][k - k0]
     }
-    ((bf16*)p.dst)[e] = (bf16)v;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = r0 + ty + 8 * i, k = k0 + tx;
+      if (row < R && k < K) ((bf16*)p.dst)[((long)row * 9 + tap) * p.k_pad + k] = (bf16)tile[ty + 8 * i][tx];
+    }
+    __syncthreads();
   }
 }
 
@@ -410,7 +427,7 @@ extern "C" int ocf_conv3x3_pack_weights(const void* device_descs, int n, int64_t
   if (!device_descs || n <= 0 || total_elements <= 0) return OCF_EINVAL;
   if (n > 65535) return OCF_EUNSUPPORTED;
   LaunchProf lp;
-  lp.launch(true, ig::conv3x3_pack_kernel, dim3(16, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+  lp.launch(true, ig::conv3x3_pack_kernel, dim3(8, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
             (const ig::PackDesc*)device_descs, n, (long)total_elements);
   return launch_status();
 }

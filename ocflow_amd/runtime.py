@@ -449,17 +449,36 @@ class TrainStepper:
             self._graph = graph
             return self
         split = self._reduce  # an all-reduce sits between backward and the optimizer
+        from ocflow_amd import conv as nconv
+        nconv.clear_grad_sinks()
+        nconv.record_native(True)   # one more eager step: which parameters get their gradients from the repo's convolution kernels?
+        with torch.cuda.stream(side):
+            self._eager_step(self._static_batch, warmup)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        nconv.record_native(False)
         params = self._grad_params()  # after the warm-up steps: exactly the parameters that reach the loss
         self._flat, views = self._flat_views(params)
+        # those kernels accumulate straight into the flat fp32 buffer (zeroed at the top of every replay): autograd produces no gradient
+        # tensor for these parameters, nothing is cast to bf16 and back, nothing is copied per parameter
+        sinks = nconv.install_grad_sinks(params, views) if os.environ.get("OCFLOW_GRAD_SINKS", "1") != "0" else set()
+        self._sink_ids = sinks
         with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
+            if sinks:
+                self._flat.zero_()
             self._static_loss = self._forward_backward(self._static_batch, 0)
-            got = self._grad_params()
+            got = [p for p in self.raw.parameters() if p.grad is not None or id(p) in sinks]
             if len(got) != len(params) or any(a is not b for a, b in zip(got, params)):
                 raise RuntimeError("TrainStepper.enable_graph: the set of parameters with gradients changed between steps")
-            self._gather(views, [p.grad for p in params])
+            rest = [i for i, p in enumerate(params) if id(p) not in sinks]
+            self._gather([views[i] for i in rest], [params[i].grad for i in rest])
+            for i, p in enumerate(params):  # a sink parameter that ALSO received a framework gradient (another call site): add it
+                if id(p) in sinks and p.grad is not None:
+                    views[i].add_(p.grad)
             if not split:
                 self._attach(params, views)
                 self._optimizer_step()
+        nconv.clear_grad_sinks()  # the captured launches keep their pointers; eager steps outside the graph use autograd's own gradients
         self._graph = graph
         if split:
             # (no collective in here: a rank whose capture raised must not leave the others waiting inside one)

@@ -265,3 +265,22 @@ def test_chain_matches_layer_by_layer_autograd(conv, dils):
     for i in range(len(dils)):
         assert _l2(runs["chain"][2][i], wr[i].grad) < 5e-2, i
         assert _l2(runs["chain"][3][i], br[i].grad) < 5e-2, i
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_packed_weights_follow_a_fused_optimizer_step(conv, dt):
+    """torch's fused Adam updates parameters WITHOUT moving their version counter: the packer must still re-pack after every
+    optimizer.step() (global post-step hook).  Regression: three eager steps ran on three-step-old packed weights (forward error 6.6
+    instead of 0.016) and FlowOccModel's loss went 3.99 -> 6.35 under plain autocast."""
+    torch.manual_seed(0)
+    w = torch.nn.Parameter((torch.randn(64, 32, 3, 3, device=DEV) * 0.1).to(dt).contiguous(memory_format=torch.channels_last))
+    b = torch.nn.Parameter(torch.randn(64, device=DEV) * 0.1)
+    x = torch.randn(2, 32, 20, 30, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    opt = torch.optim.Adam([w, b], lr=1e-1, fused=True)
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        y = conv.conv3x3_bias_act(x, w, b, 0.1, 1)
+        ref = F.leaky_relu(F.conv2d(x.float(), w.detach().to(torch.bfloat16).float(), b.detach(), 1, 1, 1), 0.1)
+        _close(y, ref, f"forward after {step} optimizer steps")
+        y.float().square().mean().backward()
+        opt.step()
