@@ -342,6 +342,14 @@ int ocf_conv3x3_pack_weights(const void* device_descs, int n, int64_t total_elem
 int ocf_conv3x3_wgrad_bias(const ocf_tensor4* x, const ocf_tensor4* dz, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky, int64_t gw_skx,
                            float* gbias, int B, int Ci, int Co, int H, int W, int dilation, int dtype, int policy, void* stream);
 
+/* ---- channel concatenation of the decoder inputs: out[:, c0_k : c0_k + channels[k]] = parts[k], out[:, sum(channels):Cout] = 0, one launch.
+ * parts: n <= 6 pixel-major (channel stride 1, one pixel pitch) bf16 views of [B, channels[k], H, W]; out: dense channels_last
+ * [B, Cout, H, W], Cout % 8 == 0, 16-byte aligned.  Anything else: OCF_EUNSUPPORTED (the caller keeps the framework's cat).
+ * replaces: torch.cat((corr, f1, flow_up, feat_up), 1) / torch.cat((f1, warped2, occ_feat_up, occ_up), 1) of flow_net.py:104-121,
+ *           flow_occ_net.py:153-176 [aten cat's generic gather kernel + the zero block of the channel alignment] */
+int ocf_concat_channels(const ocf_tensor4* const* parts, const int* channels, int n, const ocf_tensor4* out, int Cout, int B, int H, int W, int dtype,
+                        void* stream);
+
 /* ---- BatchNorm2d (batch statistics) + LeakyReLU of the feature-pyramid encoder
  * replaces: nn.BatchNorm2d + nn.LeakyReLU(0.1) of the reference's `conv_bn_relu` blocks (models/networks/feature_pyramid_net.py:5-95), i.e.
  * torch.batch_norm(training) + leaky_relu and their autograd.  Dense channels_last x / y / gy / gx of `dtype` (OCF_F32 / OCF_BF16), C a

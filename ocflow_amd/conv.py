@@ -319,8 +319,15 @@ class _ConvBiasActFn(Function):
         else:
             dz = gg
         gx = gw = None
+        if co < 8 and _native_wgrad():
+            # prediction layers (2 flow channels, 1 occlusion logit): the kernels read channels in 16-byte chunks, so the gradient goes
+            # into a zero-padded 8-channel copy (two small launches) instead of the framework's vector-1 / naive convolution backward
+            dzp = torch.zeros((B, 8, H, W), device=dz.device, dtype=dz.dtype).contiguous(memory_format=torch.channels_last)
+            dzp[:, :co] = dz
+            dz = dzp
+            use_wg3 = need_w and wgrad_eligible(x, dz, weight.shape[1], co)
         if need_x:
-            if co % 8 == 0 and _pixel_major(dz, 16):
+            if (co % 8 == 0 or co < 8) and _pixel_major(dz, 16) and dz.shape[1] % 8 == 0:
                 pkt = PACKER.get(weight, True, x.shape[1])
                 gx = igemm_raw(dz, pkt, x.shape[1], None, None, d, 1.0, 1.0)
             else:

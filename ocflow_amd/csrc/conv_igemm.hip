@@ -427,7 +427,8 @@ extern "C" int ocf_conv3x3_pack_weights(const void* device_descs, int n, int64_t
   if (!device_descs || n <= 0 || total_elements <= 0) return OCF_EINVAL;
   if (n > 65535) return OCF_EUNSUPPORTED;
   LaunchProf lp;
-  lp.launch(true, ig::conv3x3_pack_kernel, dim3(8, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+  // (64 blocks per tensor: a tile is a dependent load -> LDS -> store chain of ~2 us, the largest tensors have ~600 of them)
+  lp.launch(true, ig::conv3x3_pack_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
             (const ig::PackDesc*)device_descs, n, (long)total_elements);
   return launch_status();
 }

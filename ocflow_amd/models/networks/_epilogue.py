@@ -32,6 +32,13 @@ def cat_aligned(parts, dim: int = 1):
     if dim == 1 and x0.is_cuda and x0.dim() == 4 and x0.dtype in (torch.bfloat16, torch.float16) and not _unpadded_cat():
         ctot = sum(int(t.shape[1]) for t in parts)
         pad = -ctot % CHANNEL_ALIGN
+        native = nconv.enabled() and os.environ.get("OCFLOW_NATIVE_CAT", "1") != "0" and not torch.compiler.is_compiling()
+        if native and x0.dtype == torch.bfloat16:
+            # with the repo's own convolution kernels behind it (ocflow_amd.conv) the aligned tensor never meets a library solver, so it
+            # is always formed -- by ONE launch that gathers the parts and writes the alignment zeros (ops.concat_channels)
+            ps = [t if t.dtype == x0.dtype else t.to(x0.dtype) for t in parts]
+            if ops.concat_channels_eligible(ps):
+                return ops.concat_channels(ps, ctot + pad)
         if pad and not _padded_shape_is_known(int(x0.shape[0]), ctot + pad, int(x0.shape[2]), int(x0.shape[3])):
             pad = 0  # no find-db entry for the aligned shape: the library would choose its kernel heuristically -- keep the plain tensor
         if pad:

@@ -6,8 +6,18 @@ import os
 import torch
 import torch.nn as nn
 
+from ocflow_amd import conv as nconv
 from ocflow_amd import ops
 from ._epilogue import deconv_bias
+
+
+def _conv3x3_same(conv: nn.Conv2d, x):
+    """the stride-1 3x3 convolution of a DoubleConv block (bias-free, BatchNorm follows): on the repo's implicit-GEMM kernels where they
+    take the operands (bf16 channels_last, channel counts that are multiples of 8 -- every level but the 196-channel top)"""
+    if (conv.bias is None and nconv.enabled() and os.environ.get("OCFLOW_NATIVE_FPN", "1") != "0" and not torch.compiler.is_compiling()
+            and conv.weight.shape[0] % 8 == 0 and nconv.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
+        return nconv.conv3x3_bias_act(x, conv.weight, None, 1.0, 1)
+    return conv(x)
 
 
 def _bn_act(bn: nn.BatchNorm2d, act: nn.LeakyReLU, x, groups: int = 1):
@@ -36,7 +46,7 @@ class DoubleConv(nn.Module):
     def forward(self, x, groups: int = 1):
         s = self.double_conv
         x = _bn_act(s[1], s[2], s[0](x), groups)
-        return _bn_act(s[4], s[5], s[3](x), groups)
+        return _bn_act(s[4], s[5], _conv3x3_same(s[3], x), groups)
 
 
 class Upsample(nn.Module):

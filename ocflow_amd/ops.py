@@ -963,6 +963,58 @@ def psnr(img1, img2, pixel_max=255.0, per_sample=True):
     return val if per_sample else val.mean()
 
 
+# ------------------------------------------------------------------------- channel concatenation of the decoder inputs
+class _ConcatFn(Function):
+    @staticmethod
+    def forward(ctx, cout, *parts):
+        B, _, H, W = parts[0].shape
+        out = torch.empty((B, cout, H, W), device=parts[0].device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        n = len(parts)
+        t4s = [_lib.Tensor4(t.data_ptr(), *t.stride()) for t in parts]
+        arr = (C.POINTER(_lib.Tensor4) * n)(*[C.pointer(t) for t in t4s])
+        chans = (C.c_int * n)(*[int(t.shape[1]) for t in parts])
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.load().ocf_concat_channels(arr, chans, n, _t4(out), int(cout), B, H, W, _lib.OCF_BF16, _stream(out)), "ocf_concat_channels")
+        ctx.sizes = [int(t.shape[1]) for t in parts]
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        grads, c0 = [], 0
+        for i, c in enumerate(ctx.sizes):
+            grads.append(gy.narrow(1, c0, c) if ctx.needs_input_grad[1 + i] else None)
+            c0 += c
+        return (None, *grads)
+
+
+def concat_channels_eligible(parts) -> bool:
+    """operands ocf_concat_channels takes: up to six bf16 pixel-major [B, C_k, H, W] tensors on one HIP device"""
+    if not (1 <= len(parts) <= 6):
+        return False
+    x0 = parts[0]
+    for t in parts:
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[0] == x0.shape[0] and t.shape[2:] == x0.shape[2:]):
+            return False
+        B, C_, H, W = t.shape
+        sb, sc, sh, sw = t.stride()
+        p = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C_))
+        if not ((C_ == 1 or sc == 1) and p >= C_ and (H == 1 or sh == p * W) and (B == 1 or sb == p * W * H)):
+            return False
+    return True
+
+
+def concat_channels(parts, cout=None):
+    """`torch.cat(parts, 1)` zero-padded to `cout` channels (a multiple of 8; default: the sum rounded up to 8) as one HIP launch into
+    a dense channels_last tensor; gradients are channel slices of the incoming gradient (views, as autograd's own cat backward)"""
+    parts = list(parts)
+    total = sum(int(t.shape[1]) for t in parts)
+    cout = (total + 7) // 8 * 8 if cout is None else int(cout)
+    if cout % 8 or cout < total:
+        raise ValueError(f"cout must be a multiple of 8 and >= {total}, got {cout}")
+    _require_hip(*parts)
+    return _ConcatFn.apply(cout, *parts)
+
+
 # ------------------------------------------------------------------------- 3x3 convolution, weight gradient
 def conv3x3_wgrad(x, gy, dilation=1, out=None):
     """Weight gradient of a 3x3 / stride-1 / padding == dilation convolution (the estimator / context network layers: flow_net.py:11-37,

@@ -1096,3 +1096,36 @@ def test_conv3x3_autograd_path_matches_framework(ops):
     np.testing.assert_allclose(res[1][2].float().cpu().numpy(), res[0][2].float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
     assert not ops.conv3x3_wgrad_eligible(x0.float(), w0.float(), (1, 1), (1, 1), (1, 1), 1)
     assert not ops.conv3x3_wgrad_eligible(x0, w0, (2, 2), (1, 1), (1, 1), 1)
+
+
+@pytest.mark.gpu
+def test_concat_channels_matches_torch_cat_and_pads_with_zeros():
+    """ocf_concat_channels: the decoder-input concatenations (81 + C + 2 + 2 channels, parts that are views of wider tensors or halves of a
+    paired batch) in one launch, zero-padded to a multiple of 32 channels; values are copied, so the bar is equality"""
+    from ocflow_amd import ops
+    torch.manual_seed(3)
+    B, H, W = 3, 13, 21
+    corr = torch.randn(B, 81, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    pair = torch.randn(2 * B, 32, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    f1 = pair.view(2, B, 32, H, W)[0]
+    wide = torch.randn(B, 8, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    flow, feat = wide[:, 1:3], wide[:, 5:7]
+    parts = [corr, f1, flow, feat]
+    assert ops.concat_channels_eligible(parts)
+    leaves = [p.detach().clone().requires_grad_(True) for p in parts]
+    out = ops.concat_channels(leaves, 128)
+    ref = torch.cat([p.detach() for p in parts], 1)
+    assert out.shape == (B, 128, H, W) and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out[:, :117], ref) and float(out[:, 117:].abs().max()) == 0.0
+    g = torch.randn_like(out)
+    out.backward(g)
+    c0 = 0
+    for leaf in leaves:
+        assert torch.equal(leaf.grad, g[:, c0:c0 + leaf.shape[1]])
+        c0 += leaf.shape[1]
+    # aligned parts take the vector path; a single part; one-pixel maps
+    a = torch.randn(2, 64, 5, 7, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(2, 40, 5, 7, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    assert torch.equal(ops.concat_channels([a, b])[:, :104], torch.cat([a, b], 1))
+    one = torch.randn(2, 24, 1, 1, device="cuda").bfloat16()
+    assert torch.equal(ops.concat_channels([one, one], 64)[:, :48], torch.cat([one, one], 1))
