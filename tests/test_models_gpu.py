@@ -202,10 +202,15 @@ def test_aligned_concatenation_is_the_same_block(monkeypatch, block):
     a, b = torch.randn((1, 5, 4, 6), device=DEV), torch.randn((1, 4, 4, 6), device=DEV)
     assert torch.equal(cat_aligned([a, b]), torch.cat([a, b], 1))  # fp32: plain torch.cat
     monkeypatch.setenv("OCFLOW_UNPADDED_CAT", "0")
-    # default policy: align only inputs whose convolution the shipped find-db covers (and only under the MIOpen build it was made with)
+    # with the repo's own convolution kernels behind it (the default since round 4) the concatenation is ALWAYS aligned, in one launch
     from ocflow_amd.models.networks import _epilogue
     from ocflow_amd.runtime import miopen_db_status
     small = [a.bfloat16().contiguous(memory_format=torch.channels_last), b.bfloat16().contiguous(memory_format=torch.channels_last)]
+    always = cat_aligned(small)
+    assert always.shape[1] == 32 and torch.equal(always[:, :9], torch.cat(small, 1)) and float(always[:, 9:].abs().max()) == 0.0
+    # library policy (OCFLOW_NATIVE_CONV=0): align only inputs whose convolution the shipped find-db covers (and only under the MIOpen
+    # build it was made with)
+    monkeypatch.setenv("OCFLOW_NATIVE_CONV", "0")
     assert cat_aligned(small).shape[1] == 9  # a shape no find-db entry exists for stays as it is
     if miopen_db_status()["matched"]:
         assert _epilogue._padded_shape_is_known(8, 128, 109, 256) and not _epilogue._padded_shape_is_known(4, 128, 80, 304)
@@ -256,6 +261,11 @@ def test_aligned_concatenation_is_the_same_block(monkeypatch, block):
             ctx = context(m, dense_block(m, 2, cat_aligned(parts2)))
             return flow.float().square().mean() + upf.float().square().mean() + ctx.float().square().mean(), parts + parts2
     _grads_with_and_without_padding(monkeypatch, build, run)
+    if block != "pwc_dense_block":
+        # the same comparison with the repo's convolution kernels consuming the aligned tensor (the unpadded run then takes the library for
+        # the first layer, whose 117 / 66 / 34 input channels are not a multiple of 8, and the kernels for the rest)
+        monkeypatch.setenv("OCFLOW_NATIVE_CONV", "1")
+        _grads_with_and_without_padding(monkeypatch, build, run)
 
 
 @pytest.mark.parametrize("mode", ["fp32_cl_train", "bf16_cl_train", "fp32_nchw_train", "fp32_cl_eval"])
@@ -292,8 +302,10 @@ def test_feature_pyramid_pair_equals_two_calls(monkeypatch, mode):
         assert float((u - v).abs().max()) <= tol * (float(u.abs().max()) + 1e-3)
     gmax = max([float(u.abs().max()) for u in g0] + [1e-12])
     for u, v in zip(g0, g1):  # (the bias of a transposed convolution in front of a BatchNorm has a mathematically zero gradient: 1e-9 noise)
-        # bf16: twelve convolution + BatchNorm layers deep, different library kernels at batch 16 and 8: per cent of the gradient scale
-        assert float((u - v).abs().max()) <= (2e-3 if fp32 else 0.2) * max(float(u.abs().max()), (1e-3 if fp32 else 5e-2) * gmax)
+        # bf16: twelve convolution + BatchNorm layers deep, different library kernels (stride-2 layers) at batch 16 and 8: per cent of the
+        # gradient scale.  (0.25: with the stride-1 layers on the repo's kernels -- bit-identical per sample at any batch -- the worst
+        # element, a 16-channel first-level BatchNorm gradient, measured 0.215 of its scale; 0.2 held with the library's kernels)
+        assert float((u - v).abs().max()) <= (2e-3 if fp32 else 0.25) * max(float(u.abs().max()), (1e-3 if fp32 else 5e-2) * gmax)
     for k in s0:
         np.testing.assert_allclose(s1[k].numpy(), s0[k].numpy(), rtol=1e-4 if fp32 else 2e-2, atol=1e-5 if fp32 else 2e-3, err_msg=k)
 
