@@ -239,11 +239,25 @@ def copy_ceiling_gbps(device) -> float:
     return round(2.0 * 4 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak of an MI355X (MI355X_MICROARCH.md; the 5 PF headline figure is 2:1 sparse)
+
+
 def kernel_rooflines(summ: dict, peak: float) -> dict:
-    """per-kernel {launches, avg_us, achieved GB/s, frac} from a KernelTimer summary"""
+    """per-kernel {launches, avg_us, achieved GB/s, frac} from a KernelTimer summary; the convolution kernels (names conv3x3_*: the
+    estimator / context / encoder layers on the repo's implicit-GEMM kernels) are matrix-core bound and carry achieved TFLOP/s against the
+    dense bf16 MFMA peak instead"""
     out = {}
     for name, v in summ.items():
         if v["ms_total"] <= 0:
+            continue
+        if name.startswith("conv3x3"):
+            tf = v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12
+            out[name] = {"bound": "mfma", "launches": v["launches"], "avg_launch_us": round(1e3 * v["ms_total"] / v["launches"], 2),
+                         "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                         "us_per_step_share": round(1e3 * v["ms_total"], 1),
+                         "per_shape": {k: {"launches": w["launches"], "avg_us": round(1e3 * w["ms_total"] / w["launches"], 2),
+                                           "TFLOPs": round(w.get("flops", 0) / (1e-3 * w["ms_total"] / w["launches"]) / 1e12, 1)}
+                                       for k, w in sorted(v["by_shape"].items(), key=lambda kv: -kv[1]["ms_total"])[:24]}}
             continue
         gbps = v["bytes_total"] / (v["ms_total"] * 1e-3) / 1e9
         out[name] = {"launches": v["launches"], "avg_launch_us": round(1e3 * v["ms_total"] / v["launches"], 2), "achieved": round(gbps, 1),

@@ -547,7 +547,7 @@ class KernelTimer:
             s["bytes_total"] += meta.get("bytes", 0)
             s["flops_total"] += meta.get("flops", 0)
             key = meta.get("shape", "")
-            b = s["by_shape"].setdefault(key, {"launches": 0, "ms_total": 0.0, "bytes": meta.get("bytes", 0)})
+            b = s["by_shape"].setdefault(key, {"launches": 0, "ms_total": 0.0, "bytes": meta.get("bytes", 0), "flops": meta.get("flops", 0)})
             b["launches"] += 1
             b["ms_total"] += ms
         return out
