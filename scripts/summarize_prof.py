@@ -3,9 +3,12 @@
 
   python scripts/summarize_prof.py gpurun_out/prof_<tag>  ->  <dir>_summary.json + <dir>_kernel_stats.csv (top 60 rows)
 
-Per hand-written kernel (name contains 'ocf::'): calls, average/min/max duration from the kernel trace, grouped by grid size
-(= pyramid level); HBM traffic per launch from the PMC passes, corrected as MI355X_MICROARCH.md prescribes for gfx950
-(FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2; values are in KiB... the counter unit is bytes/1024).
+Per hand-written kernel (name contains 'ocf::'): calls, average/min/max duration from the kernel trace, grouped by TOTAL grid size
+(x * y * z work-items = pyramid level; the counter CSV of rocprofv3 only has the total, the trace CSV has the three components --
+round 3 keyed the trace by x alone and attached the counters of multi-dimensional grids to the wrong level); HBM traffic per launch from
+the PMC passes, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B request on wide coalesced
+reads -> x2 for 16-byte-per-lane streams; the factor for 8- and 12-byte per-lane loads is measured by tools/fetch_calib.cpp, see
+profiles/r4_fetch_calibration.txt; values are in KiB... the counter unit is bytes/1024).
 The raw traces (tens of MB) are deleted unless --keep."""
 import csv
 import glob
@@ -53,7 +56,10 @@ def trace_groups(path):
             name = row.get("Kernel_Name", "")
             if not ours(name):
                 continue
-            grid = row.get("Grid_Size_X") or row.get("Grid_Size") or "?"
+            if row.get("Grid_Size_X"):
+                grid = str(int(row["Grid_Size_X"]) * int(row.get("Grid_Size_Y") or 1) * int(row.get("Grid_Size_Z") or 1))
+            else:
+                grid = row.get("Grid_Size") or "?"
             dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
             groups[(short(name), grid)].append(dur)
     return groups
@@ -66,7 +72,12 @@ def counter_groups(path):
             name = row.get("Kernel_Name", "")
             if not ours(name):
                 continue
-            grid = row.get("Grid_Size_X") or row.get("Grid_Size") or "?"
+            if row.get("Grid_Size"):
+                grid = row["Grid_Size"]
+            elif row.get("Grid_Size_X"):
+                grid = str(int(row["Grid_Size_X"]) * int(row.get("Grid_Size_Y") or 1) * int(row.get("Grid_Size_Z") or 1))
+            else:
+                grid = "?"
             groups[(short(name), grid, row.get("Counter_Name", "?"))].append(float(row.get("Counter_Value", 0)))
     return groups
 
