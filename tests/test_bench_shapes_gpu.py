@@ -205,21 +205,39 @@ def test_row_kernel_edge_tiles(ops, lib, shape, with_occ):
     assert_close(out, ref, 8e-3, 1e-3)
 
 
+@pytest.mark.parametrize("with_occ", [True, False])
 @pytest.mark.parametrize("level", [2, 3, 4, 5, 6])
-def test_corr_occ_backward_at_bench_shapes(ops, level):
-    """ocf_corr_occ_bwd (tiled backward, mask folded in, d/docc by-product; channel-block split at the two smallest levels, 8-byte
-    granularity at C = 196) vs fp32 autograd of the oracle; gradients leave the kernel in bf16"""
+def test_corr_occ_backward_at_bench_shapes(ops, lib, level, with_occ):
+    """The correlation backward AS THE BENCHMARK RUNS IT: the cotangent is channels [0:81] of an 8 x 128 x h x w channels_last tensor (the
+    gradient of the decoder-input concatenation: 256-byte pixel pitch), with the occlusion mask folded in (FlowOccNet) and without
+    (FlowNet / the unsupervised step); the kernel identity is asserted -- ocf_corr_bwd_variant must answer the matrix-core kernel
+    (corr_bwd_mfma.hip: `corr_bwd_mfma_par_lds`, both gradients in one launch, the gradient operand staged through LDS) at all five
+    levels -- and its values are compared with fp32 autograd of the oracle; gradients leave the kernel in bf16."""
     f1, f2, _, occ = level_inputs(level, seed=1)
     Cc, h, w = LEVELS[level]
     gen = torch.Generator().manual_seed(77 + level)
-    cot = torch.randn((B, 81, h, w), generator=gen).bfloat16()
+    wide = torch.randn((B, 128, h, w), generator=gen).bfloat16()
+    cot = wide[:, :81]
     a, b2, o = f1.float().requires_grad_(), f2.float().requires_grad_(), occ.clone().requires_grad_()
-    g1r, g2r, gor = torch.autograd.grad(O.compute_cost_volume(a, b2 * o, 4), (a, b2, o), cot.float())
+    if with_occ:
+        g1r, g2r, gor = torch.autograd.grad(O.compute_cost_volume(a, b2 * o, 4), (a, b2, o), cot.float())
+    else:
+        g1r, g2r = torch.autograd.grad(O.compute_cost_volume(a, b2, 4), (a, b2), cot.float())
     x, y, oc = cl(f1).requires_grad_(), cl(f2).requires_grad_(), occ.to(DEV).requires_grad_()
-    g1, g2, go = torch.autograd.grad(ops.corr_warp(x, y, None, oc, 4), (x, y, oc), cl(cot))
+    wide_d = cl(wide)
+    cot_d = wide_d[:, :81]
+    assert cot_d.stride(3) == 128 and cot_d.stride(1) == 1  # the in-model layout: a channel slice at a 256-byte pitch
+    g1b, g2b = torch.empty_like(x), torch.empty_like(y)
+    v = lib.load().ocf_corr_bwd_variant(_t4(lib, x.detach()), _t4(lib, y.detach()), _t4(lib, cot_d), _t4(lib, g1b), _t4(lib, g2b), B, Cc, h, w, 4,
+                                        lib.OCF_BF16, 0)
+    assert v == 1, f"level {level}: ocf_corr_bwd_variant = {v}, expected OCF_CORR_BWD_MFMA (1)"
+    if with_occ:
+        g1, g2, go = torch.autograd.grad(ops.corr_warp(x, y, None, oc, 4), (x, y, oc), cot_d)
+        assert_close(go, gor, 2e-2, 4e-3, "grad occ")
+    else:
+        g1, g2 = torch.autograd.grad(ops.corr_warp(x, y, None, None, 4), (x, y), cot_d)
     assert_close(g1, g1r, 2e-2, 4e-3, "grad f1")
     assert_close(g2, g2r, 2e-2, 4e-3, "grad f2")
-    assert_close(go, gor, 2e-2, 4e-3, "grad occ")
 
 
 @pytest.mark.parametrize("level", [2, 3, 4, 5])
