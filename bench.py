@@ -254,7 +254,7 @@ def kernel_rooflines(summ: dict, peak: float) -> dict:
             tf = v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12
             out[name] = {"bound": "mfma", "launches": v["launches"], "avg_launch_us": round(1e3 * v["ms_total"] / v["launches"], 2),
                          "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-                         "us_per_step_share": round(1e3 * v["ms_total"], 1),
+                         "us_measured_total": round(1e3 * v["ms_total"], 1),
                          "per_shape": {k: {"launches": w["launches"], "avg_us": round(1e3 * w["ms_total"] / w["launches"], 2),
                                            "TFLOPs": round(w.get("flops", 0) / (1e-3 * w["ms_total"] / w["launches"]) / 1e12, 1)}
                                        for k, w in sorted(v["by_shape"].items(), key=lambda kv: -kv[1]["ms_total"])[:24]}}

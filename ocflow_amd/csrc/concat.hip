@@ -3,13 +3,16 @@
 // flow_net.py:104-121, flow_occ_net.py:153-176 with the alignment channels of `cat_aligned` (models/networks/_epilogue.py) written in the
 // same pass.  The framework's cat falls to its generic gather kernel for these operands (views of a paired batch, 81- and 2-channel
 // parts: 4 launches of ~68 us at 8 x 109 x 256) and needs a separate zero block for the padding.
-// Thread = one 16-byte unit (8 channels) of one output pixel: a unit inside ONE part whose pixels and channel offset are 16-byte
-// aligned is one vector load; any other unit (a part boundary, the 162-byte pixels of the cost volume) is gathered 2 bytes at a time.
+// Thread = one 16-byte unit (8 channels) of one output pixel: a unit inside ONE part is one 16-byte load -- at whatever 2-byte
+// alignment the part's pixels have (the 162-byte pixels of the cost volume: gfx950 serves unaligned global loads; the first version
+// gathered those units 2 bytes at a time and took 62 us for the 128-channel decoder input of 8 x 109 x 256, against 17 us for an
+// all-aligned concatenation of 96 channels) -- and only a unit that straddles a part boundary is gathered element by element.
 #include "ocf_common.h"
 
 namespace ocf {
 namespace cc {
 constexpr int MAXP = 6;
+struct __attribute__((packed, aligned(2))) U16B { u32x4 v; };  // a 16-byte load at 2-byte alignment (one global_load_dwordx4)
 struct Args {
   const char* p[MAXP];
   long pitch[MAXP];  // elements between consecutive pixels of part k
@@ -31,8 +34,8 @@ __global__ __launch_bounds__(256) void concat_kernel(const Args a) {
 #pragma unroll
     for (int q = 1; q < MAXP; q++) k += (q < a.n && ch >= a.c0[q]) ? 1 : 0;  // the part holding channel ch (if any)
     if (ch < a.c0[a.n]) {
-      if (a.vec[k] && ch + 8 <= a.c0[k + 1]) {
-        v = *(const u32x4*)(a.p[k] + (pix * a.pitch[k] + (ch - a.c0[k])) * 2);
+      if (ch + 8 <= a.c0[k + 1]) {
+        v = ((const U16B*)(a.p[k] + (pix * a.pitch[k] + (ch - a.c0[k])) * 2))->v;
       } else {
         unsigned short e[8];
 #pragma unroll
