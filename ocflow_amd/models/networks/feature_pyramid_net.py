@@ -15,7 +15,8 @@ def _conv3x3_same(conv: nn.Conv2d, x):
     """the stride-1 3x3 convolution of a DoubleConv block (bias-free, BatchNorm follows): on the repo's implicit-GEMM kernels where they
     take the operands (bf16 channels_last, channel counts that are multiples of 8 -- every level but the 196-channel top)"""
     if (conv.bias is None and nconv.enabled() and os.environ.get("OCFLOW_NATIVE_FPN", "1") != "0" and not torch.compiler.is_compiling()
-            and conv.weight.shape[0] % 8 == 0 and nconv.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
+            and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[1] >= 32  # (16 channels: half of every staged 64-byte pixel row is padding)
+            and nconv.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
         return nconv.conv3x3_bias_act(x, conv.weight, None, 1.0, 1)
     return conv(x)
 
