@@ -116,7 +116,7 @@ __device__ __forceinline__ void epilogue(const Args& a, const f32x4 (&acc)[MT][4
 
 template <int MT, int TW>
 __global__ __launch_bounds__(NTHR, 2) void conv3x3_igemm_kernel(const Args a) {
-  constexpr int TH = 512 / TW, FC = TW / 16;
+  constexpr int TH = 512 / TW, FC = TW / 16, SPLIT_KX = 0;
   constexpr int W_BYTES = 3 * MT * 1024, W_ITERS = (3 * MT + NWAVE - 1) / NWAVE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -204,7 +204,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_igemm_kernel(const Args a) {
   for (int s = 0; s < nstage; s++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s has landed
     __builtin_amdgcn_s_barrier();                      // everybody's has; and every wave is done reading the other buffer
-    if (s + 1 < nstage) issue(s + 1);
+    // The two waves of a SIMD (w and w + 4) issue the next stage's DMA at DIFFERENT points of the stage: an LDS-DMA instruction holds its
+    // wave at issue while the CU's load path (~60 GB/s) drains, and with all eight waves issuing first and computing afterwards the
+    // matrix cores idled through the issue phase.  Waves 0-3 issue before their first tap, waves 4-7 after it.
+    const bool early = wave < 4;
+    if (s + 1 < nstage && early) issue(s + 1);
     const char* buf = smem + (s & 1) * buf_bytes;
     const char* wbuf = buf + pix_bytes + aoff;
 #pragma unroll
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_igemm_kernel(const Args a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq[j], acc[m][j], 0, 0, 0);
       }
+      if (kx == SPLIT_KX && s + 1 < nstage && !early) issue(s + 1);
     }
   }
 
@@ -335,6 +340,10 @@ extern "C" int ocf_conv3x3_plan(int Cout, int B, int H, int W, int dilation, int
   const int tiles = (Cout + 15) / 16;
   int nblk = (tiles + 7) / 8, m = (tiles + nblk - 1) / nblk;
   while (patches * nblk < 192 && m > 2) {
+    nblk++;
+    m = (tiles + nblk - 1) / nblk;
+  }
+  if (m == 7) {  // (the 7-tile instantiation is the one that spills registers: 14 tiles run as 3 x 5)
     nblk++;
     m = (tiles + nblk - 1) / nblk;
   }
