@@ -39,6 +39,8 @@ struct Args {
   const char* act;    // [B][H][W][ap] bf16 or null
   long xp, yp, ap;    // pixel pitches, elements
   int B, H, W, Cin, Cout, wK, d, tiles_x, tiles_y;
+  int rows_epi;  // 1: row-store epilogue through LDS (Cout % 8 == 0, 16-byte aligned output pixels)
+  int tune;  // ablation (policy bits 1024 / 2048 / 4096): no fragment reads + MFMAs / no DMA / no epilogue stores
   float slope, mslope;
 };
 
@@ -111,6 +113,62 @@ __device__ __forceinline__ void epilogue(const Args& a, const f32x4 (&acc)[MT][4
         }
       }
     }
+  }
+}
+
+// Row-store epilogue (Cout % 8 == 0, 16-byte aligned output pixels): the accumulators leave the wave as WHOLE pixel rows.  Each lane
+// holds 4 consecutive channels of one pixel per accumulator register -- stored directly that is 32 instructions of 8 bytes per lane
+// at a 2*Cout-byte stride (measured: 19 of the 85 us of 8 x 128 -> 128 x 109 x 256, a store tail bound by instruction count, not by
+// bytes).  Here bias + LeakyReLU are applied in registers, the wave's 64 x (16 MT) tile goes through its own LDS slab
+// ([pixel][channel], pitch 32 MT + 16 bytes: the ds_write_b64 of 16 pixels and the ds_read_b128 of a row are both conflict-free) and
+// is stored 16 bytes per lane, 16 MT / 8 lanes per pixel row; the activation-derivative mask is read the same way.
+template <int MT, int TW, bool ACT>
+__device__ __forceinline__ void epilogue_rows(const Args& a, const f32x4 (&acc)[MT][4], char* slab, int wave, int lane, int mrow0, int b, int x0,
+                                              int y0) {
+  constexpr int FC = TW / 16, PITCH = MT * 32 + 16, CPR = MT * 2;  // 16-byte chunks per pixel row
+  const int g = lane >> 4, l15 = lane & 15;
+  const float slope = a.slope, mslope = a.mslope;
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    const int cb = mrow0 + m * 16 + 4 * g;
+    if (a.bias) bv = *(const f32x4*)(a.bias + (cb < a.Cout ? cb : 0));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        v[e] = acc[m][j][e] + bv[e];
+        v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+      }
+      const bf16x2 lo = {(bf16)v[0], (bf16)v[1]}, hi = {(bf16)v[2], (bf16)v[3]};
+      const u32x2 o = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+      *(u32x2*)(slab + (j * 16 + l15) * PITCH + (m * 16 + 4 * g) * 2) = o;
+    }
+  }
+  // (the slab is private to the wave: its own LDS writes are ordered before its reads, no barrier)
+#pragma unroll
+  for (int i = 0; i < (64 * CPR + 63) / 64; i++) {
+    const int idx = i * 64 + lane;
+    const int row = idx / CPR, chunk = idx - row * CPR;  // row = j * 16 + pixel-in-fragment
+    const int j = row >> 4, f = wave * 4 + j, fr = f / FC, fc = f - fr * FC;
+    const int yy = y0 + fr, xx = x0 + fc * 16 + (row & 15);
+    const int cb = mrow0 + chunk * 8;
+    const bool ok = idx < 64 * CPR && yy < a.H && xx < a.W && cb < a.Cout;
+    const long pix = ok ? ((long)b * a.H + yy) * a.W + xx : 0;
+    u32x4 v = *(const u32x4*)(slab + (ok ? row : 0) * PITCH + (ok ? chunk : 0) * 16);
+    if (ACT) {
+      const u32x4 mv = *(const u32x4*)(a.act + (pix * a.ap + (ok ? cb : 0)) * 2);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float lo = bf_lo(v[e]), hi = bf_hi(v[e]);
+        lo *= bf_lo(mv[e]) > 0.f ? 1.f : mslope;
+        hi *= bf_hi(mv[e]) > 0.f ? 1.f : mslope;
+        const bf16x2 p2 = {(bf16)lo, (bf16)hi};
+        v[e] = __builtin_bit_cast(unsigned, p2);
+      }
+    }
+    if (ok) *(u32x4*)(a.y + (pix * a.yp + cb) * 2) = v;
   }
 }
 
@@ -200,7 +258,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_igemm_kernel(const Args a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
+  if (!(a.tune & 2)) issue(0);
   for (int s = 0; s < nstage; s++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s has landed
     __builtin_amdgcn_s_barrier();                      // everybody's has; and every wave is done reading the other buffer
@@ -208,26 +266,36 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_igemm_kernel(const Args a) {
     // wave at issue while the CU's load path (~60 GB/s) drains, and with all eight waves issuing first and computing afterwards the
     // matrix cores idled through the issue phase.  Waves 0-3 issue before their first tap, waves 4-7 after it.
     const bool early = wave < 4;
-    if (s + 1 < nstage && early) issue(s + 1);
+    if (s + 1 < nstage && early && !(a.tune & 2)) issue(s + 1);
     const char* buf = smem + (s & 1) * buf_bytes;
     const char* wbuf = buf + pix_bytes + aoff;
 #pragma unroll
     for (int kx = 0; kx < 3; kx++) {
-      bf16x8 bq[4];
+      if (!(a.tune & 1)) {
+        bf16x8 bq[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) bq[j] = *(const bf16x8*)(buf + boff[j][kx]);
+        for (int j = 0; j < 4; j++) bq[j] = *(const bf16x8*)(buf + boff[j][kx]);
 #pragma unroll
-      for (int m = 0; m < MT; m++) {
-        const bf16x8 aq = *(const bf16x8*)(wbuf + (kx * MT + m) * 1024);
+        for (int m = 0; m < MT; m++) {
+          const bf16x8 aq = *(const bf16x8*)(wbuf + (kx * MT + m) * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq[j], acc[m][j], 0, 0, 0);
+          for (int j = 0; j < 4; j++) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq[j], acc[m][j], 0, 0, 0);
+        }
       }
-      if (kx == SPLIT_KX && s + 1 < nstage && !early) issue(s + 1);
+      if (kx == SPLIT_KX && s + 1 < nstage && !early && !(a.tune & 2)) issue(s + 1);
     }
   }
 
   // ---- epilogue: lane = pixel l15 of fragment j, registers = channels 16 m + 4 g + 0..3 ----------------------------------------------
   const int cb0 = mrow0 + 4 * g;
+  if (a.tune & 4) return;
+  if (a.rows_epi) {
+    __syncthreads();  // every wave is done reading the last stage's buffer: the slabs overlay the stage buffers
+    char* slab = smem + wave * (64 * (MT * 32 + 16));
+    if (a.act) epilogue_rows<MT, TW, true>(a, acc, slab, wave, lane, mrow0, b, x0, y0);
+    else epilogue_rows<MT, TW, false>(a, acc, slab, wave, lane, mrow0, b, x0, y0);
+    return;
+  }
   if ((a.Cout & 3) == 0) {
     if (a.act) epilogue<MT, TW, true, true>(a, acc, wave, l15, cb0, b, x0, y0);
     else epilogue<MT, TW, true, false>(a, acc, wave, l15, cb0, b, x0, y0);
@@ -368,6 +436,7 @@ extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int
   const int st = ocf_conv3x3_plan(Cout, B, H, W, dilation, &mt, &tw, &rows_pad);
   if (st != OCF_OK) return st;
   const int pw = policy & 255;
+  const int tune = (policy >> 10) & 7;  // (bit 8192: keep the direct 8-byte epilogue stores, A/B)
   if (pw == 16 || pw == 32 || pw == 64) tw = pw;  // A/B: force the patch width
   else if (pw != 0) return OCF_EINVAL;
   // channels_last views: channel stride 1, rows and images dense in pixels at one pixel pitch (size-1 dimensions carry arbitrary strides)
@@ -396,10 +465,16 @@ extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int
   a.xp = pitch(x, Cin); a.yp = pitch(y, Cout); a.ap = act ? pitch(act, Cout) : 0;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.wK = w_k; a.d = dilation;
   a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
-  a.slope = negative_slope; a.mslope = mask_slope;
+  a.slope = negative_slope; a.mslope = mask_slope; a.tune = tune;
   const int npi = (th * (tw + 2 * dilation) * 64 + 1023) / 1024;
   if (npi > ig::PIX_ITERS * ig::NWAVE) return OCF_EUNSUPPORTED;
-  const size_t lds = 2 * ((size_t)npi * 1024 + 3 * (size_t)mt * 1024);
+  size_t lds = 2 * ((size_t)npi * 1024 + 3 * (size_t)mt * 1024);
+  auto al16 = [&](const ocf_tensor4* t, int C) { return (uintptr_t)t->data % 16 == 0 && (pitch(t, C) * 2) % 16 == 0; };
+  a.rows_epi = (Cout % 8 == 0 && al16(y, Cout) && (!act || al16(act, Cout)) && (!bias || (uintptr_t)bias % 16 == 0) && !(policy & 8192)) ? 1 : 0;
+  if (a.rows_epi) {
+    const size_t slabs = (size_t)ig::NWAVE * 64 * ((size_t)mt * 32 + 16);
+    if (slabs > lds) lds = slabs;
+  }
   ig::kern_t k = tw == 64 ? ig::pick_mt<64>(mt) : (tw == 32 ? ig::pick_mt<32>(mt) : ig::pick_mt<16>(mt));
   if (!ig::lds_attr_done(k)) return OCF_ELAUNCH;
   LaunchProf lp;
