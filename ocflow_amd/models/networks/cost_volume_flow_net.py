@@ -9,6 +9,7 @@ import torch.nn.functional as F
 
 import os
 
+from ocflow_amd import conv as nconv
 from ocflow_amd import ops
 from ._epilogue import ConvLReLU, cat_aligned, conv_bias, deconv_bias
 
@@ -100,9 +101,15 @@ class FlowNetCV(nn.Module):
         return ops.warp(img, flow, align_corners=False)
 
     def forward(self, x):
-        # OCFLOW_PAD_PWC=1: the 32-channel aligned concatenations of the FPN nets here too.  DIAGNOSTIC switch (scripts/diag_fault2.py):
-        # this is the configuration in which round 2 hit a GPU memory fault at 8 x 384 x 512; off by default, see DESIGN.md section 11.
-        pad = os.environ.get("OCFLOW_PAD_PWC", "0") == "1"
+        # Aligned (32-channel) concatenations: with the repo's own convolution kernels consuming them (round 4: every dense-block layer,
+        # the prediction layers and the context network run on ocf_conv3x3_igemm / ocf_conv3x3_wgrad_bias when their input has a multiple of
+        # 8 channels) this is the default in the bf16 channels_last configuration.  The ONE library kernel class that met padded operands
+        # in round 2 -- the transposed convolution `upfeat` on a padded [in + pad, 2, 4, 4] weight, the suspect of the GPU memory fault at
+        # 8 x 384 x 512 -- is handed the unpadded channel range instead.  OCFLOW_PAD_PWC=1 forces the round-2
+        # configuration (padded operands into the library: scripts/diag_fault2.py), OCFLOW_PAD_PWC=0 the plain concatenations.
+        env = os.environ.get("OCFLOW_PAD_PWC", "auto")
+        native = env == "auto" and nconv.enabled() and x.is_cuda and torch.is_autocast_enabled() and not torch.compiler.is_compiling()
+        pad = env == "1" or native
         cat = cat_aligned if pad else torch.cat
         c1 = encode(self, x[:, :3])
         c2 = encode(self, x[:, 3:])
@@ -114,7 +121,7 @@ class FlowNetCV(nn.Module):
             f1, f2 = self.normalize([f1, f2])
             corr = self.leakyRELU(ops.compute_cost_volume(f1, f2, max_displacement=self.displacement))
             if lvl == 6:
-                feats = corr
+                feats = cat_aligned([corr]) if native else corr
             else:
                 # the NORMALISED c1 is what enters the decoder (:190)
                 feats = cat((corr, f1, up_flow.to(corr.dtype), up_feat.to(corr.dtype)), 1)
@@ -123,7 +130,8 @@ class FlowNetCV(nn.Module):
                 flow = conv_bias(getattr(self, f"predict_flow{lvl}"), feats)
                 if lvl > 2:
                     up_flow = deconv_bias(getattr(self, f"deconv{lvl}"), flow)
-                    up_feat = deconv_bias(getattr(self, f"upfeat{lvl}"), feats)
+                    upf = getattr(self, f"upfeat{lvl}")
+                    up_feat = deconv_bias(upf, feats[:, :upf.weight.shape[0]] if native else feats)
                 continue
             flow = getattr(self, f"predict_flow{lvl}")(feats)
             if lvl > 2:
