@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -56,6 +57,7 @@ class WeightPacker:
         self.entries: Dict[Tuple[int, int], _Packed] = {}
         self._order: List[_Packed] = []
         self._dev_descs: Optional[torch.Tensor] = None
+        self._retired: List[torch.Tensor] = []
         self._total = 0
         self._stamp = -1          # ops-level "weights changed" counter seen by the last refresh
         self._capture_seen = 0
@@ -69,21 +71,32 @@ class WeightPacker:
         e.transpose = bool(transpose)
         e.version = -1
         e.epoch = -1
-        e.src_ref = w
+        e.src_ref = weakref.ref(w)  # (weak: the packer must not keep the weights of every model a process ever built alive)
         self.entries[(id(w), int(transpose), int(min_rows))] = e
         self._order.append(e)
+        if self._dev_descs is not None:
+            self._retired.append(self._dev_descs)
         self._dev_descs = None  # descriptor table is rebuilt on the next refresh
         return e
 
+    def _purge(self):
+        """drop the entries whose weight has been garbage-collected (a later tensor may re-use the id)"""
+        if any(e.src_ref() is None for e in self._order):
+            self._order = [e for e in self._order if e.src_ref() is not None]
+            self.entries = {k: e for k, e in self.entries.items() if e.src_ref() is not None}
+            if self._dev_descs is not None:
+                self._retired.append(self._dev_descs)
+            self._dev_descs = None
+
     def _build_table(self, device):
-        n = len(self._order)
+        live = [(e, e.src_ref()) for e in self._order]
+        n = len(live)
         nbytes = C.c_int64(0)
         lib = _lib.load()
         _lib.check(lib.ocf_conv3x3_pack_bytes(n, C.byref(nbytes)), "ocf_conv3x3_pack_bytes")
         host = (C.c_char * nbytes.value)()
         first = C.c_int64(0)
-        for i, e in enumerate(self._order):
-            w = e.src_ref
+        for i, (e, w) in enumerate(live):
             so, si, sky, skx = w.stride()
             nxt = C.c_int64(0)
             _lib.check(lib.ocf_conv3x3_pack_describe(host, i, C.c_void_p(w.data_ptr()), so, si, sky, skx, int(w.shape[0]), int(w.shape[1]),
@@ -92,23 +105,28 @@ class WeightPacker:
             first = nxt
         self._total = first.value
         t = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).clone()
+        if self._dev_descs is not None:
+            self._retired.append(self._dev_descs)  # a captured graph may still replay a launch that reads the old table
         self._dev_descs = t.to(device)
-        self._ptrs = [e.src_ref.data_ptr() for e in self._order]
+        self._ptrs = [(w.data_ptr(), w.dtype) for _, w in live]
 
     def refresh(self, device=None):
+        self._purge()
         if not self._order:
             return
         device = device or self._order[0].dst.device
-        if self._dev_descs is None or any(e.src_ref.data_ptr() != p for e, p in zip(self._order, self._ptrs)):
+        live = [e.src_ref() for e in self._order]
+        if self._dev_descs is None or len(live) != len(self._ptrs) or any(w is None or (w.data_ptr(), w.dtype) != p for w, p in zip(live, self._ptrs)):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("ocflow_amd.conv.WeightPacker: a weight was registered or re-allocated during a graph capture; run the "
                                    "step once eagerly first")
             self._build_table(device)
+            live = [e.src_ref() for e in self._order]
         with torch.cuda.device(device):
             _lib.check(_lib.load().ocf_conv3x3_pack_weights(C.c_void_p(self._dev_descs.data_ptr()), len(self._order), self._total,
                                                             C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "ocf_conv3x3_pack_weights")
-        for e in self._order:
-            e.version = e.src_ref._version
+        for e, w in zip(self._order, live):
+            e.version = w._version
             e.epoch = _OPT_EPOCH[0]
 
     def get(self, w: torch.Tensor, transpose: bool, min_rows: int = 0) -> _Packed:
@@ -117,12 +135,17 @@ class WeightPacker:
         if w.dtype not in (torch.bfloat16, torch.float32):
             raise TypeError(f"ocflow_amd.conv: weight dtype {w.dtype}")
         e = self.entries.get((id(w), int(transpose), int(min_rows)))
+        if e is not None and e.src_ref() is not w:  # the id of a dead tensor, re-used
+            self._purge()
+            e = self.entries.get((id(w), int(transpose), int(min_rows)))
+            if e is not None and e.src_ref() is not w:
+                e = None
         if e is None:
             e = self._register(w, transpose, int(min_rows))
         # a weight changes (a) through in-place tensor ops, which move its version counter, or (b) under an optimizer step -- torch's FUSED
         # Adam updates parameters WITHOUT touching the version counter (measured: three eager steps on three-step-old packed weights), so
         # every optimizer.step() in the process moves an epoch (global post-step hook below)
-        stale = e.version != w._version or e.epoch != _OPT_EPOCH[0] or e.src_ref is not w
+        stale = e.version != w._version or e.epoch != _OPT_EPOCH[0]
         if torch.cuda.is_current_stream_capturing():
             cid = ops._capture_id(w.device)
             stale = stale or self._capture_seen != cid

@@ -2,13 +2,17 @@
 by the up-sampled occlusion map before the correlation (reference:
 models/networks/cost_volume_flow_occ_net.py:26-271).  On MI355X warp * occ -> cost volume is ONE kernel
 (ops.corr_warp); neither `warp5` nor `warp5 * up_occ6` (:204-206) is written to HBM."""
+import os
+
 import torch
 import torch.nn as nn
 
+from ._epilogue import cat_aligned, conv_bias, deconv_bias
 from .cost_volume_flow_net import (DENSE_TOTAL, DENSE_WIDTHS, ENC_WIDTHS, WARP_SCALE, build_context, build_encoder, context,
                                    conv, deconv, dense_block, encode, predict_flow)
 from .cost_volume_net import CostVolumeLayer
 from .flow_net import kaiming_init_
+from ocflow_amd import conv as nconv
 from ocflow_amd import ops
 
 
@@ -45,6 +49,10 @@ class FlowOccNetCV(nn.Module):
         return ops.warp(img, flow, align_corners=False)
 
     def forward(self, x):
+        # aligned concatenations + the repo's convolution kernels in the bf16 channels_last configuration, exactly as FlowNetCV.forward
+        # (cost_volume_flow_net.py): the library's transposed convolution `upfeat` is handed the unpadded channel range
+        native = (os.environ.get("OCFLOW_PAD_PWC", "auto") == "auto" and nconv.enabled() and x.is_cuda and torch.is_autocast_enabled()
+                  and not torch.compiler.is_compiling())
         c1 = encode(self, x[:, :3])
         c2 = encode(self, x[:, 3:])
         up_flow = up_occ = up_feat = flow = occ = feats = None
@@ -52,15 +60,24 @@ class FlowOccNetCV(nn.Module):
             f1, f2 = c1[lvl - 1], c2[lvl - 1]
             if lvl == 6:
                 feats = self.leakyRELU(self.corr(f1, f2))
+                if native:
+                    feats = cat_aligned([feats])
             else:
                 corr = self.leakyRELU(self.corr(f1, f2, up_flow, up_occ, WARP_SCALE[lvl]))
-                feats = torch.cat((corr.to(f1.dtype), f1, up_flow.to(f1.dtype), up_occ.to(f1.dtype), up_feat.to(f1.dtype)), 1)
+                parts = (corr.to(f1.dtype), f1, up_flow.to(f1.dtype), up_occ.to(f1.dtype), up_feat.to(f1.dtype))
+                feats = cat_aligned(parts) if native else torch.cat(parts, 1)
             feats = dense_block(self, lvl, feats)
-            flow = getattr(self, f"predict_flow{lvl}")(feats)
-            occ = getattr(self, f"predict_occ{lvl}")(feats)
+            if native:
+                flow = conv_bias(getattr(self, f"predict_flow{lvl}"), feats)
+                po = getattr(self, f"predict_occ{lvl}")
+                occ = po[1](conv_bias(po[0], feats))
+            else:
+                flow = getattr(self, f"predict_flow{lvl}")(feats)
+                occ = getattr(self, f"predict_occ{lvl}")(feats)
             if lvl > 2:
                 up_flow = getattr(self, f"upflow{lvl}")(flow)
                 up_occ = getattr(self, f"upocc{lvl}")(occ)
-                up_feat = getattr(self, f"upfeat{lvl}")(feats)
+                upf = getattr(self, f"upfeat{lvl}")
+                up_feat = upf(feats[:, :upf.weight.shape[0]]) if native else upf(feats)
         flow2 = flow + context(self, feats)
         return self.upsample1(flow2), self.upsample2(occ)
