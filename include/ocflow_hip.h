@@ -350,6 +350,20 @@ int ocf_conv3x3_wgrad_bias(const ocf_tensor4* x, const ocf_tensor4* dz, float* g
 int ocf_concat_channels(const ocf_tensor4* const* parts, const int* channels, int n, const ocf_tensor4* out, int Cout, int B, int H, int W, int dtype,
                         void* stream);
 
+/* ---- the estimators' up-sampling layers: ConvTranspose2d(Ci, Co, kernel 3, stride 2, padding 1), Co <= 4, Ci <= 64, bf16 pixel-major views
+ * x [B, Ci, H, W] and y [B, Co, Ho, Wo] with Ho in {2H - 1, 2H}, Wo in {2W - 1, 2W} (output_padding 0 / 1 per axis);
+ *   y[b,co,oy,ox] = bias[co] + sum x[b,ci,iy,ix] * w[ci,co,ky,kx] over oy = 2 iy - 1 + ky, ox = 2 ix - 1 + kx.
+ * w: the module's [Ci, Co, 3, 3] weight (fp32 when w_is_f32, else bf16) with element strides w_s*; bias fp32 or NULL.
+ * _bwd: gx (bf16 pixel-major, may be NULL) = input gradient; gw (fp32, element strides g_s*, ACCUMULATED with atomics, may be NULL) and
+ * gbias (fp32 [Co], accumulated, may be NULL) = parameter gradients.  Anything else: OCF_EUNSUPPORTED.
+ * replaces: `upconv1` / `upconv2` of flow_net.py:38-48 and flow_occ_net.py:46-66 (F.conv_transpose2d + bias and their autograd: the
+ *           library's vector-1 implicit GEMM / naive_conv kernels, a workspace fill and a cast per weight gradient). */
+int ocf_deconv3x3s2_fwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64_t w_so, int64_t w_sy, int64_t w_sx, int w_is_f32,
+                        const float* bias, const ocf_tensor4* y, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype, void* stream);
+int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64_t w_so, int64_t w_sy, int64_t w_sx, int w_is_f32,
+                        const ocf_tensor4* gy, const ocf_tensor4* gx, float* gw, int64_t g_si, int64_t g_so, int64_t g_sy, int64_t g_sx,
+                        float* gbias, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype, void* stream);
+
 /* ---- BatchNorm2d (batch statistics) + LeakyReLU of the feature-pyramid encoder
  * replaces: nn.BatchNorm2d + nn.LeakyReLU(0.1) of the reference's `conv_bn_relu` blocks (models/networks/feature_pyramid_net.py:5-95), i.e.
  * torch.batch_norm(training) + leaky_relu and their autograd.  Dense channels_last x / y / gy / gx of `dtype` (OCF_F32 / OCF_BF16), C a

@@ -80,6 +80,9 @@ SIGNATURES = {
     "ocf_conv3x3_pack_weights": [_vp, _i, C.c_int64, _vp],
     "ocf_conv3x3_wgrad_bias": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_concat_channels": [C.POINTER(_T4P), C.POINTER(_i), _i, _T4P, _i, _i, _i, _i, _i, _vp],
+    "ocf_deconv3x3s2_fwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _vp, _T4P, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_deconv3x3s2_bwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp,
+                            _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_bias_act_fwd": [_T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ocf_bn_act_workspace_bytes": [_i, _i, C.POINTER(C.c_int64)],

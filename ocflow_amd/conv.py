@@ -498,3 +498,77 @@ def _native_wgrad() -> bool:
 def enabled() -> bool:
     """OCFLOW_NATIVE_CONV: "1" (default) routes eligible layers through these kernels, "0" keeps the framework's convolutions"""
     return os.environ.get("OCFLOW_NATIVE_CONV", "1") != "0"
+
+
+# ---- the estimators' up-sampling layers (ConvTranspose2d 3x3, stride 2, padding 1, <= 4 output channels): csrc/deconv_small.hip
+
+def deconv_eligible(x, weight, stride, padding, dilation, groups, output_padding) -> bool:
+    """layers ocf_deconv3x3s2_* take: bf16 pixel-major x [B, Ci <= 64, H, W], weight [Ci, Co <= 4, 3, 3], stride 2, padding 1"""
+    if not (enabled() and os.environ.get("OCFLOW_NATIVE_DECONV", "1") != "0"):
+        return False
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and _pixel_major(x, 2)):
+        return False
+    if weight.dtype not in (torch.bfloat16, torch.float32) or tuple(weight.shape[2:]) != (3, 3) or groups != 1:
+        return False
+    if tuple(stride) != (2, 2) or tuple(padding) != (1, 1) or tuple(dilation) != (1, 1) or any(p not in (0, 1) for p in output_padding):
+        return False
+    return weight.shape[0] == x.shape[1] and weight.shape[0] <= 64 and weight.shape[1] <= 4
+
+
+class _DeconvBiasFn(Function):
+    """ConvTranspose2d(3x3, stride 2, padding 1) + bias: forward one launch, backward two (input gradient; weight + bias gradient into fp32)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_pad):
+        B, ci, H, W = x.shape
+        co = int(weight.shape[1])
+        Ho, Wo = 2 * H - 1 + out_pad[0], 2 * W - 1 + out_pad[1]
+        y = torch.empty((B, co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        bf = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        si, so, sy, sx = weight.stride()
+        with torch.cuda.device(x.device):
+            fn = lambda: _lib.check(_lib.load().ocf_deconv3x3s2_fwd(_t4(x), C.c_void_p(weight.data_ptr()), si, so, sy, sx,
+                                                                     int(weight.dtype == torch.float32), _ptr(bf), _t4(y), B, ci, co, H, W, Ho, Wo,
+                                                                     _lib.OCF_BF16, _stream(x)), "ocf_deconv3x3s2_fwd")
+            ops._launch("deconv3x3s2_fwd", lambda: ops._meta(f"B{B}x{ci}->{co}x{H}x{W}", 2 * B * (H * W * ci + Ho * Wo * co), 0), fn)
+        ctx.save_for_backward(x, weight, *([bias] if bias is not None else []))
+        ctx.geom = (Ho, Wo, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors[:2]
+        Ho, Wo, has_bias = ctx.geom
+        bias = ctx.saved_tensors[2] if has_bias else None
+        B, ci, H, W = x.shape
+        co = int(weight.shape[1])
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        gg = gy if gy.dtype == x.dtype else gy.to(x.dtype)
+        if not _pixel_major(gg, 2):
+            gg = gg.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty(x.shape, device=x.device, dtype=x.dtype, memory_format=torch.channels_last) if need_x else None
+        gw = gb = None
+        w_sink = b_sink = False
+        if need_w:
+            gw, w_sink = _grad_target(weight, gy.device)
+            if need_b:
+                gb, b_sink = _grad_target(bias, gy.device)
+        si, so, sy, sx = weight.stride()
+        gs = gw.stride() if gw is not None else (0, 0, 0, 0)
+        with torch.cuda.device(x.device):
+            fn = lambda: _lib.check(_lib.load().ocf_deconv3x3s2_bwd(_t4(x), C.c_void_p(weight.data_ptr()), si, so, sy, sx,
+                                                                     int(weight.dtype == torch.float32), _t4(gg), _t4(gx), _ptr(gw), gs[0], gs[1], gs[2],
+                                                                     gs[3], _ptr(gb), B, ci, co, H, W, Ho, Wo, _lib.OCF_BF16, _stream(x)),
+                                    "ocf_deconv3x3s2_bwd")
+            ops._launch("deconv3x3s2_bwd", lambda: ops._meta(f"B{B}x{ci}->{co}x{H}x{W}", 2 * B * (2 * H * W * ci + 2 * Ho * Wo * co), 0), fn)
+        if need_b and gb is None:
+            gb = gg.float().sum((0, 2, 3))
+        if gb is not None and not b_sink and bias.dtype != torch.float32:
+            gb = gb.to(bias.dtype)
+        return gx, (None if w_sink else gw), (None if (b_sink or not need_b) else gb), None
+
+
+def deconv3x3s2_bias(x, weight, bias, output_padding):
+    """`F.conv_transpose2d(x, weight, bias, 2, 1, output_padding)` on the small-channel kernels; the caller checks `deconv_eligible` first"""
+    return _DeconvBiasFn.apply(x, weight, bias, (int(output_padding[0]), int(output_padding[1])))

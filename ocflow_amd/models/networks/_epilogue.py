@@ -235,6 +235,8 @@ def deconv_bias(deconv: nn.ConvTranspose2d, x, output_size=None):
     output_padding = deconv._output_padding(x, output_size, deconv.stride, deconv.padding, deconv.kernel_size, 2, deconv.dilation)
     if deconv.bias is None or deconv.padding_mode != "zeros" or _unfused():
         return F.conv_transpose2d(x, w, deconv.bias, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
+    if nconv.deconv_eligible(x, deconv.weight, deconv.stride, deconv.padding, deconv.dilation, deconv.groups, output_padding):
+        return nconv.deconv3x3s2_bias(x, deconv.weight, deconv.bias, output_padding)
     y = F.conv_transpose2d(x, w, None, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
     return ops.bias_add(y, deconv.bias)
 

@@ -1,7 +1,13 @@
 set -o pipefail
 OUT=gpurun_out; mkdir -p $OUT
-timeout -k 10 400 python -m pytest tests/test_conv_igemm_gpu.py -q -m gpu -x 2>&1 | grep -v "MIOpen(HIP): Warning" | tail -3
-for p in 512 8704; do
-  echo "== policy $p (512 staged, row epilogue; 8704 = +8192 direct 8-byte stores)"
-  timeout -k 10 300 python scripts/bench_conv.py --levels 2,3 --tw $p --rounds 4 2>&1 | grep "d 1\|d16\|sum"
-done
+timeout -k 10 300 python -m pytest tests/test_deconv_gpu.py -q -x > $OUT/r4t_deconv.txt 2>&1
+rc=$?
+grep -v "MIOpen(HIP): Warning" $OUT/r4t_deconv.txt | tail -5
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python bench.py > $OUT/r4t_bench.json 2> $OUT/r4t_bench.err && python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4t_bench.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['unsupervised']['value'], d['cfg3']['value'])
+PY
+timeout -k 10 900 python -m pytest tests/test_models_gpu.py tests/test_configs_gpu.py tests/test_train_gpu.py -q -x > $OUT/r4t_models.txt 2>&1
+grep -v "MIOpen(HIP): Warning" $OUT/r4t_models.txt | grep -n "Fatal\|Aborted\|fault\|^E  \|FAILED\|passed\|failed" | head -20
