@@ -97,7 +97,8 @@ enum ocf_corr_variant {
   OCF_CORR_BAND_MULTI_TH4 = 12, /* bf16 band-GEMM kernel, C > 32, 4-row tiles                                      */
   OCF_CORR_BAND_MULTI_TH2 = 13, /*   ... 2-row tiles (fewer 4-row tiles than CUs)                                  */
   OCF_CORR_BAND_MULTI_TH1 = 14, /*   ... 1-row tiles (fewer than a quarter of that)                                */
-  OCF_CORR_VECTOR_F32 = 20      /* fp32 vector-ALU kernel                                                          */
+  OCF_CORR_VECTOR_F32 = 20,     /* fp32 vector-ALU kernel                                                          */
+  OCF_CORR_VECTOR_BF16 = 21     /* the same kernel on bf16 operands whose layout gives no 8- or 16-byte channel runs (NCHW, odd strides) */
 };
 int ocf_corr_fwd_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                          const ocf_tensor4* out, int B, int C, int H, int W, int d, int dtype, int policy);
@@ -157,8 +158,14 @@ enum ocf_warp_bwd_policy {
   OCF_WARP_BWD_POLICY_AUTO = 0,
   OCF_WARP_BWD_POLICY_SCATTER = 1,
   OCF_WARP_BWD_POLICY_GATHER = 2, /* window gather (near sources) + float atomics for far sources, no workspace          */
-  OCF_WARP_BWD_POLICY_BINNED = 3  /* binned gather (needs `workspace`; falls back to the window form when it is NULL)  */
+  OCF_WARP_BWD_POLICY_BINNED = 3, /* binned gather (needs `workspace`; falls back to the window form when it is NULL)  */
+  OCF_WARP_BWD_POLICY_SMALL = 4,  /* behaves as AUTO (named for tests and A/B runs): see the note on small maps below              */
+  OCF_WARP_BWD_GIMG_NATIVE = 0x100 /* flag, OR-ed to the policy: grad_img is given (and written) in `dtype` instead of fp32; only valid
+                                     when ocf_warp_bwd_plan() returned bit 1 for the same request */
 };
+/* AUTO additionally: channels_last maps of at most 1792 pixels per image (the three coarsest pyramid levels) take the single-launch
+ * kernel at ANY channel count (grad_img by list gather over the whole image, grad_flow by further workgroups of the same grid).
+ * ocf_warp_bwd_plan() result: bit 0 = zero grad_img first; bit 1 = grad_img may be passed in `dtype` (with OCF_WARP_BWD_GIMG_NATIVE). */
 /* Scratch of the BINNED gather of ocf_warp_bwd (any contents, caller-allocated, at least this many bytes): a binning pass lists, per 32 x 8
  * destination tile, the sources whose bilinear taps land in it; the gather kernel walks that list instead of a fixed +-6 pixel window, so
  * sources with ANY displacement are gathered with plain stores (the window form sent 25-44 % of the sources of an untrained model through

@@ -24,7 +24,8 @@ CORR_AUTO, CORR_BAND_ONLY, CORR_NO_WAVE, CORR_WAVE = 0, 1, 2, 3
 CORR_VARIANT_WAVE = 4  # enum ocf_corr_variant
 CORR_VARIANTS_WITH_GATHER = (1, 2, 4)  # row kernels (C <= 64) and wave kernel: the warp gathered inside the correlation launch
 CORR_BWD_AUTO, CORR_BWD_VECTOR, CORR_BWD_MFMA = 0, 1, 2
-WARP_BWD_AUTO, WARP_BWD_SCATTER, WARP_BWD_GATHER, WARP_BWD_BINNED = 0, 1, 2, 3
+WARP_BWD_AUTO, WARP_BWD_SCATTER, WARP_BWD_GATHER, WARP_BWD_BINNED, WARP_BWD_SMALL = 0, 1, 2, 3, 4
+WARP_BWD_GIMG_NATIVE = 0x100  # flag: grad_img in the feature dtype (when ocf_warp_bwd_plan answers bit 1)
 RANGE_AUTO, RANGE_SPLAT, RANGE_GATHER = 0, 1, 2
 OCF_OK = 0
 OCF_EUNSUPPORTED = -2

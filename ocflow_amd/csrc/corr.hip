@@ -595,7 +595,7 @@ static int launch_fwd_d(const T4& f1, const T4& f2, const T4& flow, const T4& oc
   return launch_status();
 }
 
-template <typename T>
+template <typename T, bool ELEMENT_LOADS_ONLY = false>
 static int corr_fwd_t(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                       const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st) {
   // in-image offsets are 32-bit in the kernels
@@ -623,10 +623,18 @@ static int corr_fwd_t(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_te
   (flow ? launch_fwd_d<T, V, 2>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)                               \
         : (occ ? launch_fwd_d<T, V, 1>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)                        \
                : launch_fwd_d<T, V, 0>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)))
-  if (vec == 16) return OCF_DISPATCH(16);
-  if (vec == 8) return OCF_DISPATCH(8);
+  if constexpr (!ELEMENT_LOADS_ONLY) {
+    if (vec == 16) return OCF_DISPATCH(16);
+    if (vec == 8) return OCF_DISPATCH(8);
+  }
   return OCF_DISPATCH(0);
 #undef OCF_DISPATCH
+}
+
+int corr_fwd_bf16_vector(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
+                         const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st) {
+  ScopedProfile prof(st);
+  return corr_fwd_t<bf16, true>(f1, f2, flow, occ, out, B, C, H, W, d, fs, ac, st);
 }
 
 // which kernel a backward request gets (enum ocf_corr_bwd_variant); shared by the launcher and by ocf_corr_bwd_variant

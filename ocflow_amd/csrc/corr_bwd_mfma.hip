@@ -652,7 +652,7 @@ __device__ __forceinline__ void compute_g1(const Lane& L, const Item& t, const c
 
 template <bool OCC>
 __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const char* s_f, const char* s_g, const T4& dst, const T4& occ,
-                                           const T4& w2own, const T4& gocc, int C, int H, int W) {
+                                           const T4& w2own, const T4& gocc, int C, int H, int W, bool gocc_plain) {
   const int i = L.i, G = L.G, w = L.w;
   const int y = t.ty0 + w;
   f32x4 acc[2][2];
@@ -676,6 +676,19 @@ __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const c
       if (OCC && gocc.p)
         wv[s][nb] = *(const u32x2*)(w2own.p + (long)t.b * w2own.sb * 2 + (unsigned)((yc * (int)w2own.sh + xc * (int)w2own.sw + (c0 < C ? c0 : 0)) * 2));
     }
+  }
+  // the epilogue's ADDRESSES (this lane's two output pixels in dst and in d/docc) are formed here, into vector registers: their
+  // tensor descriptors (pointer + three strides each) then do not stay live in scalar registers across the unrolled matrix-core
+  // loop -- that cost nine SGPR spills in the <OCC = true> instantiation; the kernel has vector registers to spare (92 of 256)
+  char* dp[2];
+  float* gop[2];
+  const bool has_gocc = OCC && gocc.p != nullptr;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int x = t.tx0 + 16 * s + i;
+    dp[s] = dst.p + (long)t.b * dst.sb * 2 + (y * (int)dst.sh + x * (int)dst.sw + t.cbase + 4 * G) * 2;
+    gop[s] = has_gocc ? (float*)gocc.p + (long)t.b * gocc.sb + (y * (int)gocc.sh + x * (int)gocc.sw) : nullptr;
+    asm volatile("" : "+v"(dp[s]), "+v"(gop[s]));
   }
   unsigned gm[3];
 #pragma unroll
@@ -736,7 +749,7 @@ __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const c
 #pragma unroll
       for (int r = 0; r < 4; r++) v[r] = acc[s][nb][r] * invC;
       if (OCC) {
-        if (gocc.p && live) {  // the reference chain rounds the gradient w.r.t. (w2*occ) to the feature dtype before this product
+        if (has_gocc && live) {  // the reference chain rounds the gradient w.r.t. (w2*occ) to the feature dtype before this product
           const u32x2 w4 = wv[s][nb];
           part = __builtin_fmaf((float)(bf16)v[0], __builtin_bit_cast(float, w4[0] << 16), part);
           part = __builtin_fmaf((float)(bf16)v[1], __builtin_bit_cast(float, w4[0] & 0xffff0000u), part);
@@ -748,16 +761,15 @@ __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const c
       }
       if (live) {
         const bf16x2 lo2 = {(bf16)v[0], (bf16)v[1]}, hi2 = {(bf16)v[2], (bf16)v[3]};
-        *(u32x2*)(dst.p + (long)t.b * dst.sb * 2 + (y * (int)dst.sh + x * (int)dst.sw + c0) * 2) =
-            u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
+        *(u32x2*)(dp[s] + 32 * nb) = u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
       }
     }
-    if (OCC && gocc.p) {  // one fp32 atomic per pixel and channel block (the four lane groups reduced by shuffle)
+    if (has_gocc) {  // one fp32 atomic per pixel and channel block (the four lane groups reduced by shuffle)
       part += __shfl_xor(part, 16, 64);
       part += __shfl_xor(part, 32, 64);
       if (inimg && G == 0) {
-        float* go = (float*)gocc.p + (long)t.b * gocc.sb + (y * (int)gocc.sh + x * (int)gocc.sw);
-        if (gridDim.y == 1) *go = part;  // (one channel block: this lane owns the pixel's value; the launcher did not zero the tensor)
+        float* go = gop[s];
+        if (gocc_plain) *go = part;  // (one channel block: this lane owns the pixel's value; the launcher did not zero the tensor)
         else atomicAdd(go, part);
       }
     }
@@ -768,7 +780,7 @@ __device__ __forceinline__ void compute_g2(const Lane& L, const Item& t, const c
 // the two passes side by side (blockIdx.z), built from the phase functions above; the gradient of the g1 pass through LDS
 template <bool OCC>
 __global__ __launch_bounds__(256, 2) void corr_bwd_mfma_par_lds(T4 f1, T4 w2, T4 g, T4 g1, T4 g2, T4 occ, T4 gocc, int B, int C, int H, int W,
-                                                               int tiles_x, int tiles_y) {
+                                                               int tiles_x, int tiles_y, int ncb) {
   using namespace bp;
   constexpr int BYTES = (SF1 + GI_BYTES) > (SF2 + SG2) ? (SF1 + GI_BYTES) : (SF2 + SG2);
   __shared__ __attribute__((aligned(16))) char smem[BYTES];
@@ -777,11 +789,17 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_mfma_par_lds(T4 f1, T4 w2, T4
   L.w = __builtin_amdgcn_readfirstlane(L.tid >> 6);
   L.i = L.lane & 15; L.G = L.lane >> 4; L.q = L.i >> 2; L.p = L.i & 3;
   L.gsh = (int)g.sh; L.gsw = (int)g.sw;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // ONE grid dimension: logical id = (tile, channel block, pass), pass fastest, and logical ids are contiguous per XCD (xcd_remap): the
+  // 2 * ncb workgroups that stage the SAME grad_out tile are dispatched back to back on one XCD, so one of them brings it in from HBM
+  // and the others hit that XCD's L2.  (With the pass in blockIdx.z and the channel block in blockIdx.y they ran a whole grid apart:
+  // FETCH 1.95x the algorithmic bytes at level 2.)
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int pass = lid & 1, tc = lid >> 1;
+  const int tile = tc / ncb, cb = tc - tile * ncb;
   const int tpi = tiles_x * tiles_y;
   const int b = tile / tpi, trem = tile - b * tpi;
-  const Item t = {b, (trem / tiles_x) * TH, (trem % tiles_x) * TW, (int)blockIdx.y * 32};
-  if (blockIdx.z == 0) {
+  const Item t = {b, (trem / tiles_x) * TH, (trem % tiles_x) * TW, cb * 32};
+  if (pass == 0) {
     R1 r1;
     issue_g1(L, t, g, H, W, r1.gi);
     issue_other<OCC>(L, t, w2, occ, C, H, W, r1.sv, r1.so);
@@ -796,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_mfma_par_lds(T4 f1, T4 w2, T4
     commit_g2(L, t, smem + SF2, r2.va, r2.vb, H, W);
     commit_other<false, FP2>(L, t, smem, r2.sv, nullptr, C, H, W);
     __syncthreads();
-    compute_g2<OCC>(L, t, smem, smem + SF2, g2, occ, w2, gocc, C, H, W);
+    compute_g2<OCC>(L, t, smem, smem + SF2, g2, occ, w2, gocc, C, H, W, ncb == 1);
   }
 }
 
@@ -852,10 +870,14 @@ int corr_bwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_t
   if (par) {
     const dim3 grid2((unsigned)(B * tx * ty), (unsigned)((C + 31) / 32), 2u);
     const bool has_occ = occ && occ->data;
+    const int ncb = (C + 31) / 32;
+    const dim3 grid1d((unsigned)(B * tx * ty) * (unsigned)ncb * 2u);
     if (g1_lds && par_phase && has_occ)
-      lp.launch(true, corr_bwd_mfma_par_lds<true>, grid2, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
+      lp.launch(true, corr_bwd_mfma_par_lds<true>, grid1d, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty,
+                ncb);
     else if (g1_lds && par_phase)
-      lp.launch(true, corr_bwd_mfma_par_lds<false>, grid2, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
+      lp.launch(true, corr_bwd_mfma_par_lds<false>, grid1d, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty,
+                ncb);
     else if (g1_lds)
       lp.launch(true, corr_bwd_mfma_par<true>, grid2, block, 0, st, mk(f1), mk(w2), mk(g), mk(g1), mk(g2), mk(occ), mk(gocc), B, C, H, W, tx, ty);
     else

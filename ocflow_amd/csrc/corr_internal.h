@@ -10,6 +10,9 @@ int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_t
 // which kernel a bf16 forward request gets (enum ocf_corr_variant), without launching anything
 int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                           const ocf_tensor4* out, int B, int C, int H, int W, int d, int policy);
+// bf16 operands without 8-/16-byte channel runs (NCHW, odd strides): the vector-ALU kernel, element loads (corr.hip)
+int corr_fwd_bf16_vector(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
+                         const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, hipStream_t st);
 // the row / direct kernels (corr_rows.hip): dense channels_last bf16 output, d = 4, no in-kernel warp; 0 = not eligible
 int corr_rows_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* out, int C, int H, int W,
                       int d);

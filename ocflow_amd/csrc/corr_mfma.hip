@@ -70,7 +70,7 @@ enum { MOUT_GENERIC = 0, MOUT_CL_VEC = 1 };
 // global loads of the next tile (or channel block) are issued before the MFMAs of the current one, and the 16-byte output
 // stores of a tile drain while the next one is staged.
 template <int VEC, int MODE, int D, bool MULTI, int TH>
-__global__ __launch_bounds__(64 * (2 * D + 1), (MULTI || TH > 4) ? 3 : 5) void corr_fwd_mfma(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H,
+__global__ __launch_bounds__(64 * (2 * D + 1), (D == 1 || (MODE == 2 && D == 3)) ? 2 : ((MULTI || TH > 4) ? 3 : 5)) void corr_fwd_mfma(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H,
                                                                  int W, float fs, WarpGeom wg, int tiles_x, int tiles_y,
                                                                  int out_mode) {
   using namespace mf;
@@ -438,23 +438,39 @@ static int launch_mfma_th(const T4& f1, const T4& f2, const T4& flow, const T4& 
   return launch_status();
 }
 
+// widest channel run both operands give the staging loads: 16 bytes, 8 bytes, or 0 = element loads only (not a band-kernel request)
+static int band_vec(const ocf_tensor4* f1, const ocf_tensor4* f2, int C) {
+  int vec = min_vec(vec_width<bf16>(f1), vec_width<bf16>(f2));
+  // the vector staging paths have no per-channel tail: 16-byte units need C % 8 == 0, 8-byte halves C % 4 == 0
+  if (vec == 16 && C % 8 != 0) vec = 8;
+  if (vec == 8 && C % 4 != 0) vec = 0;
+  return vec;
+}
+
 // which band-GEMM instantiation a shape gets (also reported by ocf_corr_fwd_variant)
-static int band_variant(int B, int C, int H, int W) {
+// `warp`: with the bilinear gather of the second operand staged in-kernel the 4-row tile does not fit the register budget of a
+// nine-wave workgroup (168 VGPRs: it spilled 41-61 dwords): such requests get 2-row tiles at every size, 1-row tiles at d = 4 (the
+// 2-row tile still spilled 2-3 dwords there)
+static int band_variant(int B, int C, int H, int W, bool warp = false, int d = 0) {
   if (C <= 32) return OCF_CORR_BAND_TH8;
   const long tiles4 = (long)B * ((W + mf::TW - 1) / mf::TW) * ((H + TH_MULTI - 1) / TH_MULTI);
-  if (tiles4 * 4 < num_cus()) return OCF_CORR_BAND_MULTI_TH1;
-  if (tiles4 < num_cus()) return OCF_CORR_BAND_MULTI_TH2;
+  if (tiles4 * 4 < num_cus() || (warp && d == 4)) return OCF_CORR_BAND_MULTI_TH1;
+  if (tiles4 < num_cus() || warp) return OCF_CORR_BAND_MULTI_TH2;
   return OCF_CORR_BAND_MULTI_TH4;
 }
 
 template <int VEC, int MODE, int D>
 static int launch_mfma(const T4& f1, const T4& f2, const T4& flow, const T4& occ, const T4& out, int B, int C, int H, int W,
                        float fs, int ac, int out_mode, hipStream_t st) {
-  switch (band_variant(B, C, H, W)) {
+  switch (band_variant(B, C, H, W, MODE == 2, D)) {
     case OCF_CORR_BAND_TH8: return launch_mfma_th<VEC, MODE, D, false, TH_SINGLE>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
     case OCF_CORR_BAND_MULTI_TH1: return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_TINY>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
-    case OCF_CORR_BAND_MULTI_TH2: return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_SMALL>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
-    default: return launch_mfma_th<VEC, MODE, D, true, TH_MULTI>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+    case OCF_CORR_BAND_MULTI_TH2:
+      if constexpr (!(MODE == 2 && D == 4)) return launch_mfma_th<VEC, MODE, D, true, TH_MULTI_SMALL>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+      return OCF_EUNSUPPORTED;  // (not reached: band_variant)
+    default:
+      if constexpr (MODE != 2) return launch_mfma_th<VEC, MODE, D, true, TH_MULTI>(f1, f2, flow, occ, out, B, C, H, W, fs, ac, out_mode, st);
+      return OCF_EUNSUPPORTED;  // (not reached: band_variant)
   }
 }
 
@@ -472,7 +488,7 @@ static int launch_mfma_d(const T4& f1, const T4& f2, const T4& flow, const T4& o
 
 int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                           const ocf_tensor4* out, int B, int C, int H, int W, int d, int policy) {
-  if (policy == OCF_CORR_POLICY_BAND_ONLY) return band_variant(B, C, H, W);
+  if (policy == OCF_CORR_POLICY_BAND_ONLY) return band_vec(f1, f2, C) == 0 ? OCF_CORR_VECTOR_BF16 : band_variant(B, C, H, W, flow != nullptr, d);
   const bool wave_ok = policy != OCF_CORR_POLICY_NO_WAVE && corr_wave_eligible(f1, f2, flow, occ, out, B, C, H, W, d);
   if (policy == OCF_CORR_POLICY_WAVE && wave_ok) return OCF_CORR_WAVE;
   const int v = corr_rows_variant(f1, f2, flow, out, C, H, W, d);  // (0 when the output is not a dense cost volume; with a flow: C <= 64 only)
@@ -481,7 +497,8 @@ int corr_fwd_bf16_variant(const ocf_tensor4* f1, const ocf_tensor4* f2, const oc
   // no row kernel for this request: the wave kernel takes the small levels with the warp gathered in registers, and cost volumes
   // written into a wider buffer (any pixel pitch) that the band kernel would write element by element
   if (wave_ok && (C > 64 || !flow)) return OCF_CORR_WAVE;
-  return band_variant(B, C, H, W);
+  if (band_vec(f1, f2, C) == 0) return OCF_CORR_VECTOR_BF16;
+  return band_variant(B, C, H, W, flow != nullptr, d);
 }
 
 int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
@@ -491,10 +508,10 @@ int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_t
   if (variant <= OCF_CORR_DIRECT) return corr_fwd_bf16_rows(f1, f2, occ, out, B, C, H, W, st, flow, fs, ac);
   auto span = [&](const ocf_tensor4* t, long c) { return (labs(t->sh) * H + labs(t->sw) * W + labs(t->sc) * c) * 2L; };
   if (span(f1, C) >= (1L << 31) || span(f2, C) >= (1L << 31)) return OCF_EUNSUPPORTED;
-  int vec = min_vec(vec_width<bf16>(f1), vec_width<bf16>(f2));
-  // the vector staging paths have no per-channel tail: 16-byte units need C % 8 == 0, 8-byte halves C % 4 == 0
-  if (vec == 16 && C % 8 != 0) vec = 8;
-  if (vec == 8 && C % 4 != 0) vec = 0;
+  const int vec = band_vec(f1, f2, C);
+  // no 8-/16-byte channel runs (NCHW, odd strides, C % 4 != 0): the vector-ALU kernel with element loads.  The band kernel's
+  // element-load staging spilled up to 377 VGPR dwords at the register budget of its nine-wave workgroups and is gone.
+  if (vec == 0) return corr_fwd_bf16_vector(f1, f2, flow, occ, out, B, C, H, W, d, fs, ac, st);
   const int nk = (2 * d + 1) * (2 * d + 1);
   const bool dense = out->sc == 1 && out->sw == nk && ((uintptr_t)out->data % 16 == 0) && (out->sh * 2) % 16 == 0 &&
                      (out->sb * 2) % 16 == 0 && ((long)mf::TW * nk * 2) % 16 == 0;
@@ -508,8 +525,7 @@ int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_t
         : (occ ? launch_mfma_d<V, 1>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)        \
                : launch_mfma_d<V, 0>(a, bq, fl, oc, o, B, C, H, W, d, fs, ac, out_mode, st)))
   if (vec == 16) return OCF_DISPATCH(16);
-  if (vec == 8) return OCF_DISPATCH(8);
-  return OCF_DISPATCH(0);
+  return OCF_DISPATCH(8);
 #undef OCF_DISPATCH
 }
 

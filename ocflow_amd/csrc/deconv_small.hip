@@ -136,16 +136,14 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const Args a) {
 
 // gw[ci,co,ky,kx] += sum x[b,ci,iy,ix] * gy[b,co,2iy-1+ky,2ix-1+kx];  gbias[co] += sum gy.
 // lane = (pixel within a group of 64 / cil, input channel), cil = Ci rounded up to a power of two: a wave walks groups of 64 / cil
-// input pixels with 9 * CO accumulators per lane; partial sums are reduced over the pixel lanes by shuffles, over the block's 16 waves
-// by LDS float adds, and ONE atomic per (block, weight) lands in the fp32 gradient (a few hundred blocks: no same-address pile-up).
+// input pixels with 9 * CO accumulators per lane; partial sums are reduced over the pixel lanes by shuffles, over the block's waves
+// through per-wave LDS copies, and ONE atomic per (block, weight) lands in the fp32 gradient (a few hundred blocks: no same-address pile-up).
 template <int CO, int NW>
 __global__ __launch_bounds__(64 * NW) void deconv_bwd_weight_kernel(const Args a, int cil, int groups_per_wave, int opix_per_block) {
-  __shared__ float red[9 * CO * MAXCI];
-  __shared__ float redb[CO];
+  extern __shared__ float red[];  // [NW][9 CO Ci]: one copy per wave, summed by the block (LDS float atomics retire one wave
+  __shared__ float redb[NW][CO];  // instruction per ~120 cycles on this part: 18 of them x 16 waves were a third of the kernel)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 9 * CO * a.Ci; i += 64 * NW) red[i] = 0.f;
-  if (threadIdx.x < CO) redb[threadIdx.x] = 0.f;
-  __syncthreads();
+  const int n = 9 * CO * a.Ci;
   const int sub = lane / cil, ci = lane % cil, spw = 64 / cil;
   const int wv = blockIdx.x * NW + wid;
   const int npix = a.B * a.H * a.W;
@@ -197,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void deconv_bwd_weight_kernel(const Args a
     for (int co = 0; co < CO; co++) {
       float v = acc[t][co];
       for (int o = 32; o >= cil; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (sub == 0 && ci < a.Ci) atomicAdd(&red[(ci * CO + co) * 9 + t], v);  // (LDS float add: 16 waves into one copy)
+      if (sub == 0 && ci < a.Ci) red[wid * n + (ci * CO + co) * 9 + t] = v;
     }
   // bias gradient: the block's share of the output pixels, lanes over pixels
   if (a.gbias) {
@@ -213,17 +211,23 @@ __global__ __launch_bounds__(64 * NW) void deconv_bwd_weight_kernel(const Args a
 #pragma unroll
     for (int co = 0; co < CO; co++) {
       const float t = wave_sum(s[co]);
-      if (lane == 0) atomicAdd(&redb[co], t);
+      if (lane == 0) redb[wid][co] = t;
     }
   }
   __syncthreads();
-  const int n = 9 * CO * a.Ci;
   for (int i = threadIdx.x; i < n; i += 64 * NW) {
-    const float v = red[i];
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) v += red[w * n + i];
     const int t = i % 9, r = i / 9, co = r % CO, c = r / CO;  // (consecutive lanes -> consecutive floats of a dense weight gradient)
     atomicAdd(a.gw + c * a.gsi + co * a.gso + (t / 3) * a.gsy + (t % 3) * a.gsx, v);
   }
-  if (a.gbias && threadIdx.x < CO) atomicAdd(a.gbias + threadIdx.x, redb[threadIdx.x]);
+  if (a.gbias && threadIdx.x < CO) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) v += redb[w][threadIdx.x];
+    atomicAdd(a.gbias + threadIdx.x, v);
+  }
 }
 }  // namespace dcv
 }  // namespace ocf
@@ -313,7 +317,8 @@ extern "C" int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t 
     const long groups = (npix + spw - 1) / spw;
     // ~2 pixel groups per wave (the loop is load-latency bound: many waves); every block ends in 9 * Co * Ci same-address atomics
     // (measured ~22 ns per block), so large maps use 16-wave blocks, at most 256 of them
-    const int nw = groups >= 2 * 16 * 128 ? 16 : 4;
+    const int nred = 9 * Co * Ci;  // floats of one wave's partial sums (16 copies must fit 48 KB of LDS)
+    const int nw = (groups >= 2 * 16 * 128 && nred * 16 * 4 <= 48 * 1024) ? 16 : 4;
     long blocks = (groups + nw * 2 - 1) / (nw * 2);
     if (blocks < nop / (512 * nw)) blocks = nop / (512 * nw);  // (the bias sum: <= 8 output pixels per thread)
     if (blocks > 256) blocks = 256;
@@ -322,8 +327,8 @@ extern "C" int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t 
     const dim3 grid((unsigned)blocks);
 #define OCF_DCV_WG(CO)                                                                                                              \
   case CO:                                                                                                                          \
-    if (nw == 16) lp.launch(true, dcv::deconv_bwd_weight_kernel<CO, 16>, grid, dim3(1024), 0, (hipStream_t)stream, a, cil, gpw, opb); \
-    else lp.launch(true, dcv::deconv_bwd_weight_kernel<CO, 4>, grid, dim3(256), 0, (hipStream_t)stream, a, cil, gpw, opb);            \
+    if (nw == 16) lp.launch(true, dcv::deconv_bwd_weight_kernel<CO, 16>, grid, dim3(1024), (size_t)nred * 64, (hipStream_t)stream, a, cil, gpw, opb); \
+    else lp.launch(true, dcv::deconv_bwd_weight_kernel<CO, 4>, grid, dim3(256), (size_t)nred * 16, (hipStream_t)stream, a, cil, gpw, opb);            \
     break;
     switch (Co) { OCF_DCV_WG(1) OCF_DCV_WG(2) OCF_DCV_WG(3) OCF_DCV_WG(4) }
 #undef OCF_DCV_WG

@@ -660,6 +660,209 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(T4 img, T4 flow, T4 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// SMALL maps (H * W <= WSMALL_PX: the three coarsest pyramid levels, 28 x 64 / 14 x 32 / 7 x 16): the whole backward in ONE launch.
+// At these sizes the three-launch binned form is launch-floor bound (5.3 + 9.9 + 5.8 us at 8 x 96 x 28 x 64 for 7.9 MB) and the scatter
+// kernel needs a zero-fill of grad_img and of grad_flow beside it.  Here a whole IMAGE is the gather window: a workgroup that owns a
+// 32 x 8 destination tile x 32 channels lists the taps of ALL H * W sources of its image (no "near" test, no bins, no overflow, nothing
+// far: no atomics on global memory and no zero-fill), then gathers as warp_bwd_gather_kernel does.  The per-source half (grad_flow) is
+// done by further workgroups of the SAME grid (blockIdx.x >= nA), lanes = (source pixel, 16-byte unit) as in warp_bwd_flow_kernel.
+// grad_img is written in OT: fp32 (the ABI's default) or the feature dtype (policy bit OCF_WARP_BWD_GIMG_NATIVE: saves the cast).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int WSMALL_PX = 1792;  // 16 bytes of dynamic LDS per source (28 KB), list slots addressed by 16-bit links
+
+template <typename T, typename OT, int VEC, bool FULL>
+__global__ __launch_bounds__(256) void warp_bwd_small_kernel(T4 img, T4 flow, T4 gout, T4 gimg, T4 gflow, int B, int C, int H, int W, float fs,
+                                                             WarpGeom wg, int tiles_x, int tiles_y, int ncb, int nA, long totalB, int upp,
+                                                             int upp_pad) {
+  constexpr int ES = (int)sizeof(T), U = Unit<T>::U, NU = 32 / U;
+  extern __shared__ unsigned s_dyn[];  // [H W] (wx1, wy1) of every source (float2) | [4 H W] next entry of slot 4 i + tap (u16)
+  __shared__ unsigned s_head[WT_W * WT_H];
+  const int tid = threadIdx.x;
+  const int HW = H * W;
+  if ((int)blockIdx.x < nA) {
+    if (!gimg.p) return;
+    float* s_wxy = (float*)s_dyn;
+    unsigned short* s_nx = (unsigned short*)(s_dyn + 2 * HW);
+    const int tc = blockIdx.x, tile = tc / ncb, c0 = (tc - tile * ncb) * 32;
+    const int tpi = tiles_x * tiles_y;
+    const int b = tile / tpi, trem = tile - b * tpi;
+    const int ty0 = (trem / tiles_x) * WT_H, tx0 = (trem % tiles_x) * WT_W;
+    const float* fl = (const float*)flow.p + (long)b * flow.sb;
+    s_head[tid] = WL_END;
+    // this thread's <= 7 sources: ALL flow loads first (one round trip), then the list pushes
+    constexpr int SPT = WSMALL_PX / 256;
+    float fu[SPT], fv[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+      const int i = tid + 256 * k, ic = i < HW ? i : 0;
+      const int sy = ic / W, sx = ic - sy * W;
+      const long fo = (long)sy * flow.sh + (long)sx * flow.sw;
+      fu[k] = fl[fo];
+      fv[k] = fl[fo + flow.sc];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+      const int i = tid + 256 * k;
+      if (i < HW) {
+        const int sy = i / W, sx = i - sy * W;
+        const Bilin s = bilin_setup(((float)sx + fu[k] * fs) * wg.ax + wg.bx, ((float)sy + fv[k] * fs) * wg.ay + wg.by, H, W);
+        unsigned prev[4];
+        bool push[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int ddx = q & 1, ddy = q >> 1;
+          const int lx = s.x0 + ddx - tx0, ly = s.y0 + ddy - ty0;
+          push[q] = ((ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0)) && lx >= 0 && lx < WT_W && ly >= 0 && ly < WT_H;
+          prev[q] = WL_END;
+          if (push[q]) prev[q] = atomicExch(&s_head[ly * WT_W + lx], (unsigned)(4 * i + q));
+        }
+        if (push[0] | push[1] | push[2] | push[3]) *(float2*)(s_wxy + 2 * i) = float2{s.wx1, s.wy1};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (push[q]) s_nx[4 * i + q] = (unsigned short)prev[q];
+      }
+    }
+    __syncthreads();
+    // gather: EPR list entries per round (the walk through LDS is cheap, the grad_out rows are L2 round trips: a pixel with the usual
+    // ~4 contributions finishes in one round); rows are kept raw (16-byte units) until the multiply-add
+    constexpr int EPR = 4;
+    const char* gb = gout.p + (long)b * gout.sb * ES;
+    float acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc[k] = 0.f;
+    auto src_row = [&](unsigned e) __attribute__((always_inline)) {
+      const int i = (int)(e >> 2);
+      const int sy = i / W, sx = i - sy * W;
+      return gb + ((long)sy * gout.sh + (long)sx * gout.sw + c0) * ES;
+    };
+    const bool fullcb = VEC == 16 && c0 + 32 <= C;  // (workgroup-uniform) whole units only: plain vector loads, no tail branch
+    const int nu_live = (min(C - c0, 32) + U - 1) / U;  // units of this channel block that hold channels at all
+    T4 gv = gout;
+    for (unsigned cur = s_head[tid]; cur != WL_END;) {
+      unsigned e[EPR];
+      float wgt[EPR];
+      bool has[EPR];
+      e[0] = cur;
+      has[0] = true;
+      unsigned nxt = s_nx[cur];  // (16-bit links: WL_END = 0xffff ends a list)
+#pragma unroll
+      for (int q = 1; q < EPR; q++) {
+        has[q] = nxt != WL_END;
+        e[q] = has[q] ? nxt : e[q - 1];  // (a finished list re-reads its last row with weight 0)
+        if (has[q]) nxt = s_nx[nxt];
+      }
+#pragma unroll
+      for (int q = 0; q < EPR; q++) {  // the tap's weight from its source's fractional sample position
+        const float2 wxy = *(const float2*)(s_wxy + 2 * (e[q] >> 2));
+        const float w = ((e[q] & 1) ? wxy.x : 1.f - wxy.x) * ((e[q] & 2) ? wxy.y : 1.f - wxy.y);
+        wgt[q] = has[q] ? w : 0.f;
+      }
+      if (fullcb) {
+        u32x4 raw[EPR][NU];
+#pragma unroll
+        for (int q = 0; q < EPR; q++) {
+          const char* r = src_row(e[q]);
+#pragma unroll
+          for (int u = 0; u < NU; u++) raw[q][u] = *(const u32x4*)(r + u * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < EPR; q++)
+#pragma unroll
+          for (int u = 0; u < NU; u++) {
+            float f[U];
+            unit_to_f<T>(raw[q][u], f);
+#pragma unroll
+            for (int k = 0; k < U; k++) acc[u * U + k] = __builtin_fmaf(wgt[q], f[k], acc[u * U + k]);
+          }
+      } else {
+        for (int q = 0; q < EPR; q++) {  // (partial channel block / 8-byte pixels: the generic unit loader, live units only)
+          if (!has[q]) break;
+          gv.p = (char*)src_row(e[q]);
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+            if (u < nu_live) {
+              float f[U];
+              load_unit_sel<T, VEC, false>(gv, 0, u * U, C - c0, f);
+#pragma unroll
+              for (int k = 0; k < U; k++) acc[u * U + k] = __builtin_fmaf(wgt[q], f[k], acc[u * U + k]);
+            }
+        }
+      }
+      cur = nxt;  // the entry after the last one of this round, or the end
+    }
+    const int y = ty0 + tid / WT_W, x = tx0 + (tid % WT_W);
+    if (y < H && x < W) {
+      OT* gi = (OT*)gimg.p + (long)b * gimg.sb + (long)y * gimg.sh + (long)x * gimg.sw + c0;
+      const bool vecst = c0 + 32 <= C && ((gimg.sw | gimg.sh | gimg.sb) & (16 / (int)sizeof(OT) - 1)) == 0 && ((uintptr_t)gimg.p & 15) == 0;
+      if (vecst && sizeof(OT) == 4) {
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) *(f32x4*)((float*)gi + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+      } else if (vecst) {
+#pragma unroll
+        for (int k = 0; k < 32; k += 8) {
+          bf16x8 v;
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = (bf16)acc[k + j];
+          *(bf16x8*)((bf16*)gi + k) = v;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+          if (c0 + k < C) gi[k] = (OT)acc[k];
+      }
+    }
+    return;
+  }
+  // ---- per-source half: grad_flow (plain stores)
+  if (!gflow.p) return;
+  const float* fl = (const float*)flow.p;
+  const long idx = ((long)blockIdx.x - nA) * 256 + tid;
+  const bool live = idx < totalB;
+  const long pix = live ? idx / upp_pad : 0;
+  const int un = live ? (int)(idx - pix * upp_pad) : 0;
+  const int c0 = un * U;
+  const bool on = live && un < upp;
+  const int x = pix % W;
+  const long r = pix / W;
+  const int y = r % H, b = r / H;
+  float gx = 0.f, gy = 0.f;
+  const long fo = (long)b * flow.sb + (long)y * flow.sh + (long)x * flow.sw;
+  const float uu = fl[fo] * fs, vv = fl[fo + flow.sc] * fs;
+  const Bilin s = bilin_setup(((float)x + uu) * wg.ax + wg.bx, ((float)y + vv) * wg.ay + wg.by, H, W);
+  if (on) {
+    float g[U], v[4][U];
+    bool ok[4];
+    load_unit_sel<T, VEC, FULL>(gout, (long)b * gout.sb + (long)y * gout.sh + (long)x * gout.sw, c0, C, g);
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int ddx = n & 1, ddy = n >> 1;
+      ok[n] = (ddx ? s.vx1 : s.vx0) & (ddy ? s.vy1 : s.vy0);
+      const int xc = min(max(s.x0 + ddx, 0), W - 1), yc = min(max(s.y0 + ddy, 0), H - 1);
+      load_unit_sel<T, VEC, FULL>(img, (long)b * img.sb + (long)yc * img.sh + (long)xc * img.sw, c0, C, v[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+      for (int k = 0; k < U; k++) v[n][k] = ok[n] ? v[n][k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      gx = __builtin_fmaf(g[k], (1.f - s.wy1) * (v[1][k] - v[0][k]) + s.wy1 * (v[3][k] - v[2][k]), gx);
+      gy = __builtin_fmaf(g[k], (1.f - s.wx1) * (v[2][k] - v[0][k]) + s.wx1 * (v[3][k] - v[1][k]), gy);
+    }
+  }
+  for (int o = upp_pad >> 1; o > 0; o >>= 1) {
+    gx += __shfl_xor(gx, o, 64);
+    gy += __shfl_xor(gy, o, 64);
+  }
+  if (live && un == 0) {
+    float* gf = (float*)gflow.p + (long)b * gflow.sb + (long)y * gflow.sh + (long)x * gflow.sw;
+    gf[0] = gx * wg.ax * fs;
+    gf[gflow.sc] = gy * wg.ay * fs;
+  }
+}
+
 template <typename T> static bool wvec_ok(const ocf_tensor4* t) {
   constexpr int U = Unit<T>::U;
   return t->sc == 1 && ((uintptr_t)t->data % 16 == 0) && t->sw % U == 0 && t->sh % U == 0 && t->sb % U == 0;
@@ -707,8 +910,9 @@ static bool warp_bwd_use_gather(const ocf_tensor4* img, const ocf_tensor4* gout,
   const long npix = (long)B * H * W;
   const bool cl = img->sc == 1 && gout->sc == 1 && gimg && gimg->sc == 1 && C >= 4;
   const bool gf_dense = !gflow || (gflow->sw == 1 && gflow->sh == W && gflow->sc == (long)H * W && gflow->sb == 2L * H * W);
+  policy &= 0xff;
   if (!cl || !gf_dense || npix * C >= (1L << 40) || policy == OCF_WARP_BWD_POLICY_SCATTER ||
-      (policy == OCF_WARP_BWD_POLICY_AUTO && npix * C < (1L << 20)) || (long)H * W >= (1L << 31))
+      ((policy == OCF_WARP_BWD_POLICY_AUTO || policy == OCF_WARP_BWD_POLICY_SMALL) && npix * C < (1L << 20)) || (long)H * W >= (1L << 31))
     return false;
   const int vec = min_vec(vec_width<T>(img), vec_width<T>(gout));
   const int upp = (C + Unit<T>::U - 1) / Unit<T>::U;
@@ -718,6 +922,16 @@ static bool warp_bwd_use_gather(const ocf_tensor4* img, const ocf_tensor4* gout,
   int upp_pad = 1;
   while (upp_pad < upp) upp_pad *= 2;
   return tiles <= 0x7fffffffL && (npix * upp_pad + 255) / 256 <= 0x7fffffffL;
+}
+
+// the single-launch small-map kernel: same layout requirements as the gather pair, whole image within the LDS list budget
+template <typename T>
+static bool warp_bwd_use_small(const ocf_tensor4* img, const ocf_tensor4* gout, const ocf_tensor4* gimg, const ocf_tensor4* gflow, int B, int C,
+                               int H, int W, int policy) {
+  const int pol = policy & 0xff;
+  if (pol != OCF_WARP_BWD_POLICY_AUTO && pol != OCF_WARP_BWD_POLICY_SMALL) return false;
+  if ((long)H * W > WSMALL_PX || !gimg) return false;
+  return warp_bwd_use_gather<T>(img, gout, gimg, gflow, B, C, H, W, OCF_WARP_BWD_POLICY_GATHER);
 }
 
 // workspace of the binned path: counters padded to a multiple of 64 entries (bins stay 256-byte aligned)
@@ -738,6 +952,31 @@ static int warp_bwd_t(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf
     const long blocks = (total + 255) / 256;
     const int vec = min_vec(vec_width<T>(img), vec_width<T>(gout));
     const int upp = (C + Unit<T>::U - 1) / Unit<T>::U;
+    const bool native = (policy & OCF_WARP_BWD_GIMG_NATIVE) != 0;
+    policy &= 0xff;
+    if (warp_bwd_use_small<T>(img, gout, gimg, gflow, B, C, H, W, policy)) {
+      const int tx = (W + WT_W - 1) / WT_W, ty = (H + WT_H - 1) / WT_H, ncb = (C + 31) / 32;
+      const long nA = (long)B * tx * ty * ncb;
+      int upp_pad = 1;
+      while (upp_pad < upp) upp_pad *= 2;
+      const long totalb = gflow ? npix * upp_pad : 0, nB = (totalb + 255) / 256;
+      if (nA + nB > 0x7fffffffL) return OCF_EUNSUPPORTED;
+      const dim3 grid((unsigned)(nA + nB));
+      const size_t lds = (size_t)H * W * 16;  // 8 bytes of sample position + 4 x 2 bytes of list links per source: 28 KB at 28 x 64
+      const bool full = vec == 16 && C % Unit<T>::U == 0;
+      LaunchProf lp;
+#define OCF_WSMALL(OT, V, F)                                                                                                              \
+  lp.launch(true, warp_bwd_small_kernel<T, OT, V, F>, grid, dim3(256), lds, st, mk(img), mk(flow), mk(gout), mk(gimg), mk(gflow), B, C, H, W, \
+            fs, wg, tx, ty, ncb, (int)nA, totalb, upp, upp_pad)
+      if (native) {
+        if (full) OCF_WSMALL(T, 16, true); else if (vec == 16) OCF_WSMALL(T, 16, false); else OCF_WSMALL(T, 8, false);
+      } else {
+        if (full) OCF_WSMALL(float, 16, true); else if (vec == 16) OCF_WSMALL(float, 16, false); else OCF_WSMALL(float, 8, false);
+      }
+#undef OCF_WSMALL
+      return launch_status();
+    }
+    if (native) return OCF_EINVAL;  // (only the plan that answered "native grad_img allowed" may be given one)
     if (warp_bwd_use_gather<T>(img, gout, gimg, gflow, B, C, H, W, policy)) {
       // gather kernel for the near sources (plain stores: writes the whole of grad_img, no zero-fill needed), then the per-source
       // kernel: grad_flow (plain stores) + float atomics for the far sources
@@ -833,12 +1072,18 @@ extern "C" int ocf_warp_bwd_plan(const ocf_tensor4* img, const ocf_tensor4* gout
                                  int H, int W, int dtype, int policy) {
   if (!img || !gout || !img->data || !gout->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
-  if (policy < OCF_WARP_BWD_POLICY_AUTO || policy > OCF_WARP_BWD_POLICY_BINNED) return OCF_EINVAL;
-  bool gather = false;
-  if (dtype == OCF_F32) gather = ocf::warp_bwd_use_gather<float>(img, gout, gimg, gflow, B, C, H, W, policy);
-  else if (dtype == OCF_BF16) gather = ocf::warp_bwd_use_gather<ocf::bf16>(img, gout, gimg, gflow, B, C, H, W, policy);
-  else return OCF_EINVAL;
-  return gather ? 0 : 1;  // bit 0: grad_img must be zeroed by the caller (scatter kernel: float atomics)
+  if ((policy & ~OCF_WARP_BWD_GIMG_NATIVE) < OCF_WARP_BWD_POLICY_AUTO || (policy & ~OCF_WARP_BWD_GIMG_NATIVE) > OCF_WARP_BWD_POLICY_SMALL) return OCF_EINVAL;
+  bool gather = false, small = false;
+  if (dtype == OCF_F32) {
+    small = ocf::warp_bwd_use_small<float>(img, gout, gimg, gflow, B, C, H, W, policy);
+    gather = small || ocf::warp_bwd_use_gather<float>(img, gout, gimg, gflow, B, C, H, W, policy);
+  } else if (dtype == OCF_BF16) {
+    small = ocf::warp_bwd_use_small<ocf::bf16>(img, gout, gimg, gflow, B, C, H, W, policy);
+    gather = small || ocf::warp_bwd_use_gather<ocf::bf16>(img, gout, gimg, gflow, B, C, H, W, policy);
+  } else return OCF_EINVAL;
+  // bit 0: grad_img must be zeroed by the caller (scatter kernel: float atomics); bit 1: grad_img may be given in `dtype` instead of fp32
+  // (pass OCF_WARP_BWD_GIMG_NATIVE with the policy then): the single-launch small-map kernel writes it with plain stores
+  return (gather ? 0 : 1) | (small ? 2 : 0);
 }
 
 extern "C" int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, const ocf_tensor4* gout, const ocf_tensor4* gimg,
@@ -848,7 +1093,7 @@ extern "C" int ocf_warp_bwd(const ocf_tensor4* img, const ocf_tensor4* flow, con
   if (!img || !flow || !gout || !img->data || !flow->data || !gout->data) return OCF_EINVAL;
   if ((gimg && !gimg->data) || (gflow && !gflow->data) || (!gimg && !gflow)) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
-  if (policy < OCF_WARP_BWD_POLICY_AUTO || policy > OCF_WARP_BWD_POLICY_BINNED) return OCF_EINVAL;
+  if ((policy & ~OCF_WARP_BWD_GIMG_NATIVE) < OCF_WARP_BWD_POLICY_AUTO || (policy & ~OCF_WARP_BWD_GIMG_NATIVE) > OCF_WARP_BWD_POLICY_SMALL) return OCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OCF_F32) return ocf::warp_bwd_t<float>(img, flow, gout, gimg, gflow, workspace, B, C, H, W, flow_scale, align_corners, policy, st);
   if (dtype == OCF_BF16)

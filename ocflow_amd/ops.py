@@ -217,14 +217,20 @@ def _warp_bwd_raw(img, flow, gout, flow_scale, align_corners, need_img, need_flo
     # the scatter kernel accumulates into grad_img with float atomics (zero it first); the gather kernels overwrite it.  Plan and
     # launch receive the SAME policy value and evaluate one decision function in the library.
     policy = POLICY.warp_bwd if policy is None else policy
-    zero_first = gimg is not None and _lib.load().ocf_warp_bwd_plan(_t4(img), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W,
-                                                                    _dtype_code(img), policy) != 0
+    plan = 0 if gimg is None else _lib.load().ocf_warp_bwd_plan(_t4(img), _t4(gout), _t4(gimg), _t4(gflow), B, C_, H, W, _dtype_code(img), policy)
+    if plan < 0:
+        _lib.check(plan, "ocf_warp_bwd_plan")
+    zero_first = bool(plan & 1)
     if zero_first:
         gimg.zero_()
+    if plan & 2 and img.dtype != torch.float32:
+        # the single-launch small-map kernel writes grad_img with plain stores: take it in the feature dtype (no cast launch afterwards)
+        gimg = _empty_like_layout(img, img.shape, img.dtype)
+        policy |= _lib.WARP_BWD_GIMG_NATIVE
 
-    # scratch of the binned gather (only allocated where the gather path is taken at all: plan == 0)
+    # scratch of the binned gather (only allocated where that path is taken: plan == 0)
     ws = None
-    if gimg is not None and policy in (_lib.WARP_BWD_AUTO, _lib.WARP_BWD_BINNED) and not zero_first:
+    if gimg is not None and policy in (_lib.WARP_BWD_AUTO, _lib.WARP_BWD_BINNED) and plan == 0:
         ws = _workspace(_lib.load().ocf_warp_bwd_workspace_bytes, B, C_, H, W, device=img.device)
 
     def launch():

@@ -1,7 +1,8 @@
 set -o pipefail
 OUT=gpurun_out; mkdir -p $OUT
-for v in auto 0; do
-OCFLOW_PAD_PWC=$v python bench.py --config cfg3 --steps 10 --warmup 3 --cpu-seconds 0 > $OUT/r4v_cfg3_$v.json 2> $OUT/r4v_cfg3_$v.err || { tail -20 $OUT/r4v_cfg3_$v.err; exit 1; }
-cut -c1-300 $OUT/r4v_cfg3_$v.json
-done
-timeout -k 10 600 python -m pytest tests/test_configs_gpu.py tests/test_models_gpu.py -q -m gpu -k "pwc or config2 or pwoc" 2>&1 | grep -v "MIOpen(HIP)" | tail -5
+timeout -k 10 600 python -m pytest tests/test_hip_parity.py tests/test_bench_shapes_gpu.py -q -k "warp" > $OUT/r4v_warp.txt 2>&1
+rc=$?
+grep -v "MIOpen(HIP): Warning" $OUT/r4v_warp.txt | grep -E "FAILED|passed|failed" | head -30
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 tools/kbench 8 bf16 cl > $OUT/r4v_kbench.txt 2>&1 || { tail -5 $OUT/r4v_kbench.txt; exit 1; }
+grep -E "^ *[0-9]+x" $OUT/r4v_kbench.txt

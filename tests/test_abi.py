@@ -58,8 +58,8 @@ def test_argument_validation_without_device():
     assert lib.ocf_corr_fwd_variant(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 4, 1, 9) == -1
     assert lib.ocf_corr_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 4, 0, 3, None) == -1
     assert lib.ocf_corr_bwd_variant(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 4, 0, 3) == -1
-    assert lib.ocf_warp_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 1.0, 0, 0, 4, None, None) == -1
-    assert lib.ocf_warp_bwd_plan(C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 0, 4) == -1
+    assert lib.ocf_warp_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 1.0, 0, 0, 5, None, None) == -1
+    assert lib.ocf_warp_bwd_plan(C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 0, 5) == -1
     nbytes = C.c_int64(0)
     assert lib.ocf_warp_bwd_workspace_bytes(8, 32, 109, 256, C.byref(nbytes)) == 0 and nbytes.value > 8 * 109 * 256 * 32
     assert lib.ocf_range_map(C.byref(good), C.c_void_p(16), None, 1, 1, 1, 3, None) == -1

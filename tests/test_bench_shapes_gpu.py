@@ -381,3 +381,38 @@ def test_warp_backward_gather_kernels_small_shapes(ops, lib, shape, dtype, ac, f
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert_close(gi, gir, tol * 5, tol, "grad img")
     assert_close(gf, gfr, tol * 5, tol, "grad flow", outliers=2e-3)
+
+
+@pytest.mark.parametrize("shape", [(8, 96, 28, 64), (8, 128, 14, 32), (8, 196, 7, 16), (2, 40, 23, 45), (3, 8, 9, 33), (1, 64, 5, 130)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ac", [False, True])
+def test_warp_backward_single_launch_small_maps(ops, lib, shape, dtype, ac):
+    """maps of at most 1792 pixels per image (the three coarsest pyramid levels of the benchmark and odd small shapes): ONE launch, a whole
+    image as the gather window -- the plan says so (bit 1, no zero-fill), grad_img comes back in the feature dtype without a cast launch,
+    large displacements and sources leaving the image included; against autograd of the oracle's grid_sample warp, and the same values as
+    the scatter kernel up to float summation order"""
+    Bb, Cc, h, w = shape
+    gen = torch.Generator().manual_seed(sum(shape) + int(ac))
+    img = torch.randn(shape, generator=gen).to(dtype)
+    flow = torch.randn((Bb, 2, h, w), generator=gen) * 5.0
+    cot = torch.randn(shape, generator=gen).to(dtype)
+    a, f = img.float().requires_grad_(), flow.clone().requires_grad_()
+    gir, gfr = torch.autograd.grad(O.warp(a, f, ac), (a, f), cot.float())
+    x, fl = cl(img).requires_grad_(), flow.to(DEV).requires_grad_()
+    from ocflow_amd.ops import _t4, _dtype_code
+    gi32 = torch.empty(shape, device=DEV, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    gfl = torch.empty((Bb, 2, h, w), device=DEV, dtype=torch.float32)
+    plan = lib.load().ocf_warp_bwd_plan(_t4(x.detach()), _t4(cl(cot)), _t4(gi32), _t4(gfl), Bb, Cc, h, w, _dtype_code(x), lib.WARP_BWD_AUTO)
+    assert plan == 2, plan
+    gi, gf = torch.autograd.grad(ops.warp(x, fl, ac), (x, fl), cl(cot))
+    assert gi.dtype == dtype
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_close(gi, gir, tol * 5, tol, "grad img")
+    assert_close(gf, gfr, tol * 5, tol, "grad flow", outliers=2e-3)
+    gi2, gf2 = torch.autograd.grad(ops.warp(x, fl, ac), (x, fl), cl(cot))
+    assert torch.equal(gf, gf2)  # (grad_img: the order of a pixel's list, hence of its sum, is the order the LDS exchanges landed in)
+    assert_close(gi2, gi.float(), tol * 5, tol, "grad img, second run")
+    with ops.kernel_policy(warp_bwd=lib.WARP_BWD_SCATTER):
+        gis, gfs = torch.autograd.grad(ops.warp(x, fl, ac), (x, fl), cl(cot))
+    assert_close(gi, gis.float(), tol * 5, tol, "grad img vs scatter kernel")
+    assert_close(gf, gfs, 1e-4, 2e-5, "grad flow vs scatter kernel", outliers=2e-3)

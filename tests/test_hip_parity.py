@@ -141,11 +141,16 @@ def test_corr_bf16_matrix_core_modes(ops, shape, d, mode, layout, monkeypatch):
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     close(out, ref, 2e-2)
     if flow is not None and layout != "nchw":
-        # the default two-launch form (warp kernel, then the correlation kernel) produces the same cost volume bit for bit:
-        # both round the gathered operand to bf16 before the contraction
+        # the default two-launch form (warp kernel, then the correlation kernel) produces the same cost volume bit for bit on the
+        # matrix-core kernels: both round the gathered operand to bf16 before the contraction.  The unaligned channel slice ("view":
+        # element loads only) is served by the vector-ALU kernel in the fused form (OCF_CORR_VECTOR_BF16) and by a matrix-core kernel
+        # after the separate warp: same operands, another summation order -- equal within the output's bf16 rounding
         monkeypatch.setattr(ops, "_FUSED_WARP", "0")
         out2 = ops.corr_warp(lay(f1), lay(f2), flow.to(DEV), None if occ is None else occ.to(DEV), d, 1.25, False)
-        assert torch.equal(out2, out)
+        if layout == "cl":
+            assert torch.equal(out2, out)
+        else:
+            close(out2, out.float(), 1e-2)
 
 
 def test_corr_bf16_output_into_concat_buffer(ops):
