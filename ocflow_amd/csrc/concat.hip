@@ -3,10 +3,14 @@
 // flow_net.py:104-121, flow_occ_net.py:153-176 with the alignment channels of `cat_aligned` (models/networks/_epilogue.py) written in the
 // same pass.  The framework's cat falls to its generic gather kernel for these operands (views of a paired batch, 81- and 2-channel
 // parts: 4 launches of ~68 us at 8 x 109 x 256) and needs a separate zero block for the padding.
-// Thread = one 16-byte unit (8 channels) of one output pixel: a unit inside ONE part is one 16-byte load -- at whatever 2-byte
-// alignment the part's pixels have (the 162-byte pixels of the cost volume: gfx950 serves unaligned global loads; the first version
-// gathered those units 2 bytes at a time and took 62 us for the 128-channel decoder input of 8 x 109 x 256, against 17 us for an
-// all-aligned concatenation of 96 channels) -- and only a unit that straddles a part boundary is gathered element by element.
+// A workgroup owns NP = 32 consecutive pixels: it assembles their output rows (NP x Cout bf16, <= 36 KB) in LDS and writes them out as
+// one contiguous run of aligned 16-byte stores.  A DENSE part (pixel pitch == its channel count: the cost volume, the up-sampled flow,
+// ...) is then a contiguous byte range too -- NP x C_k x 2 bytes, 16-byte aligned because NP = 32 -- and is streamed in with aligned
+// 16-byte loads whatever C_k is; the regrouping into output pixels happens in the LDS writes (one ds_write_b128 when part and offset are
+// 8-channel aligned, eight ds_write_b16 otherwise).  Parts with a wider pitch (channel slices) are read row by row.  The first version,
+// one thread per output unit, read the 162-byte cost-volume pixels with 16-byte loads at 2-byte alignment and gathered every unit that
+// straddles two parts element by element: 69 us for the 128-channel decoder input of 8 x 109 x 256 and 32 us for the 96-channel one,
+// against 12 us for an all-aligned concatenation of the same size (profiles/r4_bench_concat.txt).
 #include "ocf_common.h"
 
 namespace ocf {
@@ -23,34 +27,69 @@ struct Args {
   long npix;
 };
 
+constexpr int NP = 32;
+
 __global__ __launch_bounds__(256) void concat_kernel(const Args a) {
-  const int G = a.Cout >> 3;
-  const long total = a.npix * G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long pix = i / G;
-    const int ch = (int)(i - pix * G) << 3;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    int k = 0;
+  extern __shared__ u32x4 s_tile[];  // [NP][Cout] bf16
+  unsigned short* s_e = (unsigned short*)s_tile;
+  const int tid = threadIdx.x;
+  const long pix0 = (long)blockIdx.x * NP;
+  const int np = a.npix - pix0 < NP ? (int)(a.npix - pix0) : NP;
+  const int G = a.Cout >> 3, ctot = a.c0[a.n];
+  // alignment channels: zero the tail units of every pixel row (the parts overwrite what they cover)
+  if (ctot < a.Cout) {
+    const int g0 = ctot >> 3, ng = G - g0;
+    for (int i = tid; i < np * ng; i += 256) {
+      const int px = i / ng, g = g0 + (i - px * ng);
+      s_tile[px * G + g] = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();  // (a part may end inside the first zeroed unit)
+  }
 #pragma unroll
-    for (int q = 1; q < MAXP; q++) k += (q < a.n && ch >= a.c0[q]) ? 1 : 0;  // the part holding channel ch (if any)
-    if (ch < a.c0[a.n]) {
-      if (ch + 8 <= a.c0[k + 1]) {
-        v = ((const U16B*)(a.p[k] + (pix * a.pitch[k] + (ch - a.c0[k])) * 2))->v;
-      } else {
-        unsigned short e[8];
+  for (int k = 0; k < MAXP; k++) {
+    if (k >= a.n) break;
+    const int Ck = a.c0[k + 1] - a.c0[k], c0 = a.c0[k];
+    const char* src = a.p[k] + pix0 * a.pitch[k] * 2;
+    if (a.pitch[k] == Ck && ((uintptr_t)a.p[k] & 15) == 0) {
+      // dense part: NP x Ck contiguous elements (16-byte aligned start: NP * Ck * 2 is a multiple of 64)
+      const int nel = np * Ck, nfull = nel >> 3;
+      const bool al = (Ck & 7) == 0 && (c0 & 7) == 0;
+      for (int u = tid; u < nfull; u += 256) {
+        const u32x4 v = *(const u32x4*)(src + u * 16);
+        const int e = u * 8, px = e / Ck, c = e - px * Ck;
+        if (al) {
+          *(u32x4*)(s_e + px * a.Cout + c0 + c) = v;
+        } else {
+          int pp = px, cc = c;
+          const unsigned w[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int c = ch + j;
-          int kk = k;
-          while (kk + 1 < a.n && c >= a.c0[kk + 1]) kk++;
-          e[j] = c < a.c0[a.n] ? ((const unsigned short*)a.p[kk])[pix * a.pitch[kk] + (c - a.c0[kk])] : (unsigned short)0;
+          for (int j = 0; j < 8; j++) {
+            s_e[pp * a.Cout + c0 + cc] = (unsigned short)(w[j >> 1] >> ((j & 1) * 16));
+            if (++cc == Ck) { cc = 0; pp++; }
+          }
         }
-        v = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
-                  (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      }
+      for (int e = nfull * 8 + tid; e < nel; e += 256) {  // (a partial last block: fewer than 8 elements left over)
+        const int px = e / Ck, c = e - px * Ck;
+        s_e[px * a.Cout + c0 + c] = ((const unsigned short*)src)[e];
+      }
+    } else if (a.vec[k] && (Ck & 7) == 0) {
+      // channel slice of a wider tensor, 16-byte aligned rows: one unit per thread
+      const int upr = Ck >> 3;
+      for (int i = tid; i < np * upr; i += 256) {
+        const int px = i / upr, u = i - px * upr;
+        *(u32x4*)(s_e + px * a.Cout + c0 + u * 8) = *(const u32x4*)(src + ((long)px * a.pitch[k] + u * 8) * 2);
+      }
+    } else {
+      for (int i = tid; i < np * Ck; i += 256) {
+        const int px = i / Ck, c = i - px * Ck;
+        s_e[px * a.Cout + c0 + c] = ((const unsigned short*)src)[(long)px * a.pitch[k] + c];
       }
     }
-    *(u32x4*)(a.out + i * 16) = v;
   }
+  __syncthreads();
+  u32x4* dst = (u32x4*)(a.out + pix0 * a.Cout * 2);
+  for (int i = tid; i < np * G; i += 256) dst[i] = s_tile[i];
 }
 }  // namespace cc
 }  // namespace ocf
@@ -82,9 +121,10 @@ extern "C" int ocf_concat_channels(const ocf_tensor4* const* parts, const int* c
   if (c > Cout) return OCF_EINVAL;
   if (!pixel_major(out, Cout) || pitch(out, Cout) != Cout || (uintptr_t)out->data % 16 != 0) return OCF_EUNSUPPORTED;
   a.out = (char*)out->data; a.n = n; a.Cout = Cout; a.npix = (long)B * H * W;
-  const long total = a.npix * (Cout / 8);
-  const long blocks = (total + 255) / 256;
+  const long blocks = (a.npix + cc::NP - 1) / cc::NP;
+  const size_t lds = (size_t)cc::NP * Cout * 2;
+  if (blocks > 0x7fffffffL || lds > 48 * 1024) return OCF_EUNSUPPORTED;  // (Cout <= 768)
   LaunchProf lp;
-  lp.launch(true, cc::concat_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a);
+  lp.launch(true, cc::concat_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
   return launch_status();
 }

@@ -1,5 +1,8 @@
-OUT=gpurun_out; mkdir -p $OUT
-timeout -k 10 1100 python -X faulthandler -m pytest tests/test_models_gpu.py tests/test_configs_gpu.py tests/test_train_goldens_gpu.py -v -s -m gpu > $OUT/r4x_models_full.txt 2>&1
-echo "rc=$?"
-grep -v "MIOpen(HIP): Warning" $OUT/r4x_models_full.txt | grep -n "FAILED\|Fatal\|Abort\|abort\|HIP error\|hipError\|fault\|passed\|failed" | tail -12
-L=$(grep -n "Fatal Python error" $OUT/r4x_models_full.txt | head -1 | cut -d: -f1); if [ -n "$L" ]; then sed -n "$((L-30)),$((L+3))p" $OUT/r4x_models_full.txt | grep -v "MIOpen(HIP)" | cut -c1-250; fi
+set -o pipefail
+ROOT=$PWD; OUT=$ROOT/gpurun_out; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_r4x -- python3 $ROOT/bench.py --steps 10 --warmup 3 --preroll 22 --cpu-seconds 0 --unsup-steps 0 --cfg3-steps 0 > $OUT/prof_r4x.log 2>&1 || exit 1
+cd $ROOT
+OCF_STEP_SEQ=1 python scripts/step_breakdown.py $OUT/prof_r4x 40 > $OUT/r4x_breakdown.txt 2>&1
+rm -rf $OUT/prof_r4x
+head -16 $OUT/r4x_breakdown.txt

@@ -80,3 +80,12 @@ for c, (cnt, t) in sorted(cat.items(), key=lambda kv: -kv[1][1]):
 print()
 for k, (cnt, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{t / n / 1e3:9.1f} us {cnt / n:7.1f} x  {k}")
+
+# OCF_STEP_SEQ=1: the launches of ONE replayed step in order (name, grid, microseconds) -- which layer a library kernel belongs to is read
+# off its neighbours
+import os
+if os.environ.get("OCF_STEP_SEQ") == "1" and rep:
+    _, a, b = rep[len(rep) // 2]
+    print("\nlaunch sequence of one replayed step:")
+    for s, e, nme, g in rows[a:b]:
+        print(f"{(e - s) / 1e3:8.1f} us  grid {g[0]:>9d},{g[1]:>5d},{g[2]:>3d}  {short(nme)[:90]}")
