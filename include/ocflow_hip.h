@@ -371,6 +371,21 @@ int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64
                         const ocf_tensor4* gy, const ocf_tensor4* gx, float* gw, int64_t g_si, int64_t g_so, int64_t g_sy, int64_t g_sx,
                         float* gbias, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype, void* stream);
 
+/* ---- the two images of a pair as one bf16 channels_last batch: x fp32 [B, 6, H, W] (any strides; channels 0-2 / 3-5 = the two images),
+ * out bf16 dense channels_last [2B, 3, H, W] (8-byte aligned): out[b] = x[b, 0:3], out[B + b] = x[b, 3:6], rounded to bf16.
+ * replaces: torch.cat((inputs[:, 0:3], inputs[:, 3:6]), 0) of the paired encoder pass + the autocast cast of its first convolution
+ *           (reference call sites flow_net.py:100-101, flow_occ_net.py:149-150 run the encoder once per image) */
+int ocf_pair_input(const ocf_tensor4* x, void* out, int B, int H, int W, void* stream);
+
+/* ---- Adam over flat buffers: one launch for a whole network.  params / grads / exp_avg / exp_avg_sq: fp32 arrays of n elements in ONE
+ * element order (n % 4 == 0, 16-byte aligned); params_bf16: optional bf16 array of n elements that receives the updated parameters
+ * (the compute copies of a master-weight set-up), or NULL; step: device fp32 scalar holding the step count t >= 1 of THIS update.
+ *   m <- m + (1 - b1)(g - m);  v <- b2 v + (1 - b2) g^2;  p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps);  g += wd * p first.
+ * replaces: torch.optim.Adam(...).step() of models/flow_model.py:105-106 / model.py configure_optimizers [the framework's multi-tensor
+ *           kernels over 229 parameter tensors + the copy of the fp32 masters into the bf16 weights] */
+int ocf_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* params_bf16, int64_t n, float lr, double beta1,
+                  double beta2, float eps, float weight_decay, const float* step, void* stream);
+
 /* ---- BatchNorm2d (batch statistics) + LeakyReLU of the feature-pyramid encoder
  * replaces: nn.BatchNorm2d + nn.LeakyReLU(0.1) of the reference's `conv_bn_relu` blocks (models/networks/feature_pyramid_net.py:5-95), i.e.
  * torch.batch_norm(training) + leaky_relu and their autograd.  Dense channels_last x / y / gy / gx of `dtype` (OCF_F32 / OCF_BF16), C a

@@ -97,6 +97,7 @@ class FeaturePyramidNet(nn.Module):
         if not paired:
             return self(x1), self(x2)
         B = x1.shape[0]
-        pyr = self(torch.cat([x1, x2], 0), 2 if self.training else 1)
+        both = ops.pair_input(x1, x2) if ops.pair_input_eligible(x1, x2) else torch.cat([x1, x2], 0)
+        pyr = self(both, 2 if self.training else 1)
         halves = [p.view(2, B, *p.shape[1:]).unbind(0) for p in pyr]
         return [h[0] for h in halves], [h[1] for h in halves]

@@ -1021,6 +1021,28 @@ def concat_channels(parts, cout=None):
     return _ConcatFn.apply(cout, *parts)
 
 
+def pair_input_eligible(x1, x2) -> bool:
+    """x1, x2 = channels 0-2 / 3-5 of ONE fp32 [B, 6, H, W] device tensor that needs no gradient (the reference's `inputs[:, 0:3]`,
+    `inputs[:, 3:6]`), with bf16 autocast active -- the case `pair_input` serves"""
+    if not (torch.is_tensor(x1) and torch.is_tensor(x2) and x1.is_cuda and x1.dtype == torch.float32 and x2.dtype == torch.float32):
+        return False
+    if x1.dim() != 4 or x1.shape != x2.shape or x1.shape[1] != 3 or x1.stride() != x2.stride() or x1.requires_grad or x2.requires_grad:
+        return False
+    if not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+        return False
+    return x2.data_ptr() - x1.data_ptr() == 3 * x1.stride(1) * 4 and os.environ.get("OCFLOW_PAIR_INPUT", "1") != "0"
+
+
+def pair_input(x1, x2):
+    """`torch.cat((x1, x2), 0).to(bfloat16, channels_last)` for the two halves of a 6-channel pair tensor, one launch (ocf_pair_input)"""
+    B, _, H, W = x1.shape
+    out = torch.empty((2 * B, 3, H, W), device=x1.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    six = x1.as_strided((B, 6, H, W), x1.stride())  # (the parent's channels 0-5: x2 starts three channel strides after x1)
+    with torch.cuda.device(x1.device):
+        _lib.check(_lib.load().ocf_pair_input(_t4(six), C.c_void_p(out.data_ptr()), B, H, W, _stream(x1)), "ocf_pair_input")
+    return out
+
+
 # ------------------------------------------------------------------------- 3x3 convolution, weight gradient
 def conv3x3_wgrad(x, gy, dilation=1, out=None):
     """Weight gradient of a 3x3 / stride-1 / padding == dilation convolution (the estimator / context network layers: flow_net.py:11-37,

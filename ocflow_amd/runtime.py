@@ -294,6 +294,7 @@ class TrainStepper:
         self._graph_opt = None
         self._graph_pool = None
         self._flat = None
+        self._flat_adam = None
 
     # ---- fp32 masters / bf16 compute weights
     def _setup_master_weights(self):
@@ -378,7 +379,64 @@ class TrainStepper:
         for p, v in zip(params, views):
             self._masters.get(id(p), p).grad = v  # the optimizer's tensor for this parameter
 
+    def _setup_flat_adam(self, params):
+        """Re-home what Adam touches -- the fp32 parameters it updates (masters where there are any), both moments and the bf16 compute
+        copies -- into FOUR flat buffers laid out like the flat gradient buffer, every tensor becoming a view with its own shape and
+        strides, so that ocf_adam_flat updates the whole network in one launch (csrc/adam.hip).  The optimizer object keeps working on
+        the same storage (eager steps, state_dict, checkpoints).  Returns None when the optimizer is not a plain single-group Adam."""
+        opt = self.optimizer
+        if os.environ.get("OCFLOW_FLAT_ADAM", "1") == "0" or type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return None
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or torch.is_tensor(g["lr"]):
+            return None
+        targets = [self._masters.get(id(p), p) for p in params]
+        in_group = {id(t) for t in g["params"]}
+        if any(t.dtype != torch.float32 or id(t) not in in_group or t not in opt.state or "exp_avg" not in opt.state[t] for t in targets):
+            return None
+        pad = lambda n: (n + 63) & ~63  # (the layout of _flat_views)
+        total = sum(pad(t.numel()) for t in targets)
+        dev = self.env.device
+        fp, fm, fv = (torch.zeros(total, device=dev, dtype=torch.float32) for _ in range(3))
+        fb = torch.zeros(total, device=dev, dtype=torch.bfloat16) if self._masters else None
+        steps, off = [], 0
+        with torch.no_grad():
+            for p, t in zip(params, targets):
+                n = t.numel()
+                view = lambda flat: flat[off:off + n].as_strided(t.shape, t.stride())
+                st = opt.state[t]
+                for key, flat in (("exp_avg", fm), ("exp_avg_sq", fv)):
+                    v = view(flat)
+                    v.copy_(st[key])
+                    st[key] = v
+                v = view(fp)
+                v.copy_(t.data)
+                t.data = v
+                if t is not p:  # bf16 compute copy of a master
+                    v = view(fb)
+                    v.copy_(p.data)
+                    p.data = v
+                steps.append(st["step"])
+                off += pad(n)
+        if any(not torch.is_tensor(s_) or s_.device != dev or s_.dtype != torch.float32 for s_ in steps):
+            return None
+        return {"p": fp, "m": fm, "v": fv, "b": fb, "steps": steps, "n": total, "lr": float(g["lr"]), "betas": tuple(map(float, g["betas"])),
+                "eps": float(g["eps"]), "wd": float(g["weight_decay"])}
+
     def _optimizer_step(self):
+        fa = getattr(self, "_flat_adam", None)
+        if fa is not None and self._flat is not None and torch.cuda.is_current_stream_capturing():
+            # (captured: the gradients are in self._flat at every replay; eager steps gather into a fresh buffer and take the optimizer's
+            # own step below, on the same storage)
+            from . import _lib
+            import ctypes as C
+            torch._foreach_add_(fa["steps"], 1)
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+            with torch.cuda.device(self.env.device):
+                _lib.check(_lib.load().ocf_adam_flat(ptr(fa["p"]), ptr(self._flat), ptr(fa["m"]), ptr(fa["v"]), ptr(fa["b"]), fa["n"], fa["lr"],
+                                                     fa["betas"][0], fa["betas"][1], fa["eps"], fa["wd"], ptr(fa["steps"][0]),
+                                                     C.c_void_p(torch.cuda.current_stream(self.env.device).cuda_stream)), "ocf_adam_flat")
+            return
         self.optimizer.step()
         if self._masters:
             with torch.no_grad():
@@ -461,6 +519,10 @@ class TrainStepper:
         self._flat, views = self._flat_views(params)
         # those kernels accumulate straight into the flat fp32 buffer (zeroed at the top of every replay): autograd produces no gradient
         # tensor for these parameters, nothing is cast to bf16 and back, nothing is copied per parameter
+        self._flat_adam = self._setup_flat_adam(params)
+        if self._flat_adam is not None:
+            nconv.PACKER.refresh()  # the bf16 weights moved: rebuild the packer's descriptor table outside the capture
+            torch.cuda.synchronize()
         sinks = nconv.install_grad_sinks(params, views) if os.environ.get("OCFLOW_GRAD_SINKS", "1") != "0" else set()
         self._sink_ids = sinks
         with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):

@@ -244,8 +244,19 @@ def test_launcher_runs_the_shipped_two_stage_configuration(tmp_path):
         flow_io.save_flow(str(root / f"{i:07d}-flow_01.flo"), fl)
         Image.fromarray(((rs.rand(140, 200) < 0.2) * 255).astype(np.uint8)).save(root / f"{i:07d}-occ_01.png")
     cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "unsupervised_twostage.yml")
-    hist = train.main([cfg, "--steps", "13", "--override", f"root={root}", "batch_size=4", "num_workers=0", "log_every_n_steps=4",
-                       "--out", str(tmp_path / "out")])
+    # the launcher as a user starts it: `python -m ocflow_amd.train <config> ...` in its own process (it also keeps this run apart from
+    # whatever graphs, pools and library handles the tests before it left in the pytest process)
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = [cfg, "--steps", "13", "--override", f"root={root}", "batch_size=4", "num_workers=0", "log_every_n_steps=4", "--out", str(tmp_path / "out")]
+    if os.environ.get("OCFLOW_TEST_LAUNCHER_INPROC") == "1":  # (diagnostics: the same run inside the pytest process)
+        train.main(argv)
+    else:
+        run = subprocess.run([sys.executable, "-m", "ocflow_amd.train"] + argv, cwd=repo, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-3000:]
+    hist = json.load(open(tmp_path / "out" / "metrics.json"))["history"]
     assert len(hist) >= 3 and all(np.isfinite(h["train_loss"]) for h in hist)
     sd = torch.load(tmp_path / "out" / "state_dict.pt")
     assert any(k.startswith("inpainting.refine_attn.") for k in sd) and any(k.startswith("occ_pred.") for k in sd)

@@ -1134,3 +1134,54 @@ def test_concat_channels_matches_torch_cat_and_pads_with_zeros():
     assert torch.equal(ops.concat_channels([a, b])[:, :104], torch.cat([a, b], 1))
     one = torch.randn(2, 24, 1, 1, device="cuda").bfloat16()
     assert torch.equal(ops.concat_channels([one, one], 64)[:, :48], torch.cat([one, one], 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_adam_flat_matches_torch_adam(wd):
+    """ocf_adam_flat (one launch over flat parameter / gradient / moment buffers, bf16 copy written along) against torch.optim.Adam on the
+    same values for five steps: parameters and both moments within 2e-6 relative (fp32 rounding of a different operation order), the
+    bf16 copy = the rounded fp32 parameters bit for bit"""
+    import ctypes as C
+    from ocflow_amd import _lib
+    torch.manual_seed(3)
+    n = 64 * 1000
+    p0 = torch.randn(n, device=DEV)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.zeros(n, device=DEV, dtype=torch.bfloat16)
+    step = torch.zeros((), device=DEV)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    for it in range(5):
+        g = torch.randn(n, device=DEV) * (0.1 + it)
+        ref_p.grad = g.clone()
+        opt.step()
+        step += 1
+        _lib.check(_lib.load().ocf_adam_flat(ptr(p), ptr(g), ptr(m), ptr(v), ptr(pb), n, 1e-3, 0.9, 0.999, 1e-8, wd, ptr(step),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ocf_adam_flat")
+        st = opt.state[ref_p]
+        for got, want, what in ((p, ref_p.detach(), "param"), (m, st["exp_avg"], "exp_avg"), (v, st["exp_avg_sq"], "exp_avg_sq")):
+            err = float((got - want).abs().max() / (want.abs().max() + 1e-30))
+            assert err < 2e-6, (it, what, err)
+        assert torch.equal(pb, p.bfloat16())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["cl", "nchw"])
+@pytest.mark.parametrize("shape", [(2, 20, 32), (3, 7, 9), (1, 436, 1024)])
+def test_pair_input_is_cat_and_cast(ops, shape, layout):
+    """ocf_pair_input: the two 3-channel halves of a [B, 6, H, W] fp32 tensor as one [2B, 3, H, W] bf16 channels_last batch, bit for bit
+    `torch.cat((x[:, 0:3], x[:, 3:6]), 0).bfloat16()`; both input layouts, pixel counts that are / are not multiples of four"""
+    B, H, W = shape
+    x = torch.randn(B, 6, H, W, device=DEV)
+    if layout == "cl":
+        x = x.contiguous(memory_format=torch.channels_last)
+    x1, x2 = x[:, 0:3], x[:, 3:6]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert ops.pair_input_eligible(x1, x2)
+        got = ops.pair_input(x1, x2)
+    assert not ops.pair_input_eligible(x1, x2)  # (no autocast: the encoder takes the fp32 tensors as they are)
+    want = torch.cat((x1, x2), 0).bfloat16()
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
