@@ -97,28 +97,40 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
 }
 
 // totals of the two per-channel quantities over `nparts` block partials, fp64, for every channel -> tot[0][c], tot[1][c] (LDS).
-// C a divisor of 256: all 256 threads share the work (thread = (channel, slice of the partials)); otherwise one thread per channel.
+// All 256 threads share the work: thread = (channel, slice of the partials) in channel blocks of <= 256, and a thread's loads are issued
+// EIGHT partials at a time before the first add.  (The loop used to be one load pair per iteration with the fp64 add behind it: up to 32
+// dependent L2 round trips per thread -- 64 where C does not divide 256, one thread per channel -- in the prologue of EVERY block of the
+// apply / dx passes: those kernels ran 19-25 us at pyramid levels whose tensors are 5-30 MB.)
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nparts, int C, double (*tot)[MAX_C]) {
   __shared__ double s_r[2][256];
-  if (C <= 256 && 256 % C == 0) {
-    const int c = threadIdx.x % C, slot = threadIdx.x / C, nslots = 256 / C;
+  for (int cb = 0; cb < C; cb += 256) {
+    const int cw = C - cb < 256 ? C - cb : 256, nslots = 256 / cw;
+    const int c = threadIdx.x % cw, slot = threadIdx.x / cw;
     double ds = 0.0, dq = 0.0;
-    for (int b = slot; b < nparts; b += nslots) { ds += (double)part[((long)b * 2) * C + c]; dq += (double)part[((long)b * 2 + 1) * C + c]; }
+    if (slot < nslots) {
+      const float* pc = part + cb + c;
+      for (int b0 = slot; b0 < nparts; b0 += 8 * nslots) {
+        float a0[8], a1[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int b = b0 + k * nslots, bc = b < nparts ? b : b0;
+          a0[k] = pc[((long)bc * 2) * C];
+          a1[k] = pc[((long)bc * 2 + 1) * C];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (b0 + k * nslots < nparts) { ds += (double)a0[k]; dq += (double)a1[k]; }
+      }
+    }
     s_r[0][threadIdx.x] = ds; s_r[1][threadIdx.x] = dq;
     __syncthreads();
-    if (threadIdx.x < C) {
+    if (threadIdx.x < cw) {
       ds = 0.0; dq = 0.0;
-      for (int k = 0; k < nslots; k++) { ds += s_r[0][k * C + threadIdx.x]; dq += s_r[1][k * C + threadIdx.x]; }
-      tot[0][threadIdx.x] = ds; tot[1][threadIdx.x] = dq;
+      for (int k = 0; k < nslots; k++) { ds += s_r[0][k * cw + threadIdx.x]; dq += s_r[1][k * cw + threadIdx.x]; }
+      tot[0][cb + threadIdx.x] = ds; tot[1][cb + threadIdx.x] = dq;
     }
-  } else {
-    for (int c = threadIdx.x; c < C; c += 256) {
-      double ds = 0.0, dq = 0.0;
-      for (int b = 0; b < nparts; b++) { ds += (double)part[((long)b * 2) * C + c]; dq += (double)part[((long)b * 2 + 1) * C + c]; }
-      tot[0][c] = ds; tot[1][c] = dq;
-    }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
 // y = lrelu(T(x * a + b)),  a = gamma * invstd, b = beta - mean * a.  nparts > 0: batch statistics from the partials of bn_stats_kernel
@@ -234,16 +246,16 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const T* __restrict__
   }
   if (r < rpb) {
     const long step = (long)gridDim.x * rpb;
-    for (long row0 = (long)blockIdx.x * rpb + r; row0 < R; row0 += step * 2) {
-      float fx[2][V], fy[2][V], fg[2][V];
+    for (long row0 = (long)blockIdx.x * rpb + r; row0 < R; row0 += step * 4) {
+      float fx[4][V], fy[4][V], fg[4][V];
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
+      for (int k = 0; k < 4; k++) {
         const long row = row0 + k * step < R ? row0 + k * step : R - 1;
         const long o = row * C + cg * V;
         ldv<T, V>(x + o, fx[k]); ldv<T, V>(y + o, fy[k]); ldv<T, V>(gy + o, fg[k]);
       }
 #pragma unroll
-      for (int k = 0; k < 2; k++)
+      for (int k = 0; k < 4; k++)
         if (row0 + k * step < R) {
 #pragma unroll
           for (int j = 0; j < V; j++) {
@@ -493,9 +505,10 @@ template <typename T> static int pick_v(int C, std::initializer_list<const ocf_t
   return 0;
 }
 
-// blocks of the statistics passes: >= 32K elements each, at most MAX_PARTS (every block of the second pass re-reads all partials)
+// blocks of the statistics passes: >= 8K elements each (one or two rounds of loads per thread at the coarse levels: a block's loop is a
+// chain of load round trips), at most MAX_PARTS (every block of the second pass totals all partials: reduce_partials)
 static int stat_blocks(long R, int C) {
-  long want = (R * C + 32767) / 32768;
+  long want = (R * C + 8191) / 8192;
   return (int)(want < 1 ? 1 : (want < MAX_PARTS ? want : MAX_PARTS));
 }
 
