@@ -345,9 +345,13 @@ class _ConvBiasActFn(Function):
         if co < 8 and _native_wgrad():
             # prediction layers (2 flow channels, 1 occlusion logit): the kernels read channels in 16-byte chunks, so the gradient goes
             # into a zero-padded 8-channel copy (two small launches) instead of the framework's vector-1 / naive convolution backward
-            dzp = torch.zeros((B, 8, H, W), device=dz.device, dtype=dz.dtype).contiguous(memory_format=torch.channels_last)
-            dzp[:, :co] = dz
-            dz = dzp
+            if ops.concat_channels_eligible([dz]):
+                with torch.no_grad():
+                    dz = ops.concat_channels([dz], 8)  # (one launch: the copy and the zero channels together)
+            else:
+                dzp = torch.zeros((B, 8, H, W), device=dz.device, dtype=dz.dtype).contiguous(memory_format=torch.channels_last)
+                dzp[:, :co] = dz
+                dz = dzp
             use_wg3 = need_w and wgrad_eligible(x, dz, weight.shape[1], co)
         if need_x:
             if (co % 8 == 0 or co < 8) and _pixel_major(dz, 16) and dz.shape[1] % 8 == 0:
