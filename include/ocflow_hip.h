@@ -377,6 +377,19 @@ int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64
  *           (reference call sites flow_net.py:100-101, flow_occ_net.py:149-150 run the encoder once per image) */
 int ocf_pair_input(const ocf_tensor4* x, void* out, int B, int H, int W, void* stream);
 
+/* ---- supervised head of FlowOccModel: x4 bilinear up-sampling (align_corners = False) of the quarter-resolution flow [B,2,h,w] and occlusion
+ * probability [B,1,h,w] (bf16 or fp32, any strides; occ_lr / occ_gt may both be NULL), mean L1 against flow_gt fp32 [B,2,4h,4w] and mean
+ * binary cross entropy (logs clamped at -100) against occ_gt fp32 [B,1,4h,4w], without the full-resolution predictions in memory.
+ * _fwd: sums = 2 doubles of scratch (zeroed by the launcher), losses = 2 floats (the two means), partials = fp32 [B,h,w,27] scratch kept
+ *       for _bwd, or NULL when no gradient is wanted.
+ * _bwd: grad_*_loss = device fp32 scalars (dLoss/d mean; NULL = 0); writes gflow_lr / gocc_lr (either may be NULL) in the tensors' dtype.
+ * replaces: `self.upsample1(refined), self.upsample2(occ)` (flow_occ_net.py:56-57,93; cost_volume_flow_occ_net.py:43-44,83) +
+ *           `F.l1_loss(flow_pred, flow)`, `F.binary_cross_entropy(occ_pred, occ)` (models/flow_occ_model.py:48-55) and their autograd */
+int ocf_flow_occ_head_fwd(const ocf_tensor4* flow_lr, const ocf_tensor4* occ_lr, const ocf_tensor4* flow_gt, const ocf_tensor4* occ_gt,
+                          double* sums, float* losses, float* partials, int B, int h, int w, int flow_dtype, int occ_dtype, void* stream);
+int ocf_flow_occ_head_bwd(const float* partials, const float* grad_flow_loss, const float* grad_occ_loss, const ocf_tensor4* gflow_lr,
+                          const ocf_tensor4* gocc_lr, int B, int h, int w, int flow_dtype, int occ_dtype, void* stream);
+
 /* ---- Adam over flat buffers: one launch for a whole network.  params / grads / exp_avg / exp_avg_sq: fp32 arrays of n elements in ONE
  * element order (n % 4 == 0, 16-byte aligned); params_bf16: optional bf16 array of n elements that receives the updated parameters
  * (the compute copies of a master-weight set-up), or NULL; step: device fp32 scalar holding the step count t >= 1 of THIS update.

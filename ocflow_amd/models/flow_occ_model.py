@@ -4,6 +4,8 @@
 Adam over `self.model.parameters()` with `hparams['learning_rate']`."""
 import torch
 import torch.nn.functional as F
+
+from ocflow_amd import ops
 from torch.optim import Adam
 
 from .lightning_shim import LightningModule, set_hparams
@@ -44,7 +46,14 @@ class FlowOccModel(LightningModule):
 
     def general_step(self, batch, batch_idx, mode):
         imgs, flow, occ = batch
-        flow_pred, occ_pred = self.forward(imgs)
+        if getattr(self.model, "lowres_head", False) and imgs.is_cuda:
+            # the two x4 up-samplings and both losses on the quarter-resolution outputs in one forward and one backward launch
+            flow_lr, occ_lr = self.model(imgs, upsample=False)
+            if ops.flow_occ_head_eligible(flow_lr, occ_lr, flow, occ):
+                return ops.flow_occ_head_loss(flow_lr, occ_lr, flow, occ)
+            flow_pred, occ_pred = self.model.upsample1(flow_lr), self.model.upsample2(occ_lr)
+        else:
+            flow_pred, occ_pred = self.forward(imgs)
         flow_loss = F.l1_loss(flow_pred.float(), flow)
         # BCE is evaluated in fp32 (autocast refuses it in reduced precision); identical in fp32 mode
         with torch.autocast(device_type=imgs.device.type, enabled=False):

@@ -48,7 +48,9 @@ class FlowOccNetCV(nn.Module):
         """feature warp, align_corners=False variant (cost_volume_flow_occ_net.py:137-167)"""
         return ops.warp(img, flow, align_corners=False)
 
-    def forward(self, x):
+    lowres_head = True  # forward(x, upsample=False) returns the quarter-resolution (flow, occlusion)
+
+    def forward(self, x, upsample=True):
         # aligned concatenations + the repo's convolution kernels in the bf16 channels_last configuration, exactly as FlowNetCV.forward
         # (cost_volume_flow_net.py): the library's transposed convolution `upfeat` is handed the unpadded channel range
         native = (os.environ.get("OCFLOW_PAD_PWC", "auto") == "auto" and nconv.enabled() and x.is_cuda and torch.is_autocast_enabled()
@@ -80,4 +82,6 @@ class FlowOccNetCV(nn.Module):
                 upf = getattr(self, f"upfeat{lvl}")
                 up_feat = upf(feats[:, :upf.weight.shape[0]]) if native else upf(feats)
         flow2 = flow + context(self, feats)
+        if not upsample:
+            return flow2, occ
         return self.upsample1(flow2), self.upsample2(occ)

@@ -61,7 +61,9 @@ class FlowOccNet(nn.Module):
         """feature warp, align_corners=False variant (flow_occ_net.py:96-126)"""
         return ops.warp(img, flow, align_corners=False)
 
-    def forward(self, inputs, training=False, mask=None):
+    lowres_head = True  # forward(..., upsample=False) returns the quarter-resolution (flow, occlusion) the two nn.Upsample modules would take
+
+    def forward(self, inputs, training=False, mask=None, upsample=True):
         pyr1, pyr2 = self.feature_pyramid_network.forward_pair(inputs[:, 0:3], inputs[:, 3:6])
         flow_up = flow_feat_up = occ_up = occ_feat_up = None
         flow = flow_feat = occ = None
@@ -90,4 +92,6 @@ class FlowOccNet(nn.Module):
             else:
                 flow, flow_up, flow_feat_up = self.opticalflow_estimators[i](x, *size)
         refined = flow + self.context_network(cat_aligned([flow_feat, flow.to(flow_feat.dtype)]))
+        if not upsample:
+            return refined, occ
         return self.upsample1(refined), self.upsample2(occ)

@@ -1021,6 +1021,62 @@ def concat_channels(parts, cout=None):
     return _ConcatFn.apply(cout, *parts)
 
 
+class _HeadLossFn(Function):
+    """(mean L1 of the x4 up-sampled flow, mean BCE of the x4 up-sampled occlusion probability) and their gradients w.r.t. the
+    quarter-resolution tensors: ocf_flow_occ_head_fwd / _bwd (csrc/head_loss.hip)"""
+
+    @staticmethod
+    def forward(ctx, flow_lr, occ_lr, flow_gt, occ_gt):
+        B, _, h, w = flow_lr.shape
+        dev = flow_lr.device
+        sums = torch.empty(2, device=dev, dtype=torch.float64)
+        losses = torch.empty(2, device=dev, dtype=torch.float32)
+        need = ctx.needs_input_grad[0] or (occ_lr is not None and ctx.needs_input_grad[1])
+        part = torch.empty((B, h, w, 27), device=dev, dtype=torch.float32) if need else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().ocf_flow_occ_head_fwd(_t4(flow_lr), _t4(occ_lr), _t4(flow_gt), _t4(occ_gt), _ptr(sums), _ptr(losses), _ptr(part),
+                                                         B, h, w, _dtype_code(flow_lr), _dtype_code(occ_lr) if occ_lr is not None else 0,
+                                                         _stream(flow_lr)), "ocf_flow_occ_head_fwd")
+        ctx.save_for_backward(part, flow_lr, occ_lr)  # (the low-resolution tensors only for their shapes / strides / dtypes)
+        return losses[0], losses[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_flow, g_occ):
+        part, flow_lr, occ_lr = ctx.saved_tensors
+        B, _, h, w = flow_lr.shape
+        gflow = torch.empty_like(flow_lr) if ctx.needs_input_grad[0] else None
+        gocc = torch.empty_like(occ_lr) if (occ_lr is not None and ctx.needs_input_grad[1]) else None
+        scal = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_flow, g_occ = scal(g_flow), scal(g_occ)
+        with torch.cuda.device(flow_lr.device):
+            _lib.check(_lib.load().ocf_flow_occ_head_bwd(_ptr(part), _ptr(g_flow), _ptr(g_occ), _t4(gflow), _t4(gocc), B, h, w,
+                                                         _dtype_code(flow_lr), _dtype_code(occ_lr) if occ_lr is not None else 0,
+                                                         _stream(flow_lr)), "ocf_flow_occ_head_bwd")
+        return gflow, gocc, None, None
+
+
+def flow_occ_head_eligible(flow_lr, occ_lr, flow_gt, occ_gt) -> bool:
+    """quarter-resolution predictions on a HIP device, fp32 ground truth at exactly four times their size"""
+    if os.environ.get("OCFLOW_FUSED_HEAD", "1") == "0" or torch.compiler.is_compiling():
+        return False
+    ts = (flow_lr, occ_lr, flow_gt, occ_gt)
+    if not all(torch.is_tensor(t) and t.is_cuda and t.dim() == 4 for t in ts):
+        return False
+    B, _, h, w = flow_lr.shape
+    return (flow_lr.shape[1] == 2 and tuple(occ_lr.shape) == (B, 1, h, w) and tuple(flow_gt.shape) == (B, 2, 4 * h, 4 * w)
+            and tuple(occ_gt.shape) == (B, 1, 4 * h, 4 * w) and flow_gt.dtype == torch.float32 and occ_gt.dtype == torch.float32
+            and flow_lr.dtype in (torch.float32, torch.bfloat16) and occ_lr.dtype in (torch.float32, torch.bfloat16)
+            and not flow_gt.requires_grad and not occ_gt.requires_grad)
+
+
+def flow_occ_head_loss(flow_lr, occ_lr, flow_gt, occ_gt):
+    """`(F.l1_loss(up4(flow_lr).float(), flow_gt), F.binary_cross_entropy(up4(occ_lr).float(), occ_gt))` with
+    `up4 = nn.Upsample(scale_factor=4, mode="bilinear")`, in two launches forward + one backward"""
+    _require_hip(flow_lr, occ_lr, flow_gt, occ_gt)
+    return _HeadLossFn.apply(flow_lr, occ_lr, flow_gt, occ_gt)
+
+
 def pair_input_eligible(x1, x2) -> bool:
     """x1, x2 = channels 0-2 / 3-5 of ONE fp32 [B, 6, H, W] device tensor that needs no gradient (the reference's `inputs[:, 0:3]`,
     `inputs[:, 3:6]`), with bf16 autocast active -- the case `pair_input` serves"""

@@ -7,6 +7,7 @@ than ATen), bf16 kernels vs the oracle evaluated on the SAME bf16-rounded inputs
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import ocflow_oracle as O
 
@@ -1185,3 +1186,43 @@ def test_pair_input_is_cat_and_cast(ops, shape, layout):
     want = torch.cat((x1, x2), 0).bfloat16()
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)],
+                         ids=["f32", "bf16", "f32flow-bf16occ"])
+@pytest.mark.parametrize("shape", [(2, 5, 7), (1, 1, 1), (3, 2, 1), (2, 9, 16), (8, 109, 256)])
+def test_flow_occ_head_loss_matches_upsample_l1_bce(ops, shape, dtypes):
+    """ocf_flow_occ_head_fwd / _bwd against the framework's chain on the same quarter-resolution tensors:
+    `F.l1_loss(up4(flow).float(), flow_gt)`, `F.binary_cross_entropy(up4(occ).float(), occ_gt)` with nn.Upsample(scale_factor=4, bilinear),
+    forward (1e-5 relative: fp64 totals here, fp32 tree sums there) and the gradients w.r.t. the quarter-resolution tensors (fp32: 1e-5 of
+    the scale; bf16: one rounding, 1e-2), image borders, 1-pixel maps, saturated probabilities (exactly 0 and 1: the -100 clamp of the logs
+    and the 1e-12 clamp of the BCE gradient) and different loss weights included"""
+    B, h, w = shape
+    fdt, odt = dtypes
+    g = torch.Generator().manual_seed(B * 100 + h)
+    flow = (torch.randn(B, 2, h, w, generator=g) * 3).to(fdt)
+    occ = torch.sigmoid(torch.randn(B, 1, h, w, generator=g) * 4).to(odt)
+    occ.view(-1)[0] = 1.0
+    occ.view(-1)[-1] = 0.0
+    fgt = torch.randn(B, 2, 4 * h, 4 * w, generator=g) * 3
+    ogt = (torch.rand(B, 1, 4 * h, 4 * w, generator=g) < 0.3).float()
+    up = torch.nn.Upsample(scale_factor=4, mode="bilinear")
+    fr = flow.to(DEV).requires_grad_(True)
+    orr = occ.to(DEV).requires_grad_(True)
+    l1r = F.l1_loss(up(fr.float()), fgt.to(DEV))
+    bcr = F.binary_cross_entropy(up(orr.float()), ogt.to(DEV))
+    (0.7 * l1r + 1.3 * bcr).backward()
+    fd = flow.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    od = occ.to(DEV).requires_grad_(True)
+    assert ops.flow_occ_head_eligible(fd, od, fgt.to(DEV), ogt.to(DEV))
+    l1, bc = ops.flow_occ_head_loss(fd, od, fgt.to(DEV), ogt.to(DEV))
+    (0.7 * l1 + 1.3 * bc).backward()
+    assert abs(float(l1) - float(l1r)) <= 1e-5 * abs(float(l1r)) + 1e-7, (float(l1), float(l1r))
+    assert abs(float(bc) - float(bcr)) <= 1e-5 * abs(float(bcr)) + 1e-7, (float(bc), float(bcr))
+    for got, want, dt, what in ((fd.grad, fr.grad, fdt, "flow"), (od.grad, orr.grad, odt, "occ")):
+        assert got.dtype == dt and got.shape == want.shape
+        tol = 1e-5 if dt == torch.float32 else 1e-2
+        scale = float(want.float().abs().max()) + 1e-30
+        err = float((got.float() - want.float()).abs().max())
+        assert err <= tol * scale, (what, err, scale)
