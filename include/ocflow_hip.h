@@ -420,6 +420,13 @@ int ocf_bn_act_bwd(const ocf_tensor4* x, const ocf_tensor4* y, const ocf_tensor4
                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, int B, int C, int H, int W,
                    float negative_slope, int groups, int dtype, void* stream);
 
+/* ocf_bn_act_bwd without the forward output y: the sign of the pre-activation is recomputed from x with the forward's own coefficients
+ * (gamma * invstd, beta - mean * gamma * invstd, same fma and rounding: the same bits), a third less traffic in the statistics pass and a
+ * quarter less in the dx pass.  Same results as ocf_bn_act_bwd. */
+int ocf_bn_act_bwd_x(const ocf_tensor4* x, const ocf_tensor4* gy, const ocf_tensor4* gx, const float* gamma, const float* beta,
+                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, int B, int C, int H, int W,
+                     float negative_slope, int groups, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,7 @@ SIGNATURES = {
     "ocf_bn_act_workspace_bytes": [_i, _i, C.POINTER(C.c_int64)],
     "ocf_bn_act_fwd": [_T4P, _T4P, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _vp],
     "ocf_bn_act_bwd": [_T4P, _T4P, _T4P, _T4P, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ocf_bn_act_bwd_x": [_T4P, _T4P, _T4P, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
 }
 
 _lock = threading.Lock()

@@ -224,25 +224,33 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
-template <typename T, int V>
+// NOY: the forward output is not read -- the sign of the pre-activation t = T(x * a + b) is recomputed from x with the forward's own
+// coefficients (a = gamma * invstd, b = beta - mean * a from the SAVED fp32 statistics, the same fma, the same rounding: the same bits),
+// which takes a third of the traffic out of this pass and a quarter out of the dx pass
+template <typename T, int V, bool NOY>
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ gy,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ part, long R, int C, int G, float slope) {
   {  // blockIdx.y = statistics group
     const long go = (long)blockIdx.y * R * C;
-    x += go; y += go; gy += go;
+    x += go; gy += go;
+    if (!NOY) y += go;
     mean += (long)blockIdx.y * C; invstd += (long)blockIdx.y * C;
     part += (long)blockIdx.y * gridDim.x * 2 * C;
   }
   __shared__ float red[256][2 * V + 1];
   const int rpb = 256 / G;
   const int r = threadIdx.x / G, cg = threadIdx.x - r * G;
-  float s[V], q[V], mu[V], is[V];
+  float s[V], q[V], mu[V], is[V], ca[V], cb[V];
 #pragma unroll
   for (int j = 0; j < V; j++) {
+    const int c = (cg * V + j) < C ? cg * V + j : 0;
     s[j] = q[j] = 0.f;
-    mu[j] = mean[(cg * V + j) < C ? cg * V + j : 0];
-    is[j] = invstd[(cg * V + j) < C ? cg * V + j : 0];
+    mu[j] = mean[c];
+    is[j] = invstd[c];
+    ca[j] = NOY ? gamma[c] * is[j] : 0.f;
+    cb[j] = NOY ? beta[c] - mu[j] * ca[j] : 0.f;
   }
   if (r < rpb) {
     const long step = (long)gridDim.x * rpb;
@@ -252,14 +260,16 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const T* __restrict__
       for (int k = 0; k < 4; k++) {
         const long row = row0 + k * step < R ? row0 + k * step : R - 1;
         const long o = row * C + cg * V;
-        ldv<T, V>(x + o, fx[k]); ldv<T, V>(y + o, fy[k]); ldv<T, V>(gy + o, fg[k]);
+        ldv<T, V>(x + o, fx[k]); ldv<T, V>(gy + o, fg[k]);
+        if (!NOY) ldv<T, V>(y + o, fy[k]);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++)
         if (row0 + k * step < R) {
 #pragma unroll
           for (int j = 0; j < V; j++) {
-            const float dz = fy[k][j] > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
+            const float yv = NOY ? rnd<T>(__builtin_fmaf(fx[k][j], ca[j], cb[j])) : fy[k][j];
+            const float dz = yv > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
             s[j] += dz;
             q[j] = __builtin_fmaf(dz, (fx[k][j] - mu[j]) * is[j], q[j]);
           }
@@ -270,18 +280,20 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const T* __restrict__
 }
 
 // dx = gamma * invstd * (dz - dbeta / N - xhat * dgamma / N); the totals dbeta = sum dz, dgamma = sum dz * xhat from the partials
-template <typename T, int V>
+template <typename T, int V, bool NOY>
 __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ gy,
                                                         T* __restrict__ gx, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        const float* __restrict__ gamma, const float* __restrict__ part, int nparts,
-                                                        float* dgamma, float* dbeta, long R, int C, int G, float slope) {
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ part, int nparts, float* dgamma, float* dbeta, long R,
+                                                        int C, int G, float slope) {
   __shared__ double s_tot[2][MAX_C];
   __shared__ float s_o[2][MAX_C];
   // blockIdx.y = statistics group; the parameter gradients are the sums over the groups: block (0, 0) also totals group 1
   const int grp = blockIdx.y, ngrp = gridDim.y;
   {
     const long go = (long)grp * R * C;
-    x += go; y += go; gy += go; gx += go;
+    x += go; gy += go; gx += go;
+    if (!NOY) y += go;
     mean += (long)grp * C; invstd += (long)grp * C;
   }
   const bool keeper = blockIdx.x == 0 && grp == 0;
@@ -302,12 +314,13 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
   if (i0 >= n_units) return;
   const long stride = (long)gridDim.x * 256;
   const int cg = (int)(i0 % G);
-  float mu[V], is[V], k0[V], k1[V], k2[V];
+  float mu[V], is[V], k0[V], k1[V], k2[V], cb[V];
 #pragma unroll
   for (int j = 0; j < V; j++) {
     const int c = cg * V + j;
     mu[j] = mean[c]; is[j] = invstd[c];
     k0[j] = gamma[c] * is[j];
+    cb[j] = NOY ? beta[c] - mu[j] * k0[j] : 0.f;
     k1[j] = (float)s_tot[0][c] * inv_n;
     k2[j] = (float)s_tot[1][c] * inv_n;
   }
@@ -316,14 +329,16 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const long ii = i + k * stride < n_units ? i + k * stride : i0;
-      ldv<T, V>(x + ii * V, fx[k]); ldv<T, V>(y + ii * V, fy[k]); ldv<T, V>(gy + ii * V, fg[k]);
+      ldv<T, V>(x + ii * V, fx[k]); ldv<T, V>(gy + ii * V, fg[k]);
+      if (!NOY) ldv<T, V>(y + ii * V, fy[k]);
     }
 #pragma unroll
     for (int k = 0; k < 2; k++)
       if (i + k * stride < n_units) {
 #pragma unroll
         for (int j = 0; j < V; j++) {
-          const float dz = fy[k][j] > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
+          const float yv = NOY ? rnd<T>(__builtin_fmaf(fx[k][j], k0[j], cb[j])) : fy[k][j];
+          const float dz = yv > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
           fx[k][j] = k0[j] * (dz - k1[j] - (fx[k][j] - mu[j]) * is[j] * k2[j]);
         }
         stv<T, V>(gx + (i + k * stride) * V, fx[k]);
@@ -417,11 +432,11 @@ __global__ void __launch_bounds__(CB) bn_fwd_col_kernel(const T* __restrict__ x,
   }
 }
 
-template <typename T, int V>
+template <typename T, int V, bool NOY>
 __global__ void __launch_bounds__(CB) bn_bwd_col_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ gy,
                                                          T* __restrict__ gx, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         const float* __restrict__ gamma, float* dgamma, float* dbeta, long R, int C,
-                                                         float slope, int ngrp) {
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* dgamma,
+                                                         float* dbeta, long R, int C, float slope, int ngrp) {
   __shared__ float red[CB / 64][2 * V];
   const int c0 = blockIdx.x * V;
   const T *x0 = x, *y0 = y, *g0 = gy;
@@ -430,23 +445,29 @@ __global__ void __launch_bounds__(CB) bn_bwd_col_kernel(const T* __restrict__ x,
 #pragma unroll
   for (int j = 0; j < V; j++) sb[j] = sg[j] = 0.f;
   for (int grp = 0; grp < ngrp; grp++) {
-  x = x0 + (long)grp * R * C; y = y0 + (long)grp * R * C; gy = g0 + (long)grp * R * C; gx = gx0 + (long)grp * R * C;
-  float s[V], q[V], mu[V], is[V];
+  x = x0 + (long)grp * R * C; if (!NOY) y = y0 + (long)grp * R * C; gy = g0 + (long)grp * R * C; gx = gx0 + (long)grp * R * C;
+  float s[V], q[V], mu[V], is[V], ca[V], cb[V];
 #pragma unroll
-  for (int j = 0; j < V; j++) { s[j] = q[j] = 0.f; mu[j] = mean[(long)grp * C + c0 + j]; is[j] = invstd[(long)grp * C + c0 + j]; }
+  for (int j = 0; j < V; j++) {
+    s[j] = q[j] = 0.f; mu[j] = mean[(long)grp * C + c0 + j]; is[j] = invstd[(long)grp * C + c0 + j];
+    ca[j] = gamma[c0 + j] * is[j];
+    cb[j] = NOY ? beta[c0 + j] - mu[j] * ca[j] : 0.f;
+  }
   for (long r0 = threadIdx.x; r0 < R; r0 += 2 * CB) {
     float fx[2][V], fy[2][V], fg[2][V];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const long o = (r0 + CB * k < R ? r0 + CB * k : r0) * C + c0;
-      ldv<T, V>(x + o, fx[k]); ldv<T, V>(y + o, fy[k]); ldv<T, V>(gy + o, fg[k]);
+      ldv<T, V>(x + o, fx[k]); ldv<T, V>(gy + o, fg[k]);
+      if (!NOY) ldv<T, V>(y + o, fy[k]);
     }
 #pragma unroll
     for (int k = 0; k < 2; k++)
       if (r0 + CB * k < R) {
 #pragma unroll
         for (int j = 0; j < V; j++) {
-          const float dz = fy[k][j] > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
+          const float yv = NOY ? rnd<T>(__builtin_fmaf(fx[k][j], ca[j], cb[j])) : fy[k][j];
+          const float dz = yv > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
           s[j] += dz;
           q[j] = __builtin_fmaf(dz, (fx[k][j] - mu[j]) * is[j], q[j]);
         }
@@ -467,14 +488,16 @@ __global__ void __launch_bounds__(CB) bn_bwd_col_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const long o = (r0 + CB * k < R ? r0 + CB * k : r0) * C + c0;
-      ldv<T, V>(x + o, fx[k]); ldv<T, V>(y + o, fy[k]); ldv<T, V>(gy + o, fg[k]);
+      ldv<T, V>(x + o, fx[k]); ldv<T, V>(gy + o, fg[k]);
+      if (!NOY) ldv<T, V>(y + o, fy[k]);
     }
 #pragma unroll
     for (int k = 0; k < 2; k++)
       if (r0 + CB * k < R) {
 #pragma unroll
         for (int j = 0; j < V; j++) {
-          const float dz = fy[k][j] > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
+          const float yv = NOY ? rnd<T>(__builtin_fmaf(fx[k][j], ca[j], cb[j])) : fy[k][j];
+          const float dz = yv > 0.f ? fg[k][j] : rnd<T>(fg[k][j] * slope);
           fx[k][j] = k0[j] * (dz - k1[j] - (fx[k][j] - mu[j]) * is[j] * k2[j]);
         }
         stv<T, V>(gx + (r0 + CB * k) * C + c0, fx[k]);
@@ -546,23 +569,36 @@ static int fwd_v(const ocf_tensor4* x, const ocf_tensor4* y, const float* gamma,
   return launch_status();
 }
 
+// y == NULL (with beta): the y-free kernels (NOY)
 template <typename T, int V>
 static int bwd_v(const ocf_tensor4* x, const ocf_tensor4* y, const ocf_tensor4* gy, const ocf_tensor4* gx, const float* gamma,
                  const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, long R, int C, float slope,
-                 int groups, hipStream_t st) {
+                 int groups, hipStream_t st, const float* beta = nullptr) {
   const int G = C / V;
   const long n_units = R * G;
   const int nb = stat_blocks(R, C);
   LaunchProf lp;
+  const T* yd = y ? (const T*)y->data : nullptr;
   if (R * C <= COL_MAX_ELEMS) {
-    lp.launch(true, bn_bwd_col_kernel<T, V>, dim3(G), dim3(CB), 0, st, (const T*)x->data, (const T*)y->data, (const T*)gy->data, (T*)gx->data,
-              save_mean, save_invstd, gamma, dgamma, dbeta, R, C, slope, groups);
+    if (yd)
+      lp.launch(true, bn_bwd_col_kernel<T, V, false>, dim3(G), dim3(CB), 0, st, (const T*)x->data, yd, (const T*)gy->data, (T*)gx->data, save_mean,
+                save_invstd, gamma, beta, dgamma, dbeta, R, C, slope, groups);
+    else
+      lp.launch(true, bn_bwd_col_kernel<T, V, true>, dim3(G), dim3(CB), 0, st, (const T*)x->data, yd, (const T*)gy->data, (T*)gx->data, save_mean,
+                save_invstd, gamma, beta, dgamma, dbeta, R, C, slope, groups);
     return launch_status();
   }
-  lp.launch(false, bn_bwd_stats_kernel<T, V>, dim3(nb, groups), dim3(256), 0, st, (const T*)x->data, (const T*)y->data, (const T*)gy->data, save_mean,
-            save_invstd, (float*)workspace, R, C, G, slope);
-  lp.launch(true, bn_bwd_dx_kernel<T, V>, dim3(grid_for_units(n_units, G), groups), dim3(256), 0, st, (const T*)x->data, (const T*)y->data,
-            (const T*)gy->data, (T*)gx->data, save_mean, save_invstd, gamma, (const float*)workspace, nb, dgamma, dbeta, R, C, G, slope);
+  if (yd) {
+    lp.launch(false, bn_bwd_stats_kernel<T, V, false>, dim3(nb, groups), dim3(256), 0, st, (const T*)x->data, yd, (const T*)gy->data, save_mean,
+              save_invstd, gamma, beta, (float*)workspace, R, C, G, slope);
+    lp.launch(true, bn_bwd_dx_kernel<T, V, false>, dim3(grid_for_units(n_units, G), groups), dim3(256), 0, st, (const T*)x->data, yd,
+              (const T*)gy->data, (T*)gx->data, save_mean, save_invstd, gamma, beta, (const float*)workspace, nb, dgamma, dbeta, R, C, G, slope);
+  } else {
+    lp.launch(false, bn_bwd_stats_kernel<T, V, true>, dim3(nb, groups), dim3(256), 0, st, (const T*)x->data, yd, (const T*)gy->data, save_mean,
+              save_invstd, gamma, beta, (float*)workspace, R, C, G, slope);
+    lp.launch(true, bn_bwd_dx_kernel<T, V, true>, dim3(grid_for_units(n_units, G), groups), dim3(256), 0, st, (const T*)x->data, yd,
+              (const T*)gy->data, (T*)gx->data, save_mean, save_invstd, gamma, beta, (const float*)workspace, nb, dgamma, dbeta, R, C, G, slope);
+  }
   return launch_status();
 }
 
@@ -620,5 +656,27 @@ extern "C" int ocf_bn_act_bwd(const ocf_tensor4* x, const ocf_tensor4* y, const 
   }
   if (bn::pick_v<float>(C, {x, y, gy, gx}) == 4)
     return bn::bwd_v<float, 4>(x, y, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, groups, st);
+  return OCF_EUNSUPPORTED;
+}
+
+/* the same backward WITHOUT the forward output: the LeakyReLU mask is recomputed from x (see bn_bwd_stats_kernel) */
+extern "C" int ocf_bn_act_bwd_x(const ocf_tensor4* x, const ocf_tensor4* gy, const ocf_tensor4* gx, const float* gamma, const float* beta,
+                                const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, int B, int C,
+                                int H, int W, float negative_slope, int groups, int dtype, void* stream) {
+  clear_stale_error();
+  if (groups < 1 || groups > 2 || B % (groups > 0 ? groups : 1) != 0) return OCF_EINVAL;
+  if (!x || !gy || !gx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !workspace) return OCF_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (dtype != OCF_F32 && dtype != OCF_BF16)) return OCF_EINVAL;
+  if (!bn::dense_cl(x, B, C, H, W) || !bn::dense_cl(gy, B, C, H, W) || !bn::dense_cl(gx, B, C, H, W)) return OCF_EUNSUPPORTED;
+  const long R = (long)(B / groups) * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OCF_BF16) {
+    const int v = bn::pick_v<bf16>(C, {x, gy, gx});
+    if (v == 8) return bn::bwd_v<bf16, 8>(x, nullptr, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, groups, st, beta);
+    if (v == 4) return bn::bwd_v<bf16, 4>(x, nullptr, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, groups, st, beta);
+    return OCF_EUNSUPPORTED;
+  }
+  if (bn::pick_v<float>(C, {x, gy, gx}) == 4)
+    return bn::bwd_v<float, 4>(x, nullptr, gy, gx, gamma, save_mean, save_invstd, dgamma, dbeta, workspace, R, C, negative_slope, groups, st, beta);
   return OCF_EUNSUPPORTED;
 }

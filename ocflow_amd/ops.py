@@ -1309,7 +1309,10 @@ class _BnActFn(Function):
                                             _ptr(mean), _ptr(invstd), _ptr(ws), B, C_, H, W, float(eps), float(momentum), float(slope), 1,
                                             int(groups), _dtype_code(x), _stream(x))
         _lib.check(st, "ocf_bn_act_fwd")
-        ctx.save_for_backward(x, y, weight, mean, invstd)
+        # the backward recomputes the LeakyReLU mask from x (ocf_bn_act_bwd_x): y is not kept for it.  OCFLOW_BN_BWD_Y=1: the first form,
+        # which reads the saved output (A/B; same results)
+        ctx.with_y = os.environ.get("OCFLOW_BN_BWD_Y", "0") == "1"
+        ctx.save_for_backward(x, y if ctx.with_y else None, weight, bias, mean, invstd)
         ctx.slope = float(slope)
         ctx.groups = int(groups)
         return y
@@ -1317,7 +1320,7 @@ class _BnActFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, bias, mean, invstd = ctx.saved_tensors
         B, C_, H, W = x.shape
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
@@ -1328,9 +1331,14 @@ class _BnActFn(Function):
         dbeta = torch.empty(C_, device=x.device, dtype=torch.float32)
         ws = _bn_workspace(C_, x.device, ctx.groups)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.load().ocf_bn_act_bwd(_t4(x), _t4(y), _t4(gy), _t4(gx), _ptr(weight), _ptr(mean), _ptr(invstd), _ptr(dgamma),
-                                                  _ptr(dbeta), _ptr(ws), B, C_, H, W, ctx.slope, ctx.groups, _dtype_code(x), _stream(x)),
-                       "ocf_bn_act_bwd")
+            if ctx.with_y:
+                _lib.check(_lib.load().ocf_bn_act_bwd(_t4(x), _t4(y), _t4(gy), _t4(gx), _ptr(weight), _ptr(mean), _ptr(invstd), _ptr(dgamma),
+                                                      _ptr(dbeta), _ptr(ws), B, C_, H, W, ctx.slope, ctx.groups, _dtype_code(x), _stream(x)),
+                           "ocf_bn_act_bwd")
+            else:
+                _lib.check(_lib.load().ocf_bn_act_bwd_x(_t4(x), _t4(gy), _t4(gx), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd),
+                                                        _ptr(dgamma), _ptr(dbeta), _ptr(ws), B, C_, H, W, ctx.slope, ctx.groups,
+                                                        _dtype_code(x), _stream(x)), "ocf_bn_act_bwd_x")
         return gx, dgamma, dbeta, None, None, None, None, None, None, None
 
 

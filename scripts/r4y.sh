@@ -1,6 +1,6 @@
 set -o pipefail
 OUT=gpurun_out; mkdir -p $OUT
-timeout -k 10 400 python -m pytest tests/test_hip_parity.py -q -k "head_loss" > $OUT/r4y_t1.txt 2>&1
+timeout -k 10 400 python -m pytest tests/test_hip_parity.py -q -k "batchnorm or bn_" > $OUT/r4y_t1.txt 2>&1
 rc=$?
 grep -v "MIOpen(HIP): Warning" $OUT/r4y_t1.txt | grep -E "^E  |FAILED|passed|failed" | head -20
 [ $rc -eq 0 ] || exit $rc

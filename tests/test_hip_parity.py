@@ -999,6 +999,30 @@ def test_batchnorm_lrelu_vs_framework(ops, shape, dtype):
     assert int(bn.num_batches_tracked) == 2
 
 
+@pytest.mark.parametrize("shape,groups", [((2, 16, 21, 45), 1), ((4, 196, 7, 16), 2), ((8, 32, 28, 64), 2), ((3, 4, 5, 6), 1), ((6, 64, 55, 128), 2)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_backward_without_the_output_is_the_same_backward(ops, shape, groups, dtype, monkeypatch):
+    """ocf_bn_act_bwd_x (the LeakyReLU mask recomputed from x with the forward's coefficients) against ocf_bn_act_bwd (the mask read from the
+    saved output): bit-identical input and parameter gradients, column kernel and two-pass kernels, one and two statistics groups"""
+    import torch.nn as nn
+    B, C_, H, W = shape
+    gen = torch.Generator().manual_seed(C_ * 3 + H)
+    x0 = (torch.randn(shape, generator=gen) * 1.7 + 0.4).to(dtype)
+    cot = torch.randn(shape, generator=gen).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    res = []
+    for with_y in ("1", "0"):
+        monkeypatch.setenv("OCFLOW_BN_BWD_Y", with_y)
+        bn = nn.BatchNorm2d(C_).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C_, generator=torch.Generator().manual_seed(1)) + 0.5)
+            bn.bias.copy_(torch.randn(C_, generator=torch.Generator().manual_seed(2)) * 0.3)
+        x = x0.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+        y = ops.batchnorm_lrelu(x, bn, 0.1, groups)
+        res.append(torch.autograd.grad(y, (x, bn.weight, bn.bias), cot))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape", [(4, 16, 21, 45), (4, 196, 7, 16), (16, 32, 28, 64), (2, 128, 14, 32), (6, 64, 55, 128)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_batchnorm_lrelu_two_statistics_groups(ops, shape, dtype):
