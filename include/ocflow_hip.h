@@ -365,11 +365,15 @@ int ocf_concat_channels(const ocf_tensor4* const* parts, const int* channels, in
  * gbias (fp32 [Co], accumulated, may be NULL) = parameter gradients.  Anything else: OCF_EUNSUPPORTED.
  * replaces: `upconv1` / `upconv2` of flow_net.py:38-48 and flow_occ_net.py:46-66 (F.conv_transpose2d + bias and their autograd: the
  *           library's vector-1 implicit GEMM / naive_conv kernels, a workspace fill and a cast per weight gradient). */
+/* act = 1: y = sigmoid(bf16(result)) (`torch.sigmoid(deconv(...))` of flow_occ_net.py:62-66 in one launch); the backward then takes the
+ * forward's output as y_act and applies the sigmoid derivative to gy on the fly (bf16-rounded, as the framework's sigmoid_backward);
+ * act = 0 / y_act = NULL: the plain layer. */
 int ocf_deconv3x3s2_fwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64_t w_so, int64_t w_sy, int64_t w_sx, int w_is_f32,
-                        const float* bias, const ocf_tensor4* y, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype, void* stream);
+                        const float* bias, const ocf_tensor4* y, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int act, int dtype,
+                        void* stream);
 int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64_t w_so, int64_t w_sy, int64_t w_sx, int w_is_f32,
                         const ocf_tensor4* gy, const ocf_tensor4* gx, float* gw, int64_t g_si, int64_t g_so, int64_t g_sy, int64_t g_sx,
-                        float* gbias, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype, void* stream);
+                        float* gbias, const ocf_tensor4* y_act, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype, void* stream);
 
 /* ---- the two images of a pair as one bf16 channels_last batch: x fp32 [B, 6, H, W] (any strides; channels 0-2 / 3-5 = the two images),
  * out bf16 dense channels_last [2B, 3, H, W] (8-byte aligned): out[b] = x[b, 0:3], out[B + b] = x[b, 3:6], rounded to bf16.

@@ -81,8 +81,8 @@ SIGNATURES = {
     "ocf_conv3x3_pack_weights": [_vp, _i, C.c_int64, _vp],
     "ocf_conv3x3_wgrad_bias": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_concat_channels": [C.POINTER(_T4P), C.POINTER(_i), _i, _T4P, _i, _i, _i, _i, _i, _vp],
-    "ocf_deconv3x3s2_fwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _vp, _T4P, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "ocf_deconv3x3s2_bwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp,
+    "ocf_deconv3x3s2_fwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _vp, _T4P, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_deconv3x3s2_bwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _T4P,
                             _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_pair_input": [_T4P, _vp, _i, _i, _i, _vp],
     "ocf_flow_occ_head_fwd": [_T4P, _T4P, _T4P, _T4P, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

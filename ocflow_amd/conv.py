@@ -523,7 +523,7 @@ class _DeconvBiasFn(Function):
     """ConvTranspose2d(3x3, stride 2, padding 1) + bias: forward one launch, backward two (input gradient; weight + bias gradient into fp32)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_pad):
+    def forward(ctx, x, weight, bias, out_pad, act):
         B, ci, H, W = x.shape
         co = int(weight.shape[1])
         Ho, Wo = 2 * H - 1 + out_pad[0], 2 * W - 1 + out_pad[1]
@@ -533,18 +533,18 @@ class _DeconvBiasFn(Function):
         with torch.cuda.device(x.device):
             fn = lambda: _lib.check(_lib.load().ocf_deconv3x3s2_fwd(_t4(x), C.c_void_p(weight.data_ptr()), si, so, sy, sx,
                                                                      int(weight.dtype == torch.float32), _ptr(bf), _t4(y), B, ci, co, H, W, Ho, Wo,
-                                                                     _lib.OCF_BF16, _stream(x)), "ocf_deconv3x3s2_fwd")
+                                                                     int(act), _lib.OCF_BF16, _stream(x)), "ocf_deconv3x3s2_fwd")
             ops._launch("deconv3x3s2_fwd", lambda: ops._meta(f"B{B}x{ci}->{co}x{H}x{W}", 2 * B * (H * W * ci + Ho * Wo * co), 0), fn)
-        ctx.save_for_backward(x, weight, *([bias] if bias is not None else []))
+        ctx.save_for_backward(x, weight, y if act else None, *([bias] if bias is not None else []))
         ctx.geom = (Ho, Wo, bias is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors[:2]
+        x, weight, y_act = ctx.saved_tensors[:3]
         Ho, Wo, has_bias = ctx.geom
-        bias = ctx.saved_tensors[2] if has_bias else None
+        bias = ctx.saved_tensors[3] if has_bias else None
         B, ci, H, W = x.shape
         co = int(weight.shape[1])
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
@@ -563,16 +563,19 @@ class _DeconvBiasFn(Function):
         with torch.cuda.device(x.device):
             fn = lambda: _lib.check(_lib.load().ocf_deconv3x3s2_bwd(_t4(x), C.c_void_p(weight.data_ptr()), si, so, sy, sx,
                                                                      int(weight.dtype == torch.float32), _t4(gg), _t4(gx), _ptr(gw), gs[0], gs[1], gs[2],
-                                                                     gs[3], _ptr(gb), B, ci, co, H, W, Ho, Wo, _lib.OCF_BF16, _stream(x)),
+                                                                     gs[3], _ptr(gb), _t4(y_act), B, ci, co, H, W, Ho, Wo, _lib.OCF_BF16,
+                                                                     _stream(x)),
                                     "ocf_deconv3x3s2_bwd")
             ops._launch("deconv3x3s2_bwd", lambda: ops._meta(f"B{B}x{ci}->{co}x{H}x{W}", 2 * B * (2 * H * W * ci + 2 * Ho * Wo * co), 0), fn)
         if need_b and gb is None:
-            gb = gg.float().sum((0, 2, 3))
+            dz = gg.float() if y_act is None else (gg.float() * (1.0 - y_act.float()) * y_act.float()).to(gg.dtype).float()
+            gb = dz.sum((0, 2, 3))
         if gb is not None and not b_sink and bias.dtype != torch.float32:
             gb = gb.to(bias.dtype)
-        return gx, (None if w_sink else gw), (None if (b_sink or not need_b) else gb), None
+        return gx, (None if w_sink else gw), (None if (b_sink or not need_b) else gb), None, None
 
 
-def deconv3x3s2_bias(x, weight, bias, output_padding):
-    """`F.conv_transpose2d(x, weight, bias, 2, 1, output_padding)` on the small-channel kernels; the caller checks `deconv_eligible` first"""
-    return _DeconvBiasFn.apply(x, weight, bias, (int(output_padding[0]), int(output_padding[1])))
+def deconv3x3s2_bias(x, weight, bias, output_padding, sigmoid: bool = False):
+    """`F.conv_transpose2d(x, weight, bias, 2, 1, output_padding)` -- with `sigmoid`: `torch.sigmoid(...)` of it, forward and backward in the
+    same launches -- on the small-channel kernels; the caller checks `deconv_eligible` first"""
+    return _DeconvBiasFn.apply(x, weight, bias, (int(output_padding[0]), int(output_padding[1])), bool(sigmoid))

@@ -20,8 +20,10 @@ struct Args {
   bf16* gx;         // backward: gradient of x [B][H][W][gxp]
   float* gw;        // fp32, element strides gsi / gso / gsy / gsx (accumulated)
   float* gbias;     // fp32 [Co] (accumulated) or null
-  long xp, yp, gyp, gxp, wsi, wso, wsy, wsx, gsi, gso, gsy, gsx;
+  const bf16* ya;   // backward with act: the forward's output (sigmoid values), pixel pitch yap
+  long xp, yp, gyp, gxp, wsi, wso, wsy, wsx, gsi, gso, gsy, gsx, yap;
   int B, H, W, Ho, Wo, Ci, Co, w_f32;
+  int act;          // 0: none; 1: sigmoid applied to the bf16-rounded result (forward) / its derivative applied to gy (backward)
 };
 
 __device__ __forceinline__ float wload(const Args& a, int ci, int co, int ky, int kx) {
@@ -37,6 +39,15 @@ __device__ __forceinline__ void stage_w(const Args& a, float* sw) {
     sw[i] = (float)(bf16)wload(a, ci, co, t / 3, t % 3);  // (fp32 master weights: the bf16 rounding autocast applies)
   }
   __syncthreads();
+}
+
+// gradient w.r.t. the transposed convolution's own result at element `off` of gy: gy itself, or with act the bf16-rounded gy * (1 - y) * y
+// (the framework's sigmoid_backward, rounded to the feature dtype before the convolution's backward reads it)
+__device__ __forceinline__ float dz_at(const Args& a, long gy_off, long ya_off) {
+  const float g = (float)a.gy[gy_off];
+  if (!a.act) return g;
+  const float y = (float)a.ya[ya_off];
+  return (float)(bf16)((g * (1.f - y)) * y);
 }
 
 // thread = one output pixel, all Co channels; VEC: x pixels are 16-byte aligned and Ci % 8 == 0 (8 channels per load)
@@ -85,7 +96,11 @@ __global__ __launch_bounds__(256) void deconv_fwd_kernel(const Args a) {
     }
     bf16* yr = a.y + (long)p * a.yp;
 #pragma unroll
-    for (int co = 0; co < CO; co++) yr[co] = (bf16)acc[co];
+    for (int co = 0; co < CO; co++) {
+      float v = acc[co];
+      if (a.act) v = 1.f / (1.f + expf(-(float)(bf16)v));  // (sigmoid of the bf16 value the unfused chain would have stored)
+      yr[co] = (bf16)v;
+    }
   }
 }
 
@@ -112,11 +127,11 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const Args a) {
       for (int kx = 0; kx < 3; kx++) {
         const int ox = 2 * ix - 1 + kx;
         if (ox < 0 || ox >= a.Wo) continue;
-        const bf16* gr = a.gy + (((long)b * a.Ho + oy) * a.Wo + ox) * a.gyp;
+        const long op = ((long)b * a.Ho + oy) * a.Wo + ox;
         const float* wr = sw + (ky * 3 + kx) * CO * a.Ci + c0;
 #pragma unroll
         for (int co = 0; co < CO; co++) {
-          const float gv = (float)gr[co];
+          const float gv = dz_at(a, op * a.gyp + co, op * a.yap + co);
 #pragma unroll
           for (int j = 0; j < CPT; j++) acc[j] = __builtin_fmaf(gv, wr[co * a.Ci + j], acc[j]);
         }
@@ -155,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void deconv_bwd_weight_kernel(const Args a
   const int g0 = wv * groups_per_wave;
   int ng = (npix - g0 * spw + spw - 1) / spw;  // groups this wave has (wave-uniform)
   if (ng > groups_per_wave) ng = groups_per_wave;
-  const bool pair = CO == 2 && (a.gyp & 1) == 0 && ((uintptr_t)a.gy & 3) == 0;  // both channels of a gy pixel in one 4-byte load
+  const bool pair = CO == 2 && !a.act && (a.gyp & 1) == 0 && ((uintptr_t)a.gy & 3) == 0;  // both channels of a gy pixel in one 4-byte load
   constexpr int UNR = CO <= 2 ? 4 : 1;  // (3 and 4 output channels: the accumulators leave no room)
 #pragma unroll UNR
   for (int g = 0; g < ng; g++) {
@@ -173,7 +188,8 @@ __global__ __launch_bounds__(64 * NW) void deconv_bwd_weight_kernel(const Args a
       for (int kx = 0; kx < 3; kx++) {
         const int ox = 2 * ix - 1 + kx;
         const bool ok = oky && ox >= 0 && ox < a.Wo;
-        const bf16* gr = a.gy + (((long)b * a.Ho + (oky ? oy : 0)) * a.Wo + (ok ? ox : 0)) * a.gyp;
+        const long op = ((long)b * a.Ho + (oky ? oy : 0)) * a.Wo + (ok ? ox : 0);
+        const bf16* gr = a.gy + op * a.gyp;
         if (pair) {
           const unsigned u = ok ? *(const unsigned*)gr : 0u;
           acc[ky * 3 + kx][0] = __builtin_fmaf(xv, __uint_as_float(u << 16), acc[ky * 3 + kx][0]);
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(64 * NW) void deconv_bwd_weight_kernel(const Args a
         } else {
 #pragma unroll
           for (int co = 0; co < CO; co++) {
-            const float gv = ok ? (float)gr[co] : 0.f;
+            const float gv = ok ? dz_at(a, op * a.gyp + co, op * a.yap + co) : 0.f;
             acc[ky * 3 + kx][co] = __builtin_fmaf(xv, gv, acc[ky * 3 + kx][co]);
           }
         }
@@ -206,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void deconv_bwd_weight_kernel(const Args a
     for (int co = 0; co < CO; co++) s[co] = 0.f;
     for (int q = q0 + threadIdx.x; q < q1; q += 64 * NW) {
 #pragma unroll
-      for (int co = 0; co < CO; co++) s[co] += (float)a.gy[(long)q * a.gyp + co];
+      for (int co = 0; co < CO; co++) s[co] += dz_at(a, (long)q * a.gyp + co, (long)q * a.yap + co);
     }
 #pragma unroll
     for (int co = 0; co < CO; co++) {
@@ -251,8 +267,8 @@ static bool dcv_shape_ok(int B, int Ci, int Co, int H, int W, int Ho, int Wo) {
 }
 
 extern "C" int ocf_deconv3x3s2_fwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64_t w_so, int64_t w_sy, int64_t w_sx, int w_is_f32,
-                                   const float* bias, const ocf_tensor4* y, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype,
-                                   void* stream) {
+                                   const float* bias, const ocf_tensor4* y, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int act,
+                                   int dtype, void* stream) {
   using namespace ocf;
   clear_stale_error();
   if (!x || !y || !w || !x->data || !y->data) return OCF_EINVAL;
@@ -260,6 +276,8 @@ extern "C" int ocf_deconv3x3s2_fwd(const ocf_tensor4* x, const void* w, int64_t 
   if (dtype != OCF_BF16 || Co > dcv::MAXCO || Ci > dcv::MAXCI) return OCF_EUNSUPPORTED;
   dcv::Args a = {};
   if (!dcv_fill(a, x, Ci, H, W, y, Co, Ho, Wo, B, &a.xp, &a.yp)) return OCF_EUNSUPPORTED;
+  if (act != 0 && act != 1) return OCF_EINVAL;
+  a.act = act;
   a.x = (const bf16*)x->data; a.y = (bf16*)y->data; a.w = w; a.bias = bias; a.w_f32 = w_is_f32;
   a.wsi = w_si; a.wso = w_so; a.wsy = w_sy; a.wsx = w_sx;
   const long npix = (long)B * Ho * Wo, blocks = (npix + 255) / 256;
@@ -278,7 +296,8 @@ extern "C" int ocf_deconv3x3s2_fwd(const ocf_tensor4* x, const void* w, int64_t 
 
 extern "C" int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64_t w_so, int64_t w_sy, int64_t w_sx, int w_is_f32,
                                    const ocf_tensor4* gy, const ocf_tensor4* gx, float* gw, int64_t g_si, int64_t g_so, int64_t g_sy, int64_t g_sx,
-                                   float* gbias, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype, void* stream) {
+                                   float* gbias, const ocf_tensor4* y_act, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype,
+                                   void* stream) {
   using namespace ocf;
   clear_stale_error();
   if (!x || !gy || !w || !x->data || !gy->data) return OCF_EINVAL;
@@ -286,6 +305,13 @@ extern "C" int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t 
   if (dtype != OCF_BF16 || Co > dcv::MAXCO || Ci > dcv::MAXCI) return OCF_EUNSUPPORTED;
   dcv::Args a = {};
   if (!dcv_fill(a, x, Ci, H, W, gy, Co, Ho, Wo, B, &a.xp, &a.gyp)) return OCF_EUNSUPPORTED;
+  if (y_act) {  // sigmoid output of the fused forward: same shape as gy
+    if (!y_act->data) return OCF_EINVAL;
+    dcv::Args t = a;
+    long xp_, yap_;
+    if (!dcv_fill(t, x, Ci, H, W, y_act, Co, Ho, Wo, B, &xp_, &yap_)) return OCF_EUNSUPPORTED;
+    a.act = 1; a.ya = (const bf16*)y_act->data; a.yap = yap_;
+  }
   a.x = (const bf16*)x->data; a.gy = (const bf16*)gy->data; a.w = w; a.w_f32 = w_is_f32;
   a.wsi = w_si; a.wso = w_so; a.wsy = w_sy; a.wsx = w_sx;
   a.gw = gw; a.gsi = g_si; a.gso = g_so; a.gsy = g_sy; a.gsx = g_sx; a.gbias = gbias;

@@ -229,16 +229,18 @@ def conv_bias(conv: nn.Conv2d, x):
     return ops.bias_add(_conv_nobias(conv, x), conv.bias)
 
 
-def deconv_bias(deconv: nn.ConvTranspose2d, x, output_size=None):
-    """nn.ConvTranspose2d(bias=True)(x, output_size=...) as a bias-free transposed convolution + in-place bias kernel"""
+def deconv_bias(deconv: nn.ConvTranspose2d, x, output_size=None, sigmoid: bool = False):
+    """nn.ConvTranspose2d(bias=True)(x, output_size=...) as a bias-free transposed convolution + in-place bias kernel; `sigmoid=True`:
+    torch.sigmoid of it (flow_occ_net.py:62-66), inside the same launches where the repo's small-channel kernels take the layer"""
+    act = torch.sigmoid if sigmoid else (lambda t: t)
     w = _match_in_channels(deconv.weight, x.shape[1], dim=0) if deconv.groups == 1 else deconv.weight  # (weight is [in, out, kh, kw])
     output_padding = deconv._output_padding(x, output_size, deconv.stride, deconv.padding, deconv.kernel_size, 2, deconv.dilation)
     if deconv.bias is None or deconv.padding_mode != "zeros" or _unfused():
-        return F.conv_transpose2d(x, w, deconv.bias, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
+        return act(F.conv_transpose2d(x, w, deconv.bias, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation))
     if nconv.deconv_eligible(x, deconv.weight, deconv.stride, deconv.padding, deconv.dilation, deconv.groups, output_padding):
-        return nconv.deconv3x3s2_bias(x, deconv.weight, deconv.bias, output_padding)
+        return nconv.deconv3x3s2_bias(x, deconv.weight, deconv.bias, output_padding, sigmoid)
     y = F.conv_transpose2d(x, w, None, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
-    return ops.bias_add(y, deconv.bias)
+    return act(ops.bias_add(y, deconv.bias))
 
 
 class ConvLReLU(nn.Sequential):

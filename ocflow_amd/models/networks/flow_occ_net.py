@@ -40,7 +40,7 @@ class OcclusionEstimator(nn.Module):
             return torch.sigmoid(10 * logit)
         size = (h_up, w_up)
         occ = torch.sigmoid(logit)
-        return occ, torch.sigmoid(deconv_bias(self.upconv2, occ, size)), torch.sigmoid(deconv_bias(self.upconv1, feat, size))
+        return occ, deconv_bias(self.upconv2, occ, size, sigmoid=True), deconv_bias(self.upconv1, feat, size, sigmoid=True)
 
 
 class FlowOccNet(nn.Module):

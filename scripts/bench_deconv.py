@@ -79,7 +79,7 @@ for lvl in (3, 4, 5, 6):
         def raw(dx, dw):
             _lib.check(L.ocf_deconv3x3s2_bwd(_t4(x.detach()), C.c_void_p(w.data_ptr()), ws[0], ws[1], ws[2], ws[3], 1, _t4(gy), _t4(gx if dx else None),
                                              C.c_void_p(gw.data_ptr()) if dw else None, 9 * co, 9, 3, 1, C.c_void_p(gb.data_ptr()) if dw else None,
-                                             B, ci, co, H, W, Ho, Wo, _lib.OCF_BF16, st()), "bwd")
+                                             None, B, ci, co, H, W, Ho, Wo, _lib.OCF_BF16, st()), "bwd")
 
         t = [timeit(f) for f in (ours_f, lib_f, ours_fb, lib_fb, lambda: raw(True, False), lambda: raw(False, True))]
         for i in range(4):

@@ -84,3 +84,38 @@ def test_deconv_reads_a_channel_slice_and_the_module_routes_here():
     _close(y, ref, "sliced input")
     m4 = torch.nn.ConvTranspose2d(16, 2, 4, 2, 1).to(DEV)  # the PWC estimators' 4x4 deconvolutions stay with the library
     assert not conv.deconv_eligible(x, m4.weight, m4.stride, m4.padding, m4.dilation, m4.groups, (0, 0))
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,op", [(2, 16, 1, 7, 16, (1, 1)), (2, 1, 1, 14, 32, (1, 1)), (1, 32, 2, 9, 13, (0, 1)), (8, 16, 1, 55, 128, (0, 1))])
+def test_deconv_with_fused_sigmoid_matches_the_two_op_chain(B, ci, co, H, W, op):
+    """`torch.sigmoid(conv_transpose2d(x) + bias)` (flow_occ_net.py:62-66) in the launches of the transposed convolution: forward = sigmoid of
+    the bf16-rounded result, backward = the sigmoid derivative applied to the incoming gradient on the fly (bf16-rounded, as the framework's
+    sigmoid_backward) -- against the unfused chain on the same kernels (forward within one bf16 rounding of the sigmoid's own evaluation,
+    gradients 1e-2) and against fp32 autograd"""
+    from ocflow_amd import conv
+    g = torch.Generator().manual_seed(ci * 10 + co)
+    x = torch.randn(B, ci, H, W, generator=g).bfloat16()
+    w = torch.randn(ci, co, 3, 3, generator=g) * 0.3
+    b = torch.randn(co, generator=g) * 0.5
+    Ho, Wo = 2 * H - 1 + op[0], 2 * W - 1 + op[1]
+    gy = torch.randn(B, co, Ho, Wo, generator=g).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (True, False):
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        y = conv.deconv3x3s2_bias(xd, wd, bd, op, True) if fused else torch.sigmoid(conv.deconv3x3s2_bias(xd, wd, bd, op))
+        y.backward(gy)
+        outs.append((y, xd.grad, wd.grad, bd.grad))
+    _close(outs[0][0], outs[1][0], "forward vs unfused", 1e-2, 4e-3)
+    _close(outs[0][1], outs[1][1], "input gradient vs unfused")
+    # (the two sigmoid evaluations may round a value to neighbouring bf16 numbers: y (1 - y) then differs by one bf16 ulp = 4e-3 there)
+    assert _l2(outs[0][2], outs[1][2]) < 1e-2
+    # the bias gradient is a sum of signed terms that largely cancel: its bar is relative to the sum of their magnitudes (<= |gy| / 4)
+    bias_scale = float(gy.float().abs().sum()) * 0.25 / co
+    assert float((outs[0][3] - outs[1][3]).abs().max()) < 2e-3 * bias_scale
+    xr, wr, br = x.float().requires_grad_(True), w.bfloat16().float().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.sigmoid(F.conv_transpose2d(xr, wr, br, 2, 1, op))
+    yr.backward(gy.float().cpu())
+    _close(outs[0][0], yr, "forward vs fp32")
+    _close(outs[0][1], xr.grad, "input gradient vs fp32", 2e-2, 2e-2)
+    assert _l2(outs[0][2], wr.grad) < 1e-2 and float((outs[0][3].cpu() - br.grad).abs().max()) < 2e-3 * bias_scale
