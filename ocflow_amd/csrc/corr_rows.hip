@@ -554,7 +554,10 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
   }
   // persistent grid: a multiple of 8 (XCD-affine walk), at most what is co-resident
   long gsz = ((ntiles + 7) / 8) * 8;
-  const long cap = (long)wg_per_cu * rows_num_cus();
+  long cap = (long)wg_per_cu * rows_num_cus();
+#ifdef OCF_TUNING_BUILD
+  if (getenv("OCF_ROWS_CAP")) cap = atol(getenv("OCF_ROWS_CAP"));  // grid-balance experiments
+#endif
   if (gsz > cap) gsz = cap;
   const dim3 grid((unsigned)gsz), block(GG::NT);
   ProfileSlot& ps = profile_slot();
