@@ -365,7 +365,7 @@ static kern_t pick_mt(int mt) {
     case 4: return conv3x3_igemm_kernel<4, TW>;
     case 5: return conv3x3_igemm_kernel<5, TW>;
     case 6: return conv3x3_igemm_kernel<6, TW>;
-    case 7: return conv3x3_igemm_kernel<7, TW>;
+    // (no 7-tile instantiation: it spilled 16 VGPR dwords; ocf_conv3x3_plan never asks for it -- 14 tiles run as 3 x 5)
     default: return conv3x3_igemm_kernel<8, TW>;
   }
 }
