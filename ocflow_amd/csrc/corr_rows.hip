@@ -621,6 +621,15 @@ int corr_fwd_bf16_rows(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_t
       return occ ? launch_direct_kb<16, 1>(a, bq, oc, o, B, C, H, W, st) : launch_direct_kb<16, 0>(a, bq, oc, o, B, C, H, W, st);
     return occ ? launch_direct_kb<8, 1>(a, bq, oc, o, B, C, H, W, st) : launch_direct_kb<8, 0>(a, bq, oc, o, B, C, H, W, st);
   }
+#ifdef OCF_TUNING_BUILD
+  if (C <= 32) {  // tile-shape experiments for the one-block kernel
+    static const int kv = getenv("OCF_ROWS_K1_SHAPE") ? atoi(getenv("OCF_ROWS_K1_SHAPE")) : 0;
+    if (kv == 1) return occ ? launch_rows<1, 2, 1, 1>(a, bq, oc, o, B, C, H, W, st) : launch_rows<1, 2, 1, 0>(a, bq, oc, o, B, C, H, W, st);
+    if (kv == 2) return occ ? launch_rows<1, 2, 2, 1>(a, bq, oc, o, B, C, H, W, st) : launch_rows<1, 2, 2, 0>(a, bq, oc, o, B, C, H, W, st);
+    if (kv == 3) return occ ? launch_rows<1, 4, 2, 1>(a, bq, oc, o, B, C, H, W, st) : launch_rows<1, 4, 2, 0>(a, bq, oc, o, B, C, H, W, st);
+    if (kv == 4) return occ ? launch_rows<1, 2, 2, 1, 2>(a, bq, oc, o, B, C, H, W, st) : launch_rows<1, 2, 2, 0, 2>(a, bq, oc, o, B, C, H, W, st);
+  }
+#endif
   if (C <= 32) return occ ? launch_rows<1, 4, 1, 1>(a, bq, oc, o, B, C, H, W, st) : launch_rows<1, 4, 1, 0>(a, bq, oc, o, B, C, H, W, st);
 #ifdef OCF_TUNING_BUILD
   static const int p1 = getenv("OCF_ROWS_K2_PASSES") ? atoi(getenv("OCF_ROWS_K2_PASSES")) : 2;
