@@ -375,6 +375,14 @@ int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64
                         const ocf_tensor4* gy, const ocf_tensor4* gx, float* gw, int64_t g_si, int64_t g_so, int64_t g_sy, int64_t g_sx,
                         float* gbias, const ocf_tensor4* y_act, int B, int Ci, int Co, int H, int W, int Ho, int Wo, int dtype, void* stream);
 
+/* ---- 3x3 / stride-1 / padding-1 convolution with 16 input and 16 output channels (bias-free: `layer1.double_conv.3` of the feature pyramid,
+ * feature_pyramid_net.py:21-33), bf16 pixel-major x / y [B,16,H,W] (16-byte aligned pixels), w = the module's [16,16,3,3] weight (element
+ * strides, fp32 or bf16).  transpose = 0: y = conv(x, w); transpose = 1: the input gradient (x = grad_out, y = grad_in: the same kernel
+ * with the weight read transposed and tap-flipped).  B fragments straight from global memory, no LDS (csrc/conv_c16.hip).
+ * replaces: F.conv2d / the input half of its autograd for that layer [the library: 54 us forward, 57 + 17 us input gradient at 16 x 218 x 512] */
+int ocf_conv3x3_c16(const ocf_tensor4* x, const void* w, int64_t w_so, int64_t w_si, int64_t w_sky, int64_t w_skx, int w_is_f32,
+                    const ocf_tensor4* y, int B, int H, int W, int transpose, int dtype, void* stream);
+
 /* ---- the two images of a pair as one bf16 channels_last batch: x fp32 [B, 6, H, W] (any strides; channels 0-2 / 3-5 = the two images),
  * out bf16 dense channels_last [2B, 3, H, W] (8-byte aligned): out[b] = x[b, 0:3], out[B + b] = x[b, 3:6], rounded to bf16.
  * replaces: torch.cat((inputs[:, 0:3], inputs[:, 3:6]), 0) of the paired encoder pass + the autocast cast of its first convolution

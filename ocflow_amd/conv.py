@@ -579,3 +579,58 @@ def deconv3x3s2_bias(x, weight, bias, output_padding, sigmoid: bool = False):
     """`F.conv_transpose2d(x, weight, bias, 2, 1, output_padding)` -- with `sigmoid`: `torch.sigmoid(...)` of it, forward and backward in the
     same launches -- on the small-channel kernels; the caller checks `deconv_eligible` first"""
     return _DeconvBiasFn.apply(x, weight, bias, (int(output_padding[0]), int(output_padding[1])), bool(sigmoid))
+
+
+# ---- the encoder's full-resolution 16 -> 16 layer (csrc/conv_c16.hip): forward and input gradient on the direct matrix-core kernel, weight
+# gradient from the framework
+
+def c16_eligible(x, conv) -> bool:
+    w = conv.weight
+    if not (enabled() and os.environ.get("OCFLOW_NATIVE_C16", "1") != "0" and conv.bias is None):
+        return False
+    if tuple(w.shape) != (16, 16, 3, 3) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1) or tuple(conv.dilation) != (1, 1) \
+            or conv.groups != 1 or conv.padding_mode != "zeros" or w.dtype not in (torch.bfloat16, torch.float32):
+        return False
+    return (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 16 and _pixel_major(x, 16))
+
+
+def _c16_raw(x, weight, transpose: bool):
+    B, _, H, W = x.shape
+    y = torch.empty((B, 16, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    so, si, sky, skx = weight.stride()
+    with torch.cuda.device(x.device):
+        fn = lambda: _lib.check(_lib.load().ocf_conv3x3_c16(_t4(x), C.c_void_p(weight.data_ptr()), so, si, sky, skx,
+                                                            int(weight.dtype == torch.float32), _t4(y), B, H, W, int(transpose), _lib.OCF_BF16,
+                                                            _stream(x)), "ocf_conv3x3_c16")
+        ops._launch("conv3x3_c16", lambda: ops._meta(f"B{B}x16->16x{H}x{W}", B * H * W * 64, 2 * B * H * W * 9 * 256), fn)
+    return y
+
+
+class _ConvC16Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return _c16_raw(x, weight, False)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gg = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
+        if not _pixel_major(gg, 16):
+            gg = gg.contiguous(memory_format=torch.channels_last)
+        gx = _c16_raw(gg, weight, True) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            ggc = gg if gg.is_contiguous(memory_format=torch.channels_last) else gg.contiguous(memory_format=torch.channels_last)
+            xc = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            gw = torch.ops.aten.convolution_backward(ggc, xc, _shape_like(weight, 16), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     [False, True, False])[1]
+            if gw.dtype != weight.dtype:
+                gw = gw.to(weight.dtype)
+        return gx, gw
+
+
+def conv3x3_c16(x, weight):
+    """`F.conv2d(x, weight, None, 1, 1)` for the 16 -> 16 layer; the caller checks `c16_eligible` first"""
+    return _ConvC16Fn.apply(x, weight)

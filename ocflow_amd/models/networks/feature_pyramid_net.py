@@ -18,6 +18,8 @@ def _conv3x3_same(conv: nn.Conv2d, x):
             and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[1] >= 32  # (16 channels: half of every staged 64-byte pixel row is padding)
             and nconv.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
         return nconv.conv3x3_bias_act(x, conv.weight, None, 1.0, 1)
+    if not torch.compiler.is_compiling() and os.environ.get("OCFLOW_NATIVE_FPN", "1") != "0" and nconv.c16_eligible(x, conv):
+        return nconv.conv3x3_c16(x, conv.weight)  # the full-resolution 16 -> 16 layer: forward + input gradient (csrc/conv_c16.hip)
     return conv(x)
 
 

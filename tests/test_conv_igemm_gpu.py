@@ -284,3 +284,31 @@ def test_packed_weights_follow_a_fused_optimizer_step(conv, dt):
         _close(y, ref, f"forward after {step} optimizer steps")
         y.float().square().mean().backward()
         opt.step()
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16], ids=["w32", "w16"])
+@pytest.mark.parametrize("B,H,W", [(2, 9, 37), (1, 1, 1), (3, 20, 16), (16, 218, 512), (1, 5, 130)])
+def test_c16_direct_kernel_forward_and_input_gradient(B, H, W, wdt):
+    """ocf_conv3x3_c16 (the encoder's 16 -> 16 layer: B fragments straight from global memory) against the framework's fp32 convolution on
+    the same bf16-rounded operands: forward 1e-2, input gradient 1e-2 (one bf16 rounding of an fp32 accumulation), partial 16-pixel
+    groups, 1-pixel maps, the benchmark's 16 x 218 x 512; the weight gradient (framework) alongside"""
+    from ocflow_amd import conv as nconv
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, 16, H, W, generator=g).bfloat16()
+    w = (torch.randn(16, 16, 3, 3, generator=g) * 0.1).to(wdt)
+    gy = torch.randn(B, 16, H, W, generator=g).bfloat16()
+    m = torch.nn.Conv2d(16, 16, 3, 1, 1, bias=False).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(w.to(DEV))
+    m = m.to(wdt)
+    xd = _dev_cl(x).requires_grad_(True)
+    assert nconv.c16_eligible(xd, m)
+    y = nconv.conv3x3_c16(xd, m.weight)
+    y.backward(_dev_cl(gy))
+    xr = x.float().requires_grad_(True)
+    wr = w.bfloat16().float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr.backward(gy.float())
+    _close(y, yr, "forward")
+    _close(xd.grad, xr.grad, "input gradient")
+    assert _l2(m.weight.grad, wr.grad) < 1e-2
