@@ -392,7 +392,7 @@ int ocf_pair_input(const ocf_tensor4* x, void* out, int B, int H, int W, void* s
 /* ---- supervised head of FlowOccModel: x4 bilinear up-sampling (align_corners = False) of the quarter-resolution flow [B,2,h,w] and occlusion
  * probability [B,1,h,w] (bf16 or fp32, any strides; occ_lr / occ_gt may both be NULL), mean L1 against flow_gt fp32 [B,2,4h,4w] and mean
  * binary cross entropy (logs clamped at -100) against occ_gt fp32 [B,1,4h,4w], without the full-resolution predictions in memory.
- * _fwd: sums = 2 doubles of scratch (zeroed by the launcher), losses = 2 floats (the two means), partials = fp32 [B,h,w,27] scratch kept
+ * _fwd: sums = 2 doubles of scratch (zeroed by the launcher), losses = 2 floats (the two means), partials = fp32 scratch of 27 * B * h * w elements kept
  *       for _bwd, or NULL when no gradient is wanted.
  * _bwd: grad_*_loss = device fp32 scalars (dLoss/d mean; NULL = 0); writes gflow_lr / gocc_lr (either may be NULL) in the tensors' dtype.
  * replaces: `self.upsample1(refined), self.upsample2(occ)` (flow_occ_net.py:56-57,93; cost_volume_flow_occ_net.py:43-44,83) +

@@ -18,7 +18,7 @@ namespace hl {
 struct Args {
   T4 flow, occ, fgt, ogt;  // quarter-resolution flow [B,2,h,w] / occlusion [B,1,h,w] (bf16 or fp32), ground truth fp32 [B,2,4h,4w] / [B,1,4h,4w]
   double* sums;            // [0] = sum |flow_pred - flow_gt|, [1] = sum BCE terms
-  float* part;             // [B][h][w][27] or null (no gradient wanted)
+  float* part;             // [27][B h w] or null (no gradient wanted)
   int B, h, w, flow_bf16, occ_bf16;
 };
 
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const Args a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   double l1 = 0.0, bce = 0.0;
   if (i < npx) {
+    float l1f = 0.f, bcef = 0.f;  // this thread's 32 + 16 terms in fp32, the totals in fp64
     const int bx = i % a.w, r = i / a.w, by = r % a.h, b = r / a.h;
     const bool has_occ = a.occ.p != nullptr;
     // the 3 x 3 neighbourhood (clamped coordinates: a clamped slot is only ever addressed through the clamped tap index)
@@ -53,22 +54,45 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const Args a) {
       for (int dx = 0; dx < 3; dx++)
 #pragma unroll
         for (int c = 0; c < 3; c++) g[dy][dx][c] = 0.f;
+    // the ground truth of the whole 4 x 4 block FIRST (12 float4 loads when the rows are contiguous): issued per sample, right before
+    // their use, they were sixteen dependent round trips at three waves per SIMD (40 us for 67 MB)
+    float gtv[4][3][4];
+    {
+      const bool vec = a.fgt.sw == 1 && (!has_occ || a.ogt.sw == 1) && (((uintptr_t)a.fgt.p | (uintptr_t)a.ogt.p) & 15) == 0 &&
+                       ((a.fgt.sh | a.fgt.sc | a.fgt.sb | a.ogt.sh | a.ogt.sb) & 3) == 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float* fr = (const float*)a.fgt.p + (long)b * a.fgt.sb + (long)(4 * by + j) * a.fgt.sh + (long)(4 * bx) * a.fgt.sw;
+        const float* orow = has_occ ? (const float*)a.ogt.p + (long)b * a.ogt.sb + (long)(4 * by + j) * a.ogt.sh + (long)(4 * bx) * a.ogt.sw : nullptr;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float* src = c < 2 ? fr + (long)c * a.fgt.sc : orow;
+          if (c == 2 && !has_occ) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) gtv[j][c][k] = 0.f;
+          } else if (vec) {
+            const f32x4 v = *(const f32x4*)src;
+            gtv[j][c][0] = v[0]; gtv[j][c][1] = v[1]; gtv[j][c][2] = v[2]; gtv[j][c][3] = v[3];
+          } else {
+            const long sw = c < 2 ? a.fgt.sw : a.ogt.sw;
+#pragma unroll
+            for (int k = 0; k < 4; k++) gtv[j][c][k] = src[k * sw];
+          }
+        }
+      }
+    }
     // Sample j of a block reads rows (slot 0, slot 1) of the neighbourhood for j = 0, 1 and (slot 1, slot 2) for j = 2, 3, with the second
     // tap's weight ly = 0.625, 0.875, 0.125, 0.375 -- static register indices.  At the image border PyTorch's rule (source coordinate
     // clamped at 0; second tap clamped to the last row) puts the whole weight on the border row: the weights are folded onto slot 1 there.
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int Y = 4 * by + j;
       constexpr float LY[4] = {0.625f, 0.875f, 0.125f, 0.375f};
       const int rA = j < 2 ? 0 : 1, rB = rA + 1;
       float hB = LY[j], hA = 1.f - LY[j];
       if (j < 2 && by == 0) { hA = 0.f; hB = 1.f; }
       if (j >= 2 && by == a.h - 1) { hA = 1.f; hB = 0.f; }
-      const float* fg0 = (const float*)a.fgt.p + (long)b * a.fgt.sb + (long)Y * a.fgt.sh;
-      const float* og = has_occ ? (const float*)a.ogt.p + (long)b * a.ogt.sb + (long)Y * a.ogt.sh : nullptr;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int X = 4 * bx + k;
         const int cA = k < 2 ? 0 : 1, cB = cA + 1;
         float wB = LY[k], wA = 1.f - LY[k];
         if (k < 2 && bx == 0) { wA = 0.f; wB = 1.f; }
@@ -78,18 +102,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const Args a) {
         for (int c = 0; c < 2; c++) {
           // (the order of the framework's kernel: h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11))
           const float p = hA * (wA * nf[rA][cA][c] + wB * nf[rA][cB][c]) + hB * (wA * nf[rB][cA][c] + wB * nf[rB][cB][c]);
-          const float t = fg0[(long)c * a.fgt.sc + (long)X * a.fgt.sw];
+          const float t = gtv[j][c][k];
           const float d = p - t;
-          l1 += (double)fabsf(d);
+          l1f += fabsf(d);
           dpred[c] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         }
         dpred[2] = 0.f;
         if (has_occ) {
           const float p = hA * (wA * nf[rA][cA][2] + wB * nf[rA][cB][2]) + hB * (wA * nf[rB][cA][2] + wB * nf[rB][cB][2]);
-          const float t = og[(long)X * a.ogt.sw];
-          const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);  // (F.binary_cross_entropy clamps the logs at -100)
-          bce += (double)(-(t * lp + (1.f - t) * lq));
-          dpred[2] = (p - t) / fmaxf((1.f - p) * p, 1e-12f);
+          const float t = gtv[j][2][k];
+          // (F.binary_cross_entropy clamps the logs at -100; v_log_f32 / v_rcp_f32: 1 ulp, the kernel was bound by the libm sequences)
+          const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.f - p), -100.f);
+          bcef -= t * lp + (1.f - t) * lq;
+          dpred[2] = (p - t) * __frcp_rn(fmaxf((1.f - p) * p, 1e-12f));
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -100,14 +125,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const Args a) {
         }
       }
     }
-    if (a.part) {
-      float* o = a.part + (long)i * 27;
+    l1 = (double)l1f;
+    bce = (double)bcef;
+    if (a.part) {  // planar [27][pixels]: every store instruction of a wave is one contiguous 256-byte run (pixel-major rows of 27 floats were
+      float* o = a.part + i;  // 27 stores of 64 scattered lines each: 55 us for this kernel)
 #pragma unroll
       for (int dy = 0; dy < 3; dy++)
 #pragma unroll
         for (int dx = 0; dx < 3; dx++)
 #pragma unroll
-          for (int c = 0; c < 3; c++) o[(dy * 3 + dx) * 3 + c] = g[dy][dx][c];
+          for (int c = 0; c < 3; c++) o[(long)((dy * 3 + dx) * 3 + c) * npx] = g[dy][dx][c];
     }
   }
   l1 = wave_sum_d(l1);
@@ -139,8 +166,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       // the block at (y - dy, x - dx) holds this pixel in its neighbourhood slot (dy + 1, dx + 1)
       const int yy = y - dy, xx = x - dx;
       if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-      const float* p = part + ((long)(b * h + yy) * w + xx) * 27 + ((dy + 1) * 3 + (dx + 1)) * 3;
-      s[0] += p[0]; s[1] += p[1]; s[2] += p[2];
+      const float* p = part + (long)(((dy + 1) * 3 + (dx + 1)) * 3) * npx + ((long)(b * h + yy) * w + xx);
+      s[0] += p[0]; s[1] += p[npx]; s[2] += p[2 * (long)npx];
     }
   const float gf = go_flow ? *go_flow * inv_nf : 0.f, go = go_occ ? *go_occ * inv_no : 0.f;
   if (gflow.p) {
