@@ -382,6 +382,14 @@ int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64
  * replaces: F.conv2d / the input half of its autograd for that layer [the library: 54 us forward, 57 + 17 us input gradient at 16 x 218 x 512] */
 int ocf_conv3x3_c16(const ocf_tensor4* x, const void* w, int64_t w_so, int64_t w_si, int64_t w_sky, int64_t w_skx, int w_is_f32,
                     const ocf_tensor4* y, int B, int H, int W, int transpose, int dtype, void* stream);
+/* weight gradient of that layer: gw (fp32 [16][16][3][3], element strides, ADDED to: zeroed by the caller; block sums through `workspace`,
+ * no atomics) += sum over
+ * pixels of gy[px][o] * x[px + tap][i]; x, gy as above.  replaces: the weight half of the layer's autograd [the library: 106 us + a fill
+ * and a cast launch] */
+int ocf_conv3x3_c16_wgrad_workspace_bytes(int B, int H, int W, int64_t* bytes);
+int ocf_conv3x3_c16_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t g_so, int64_t g_si, int64_t g_sky, int64_t g_skx,
+                          void* workspace /* ocf_conv3x3_c16_wgrad_workspace_bytes(), any contents */, int B, int H, int W, int dtype,
+                          void* stream);
 
 /* ---- the two images of a pair as one bf16 channels_last batch: x fp32 [B, 6, H, W] (any strides; channels 0-2 / 3-5 = the two images),
  * out bf16 dense channels_last [2B, 3, H, W] (8-byte aligned): out[b] = x[b, 0:3], out[B + b] = x[b, 3:6], rounded to bf16.

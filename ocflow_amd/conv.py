@@ -621,7 +621,20 @@ class _ConvC16Fn(Function):
             gg = gg.contiguous(memory_format=torch.channels_last)
         gx = _c16_raw(gg, weight, True) if ctx.needs_input_grad[0] else None
         gw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and os.environ.get("OCFLOW_NATIVE_C16_WGRAD", "1") != "0" and _pixel_major(x, 16):
+            acc, sink = _grad_target(weight, gy.device)  # fp32, zeroed (or the stepper's flat gradient buffer)
+            B, _, H, W = x.shape
+            so, si, sky, skx = acc.stride()
+            nb = C.c_int64(0)
+            _lib.check(_lib.load().ocf_conv3x3_c16_wgrad_workspace_bytes(B, H, W, C.byref(nb)), "ocf_conv3x3_c16_wgrad_workspace_bytes")
+            ws = torch.empty(nb.value, device=x.device, dtype=torch.uint8)
+            with torch.cuda.device(x.device):
+                fn = lambda: _lib.check(_lib.load().ocf_conv3x3_c16_wgrad(_t4(x), _t4(gg), C.c_void_p(acc.data_ptr()), so, si, sky, skx,
+                                                                          C.c_void_p(ws.data_ptr()), B, H, W, _lib.OCF_BF16, _stream(x)),
+                                        "ocf_conv3x3_c16_wgrad")
+                ops._launch("conv3x3_c16_wgrad", lambda: ops._meta(f"B{B}x16->16x{H}x{W}", B * H * W * 64, 2 * B * H * W * 9 * 256), fn)
+            gw = None if sink else acc
+        elif ctx.needs_input_grad[1]:
             ggc = gg if gg.is_contiguous(memory_format=torch.channels_last) else gg.contiguous(memory_format=torch.channels_last)
             xc = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
             gw = torch.ops.aten.convolution_backward(ggc, xc, _shape_like(weight, 16), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,

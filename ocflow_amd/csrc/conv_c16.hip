@@ -100,6 +100,178 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const Args a) {
 }  // namespace c16
 }  // namespace ocf
 
+namespace ocf {
+namespace c16 {
+// ---- weight gradient of the same layer: dW[o][i][ky][kx] = sum_px gy[px][o] * x[px + (ky-1, kx-1)][i].  GEMM view: M = o, N = i, K = pixels,
+// once per tap -- and a matrix-core fragment wants 8 consecutive PIXELS of one channel while both tensors are pixel-major.  The transpose
+// is done by the LDS WRITES: a block owns a strip of 128 columns of one image and walks down its rows; each step stages ONE new row of x and
+// one row of gy, every thread scattering the channels of two neighbouring pixels into channel-major LDS rows (32-bit writes).  The three most recent x rows stay in a ring
+// (each row is read from memory once).  Wave w contracts pixels 32 w .. 32 w + 31 of the strip: per row one A fragment (gy), nine B
+// fragments, nine v_mfma_f32_16x16x32_bf16 into nine accumulators that live for the whole walk; every wave ends by writing its sums to a
+// workspace row, which a second launch totals into the fp32 gradient.  The next row's global loads are issued before the
+// current row is computed.  (The library: 106 us + a fill and a cast launch at 16 x 218 x 512.)
+constexpr int SW = 128, PITCH = SW + 8;  // strip width; gy LDS row pitch in elements (272 bytes: the 16 channel rows of a fragment read tile all 64 banks)
+constexpr int XH = 8, XPITCH = SW + 2 * XH + 8;  // x rows: 8 halo pixels on either side (fragment bases stay 16-byte aligned), pitch 304 bytes
+
+struct WArgs {
+  const char* x;   // [B][H][W][xp] bf16
+  const char* gy;  // [B][H][W][gp] bf16
+  float* ws;       // [blocks][4 waves][2304] wave sums
+  long xp, gp;
+  int B, H, W, strips, ysegs, rows_per_seg;
+};
+
+// ONE channel-major copy of every x row (ring of three rows), written as 32-bit pairs of neighbouring pixels; the fragments of the taps
+// kx = 0 / 2 (pixel shift -1 / +1) are assembled in registers from the aligned 16-byte read of the centre fragment and the 32-bit words
+// before / after it (v_alignbyte).  (Three shifted copies written with ds_write_b16 -- 32 LDS write instructions per thread and row --
+// made the kernel LDS-write bound: 80 us.)
+__global__ __launch_bounds__(256) void conv3x3_c16_wgrad_kernel(const WArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_gy[16 * PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned short s_x[3][16 * XPITCH];  // [ring slot][channel][XH + strip pixel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kg = lane >> 4;
+  int bid = blockIdx.x;
+  const int strip = bid % a.strips; bid /= a.strips;
+  const int seg = bid % a.ysegs, b = bid / a.ysegs;
+  const int px0 = strip * SW, y_begin = seg * a.rows_per_seg, y_end = min(a.H, y_begin + a.rows_per_seg);
+  const char* xb = a.x + (long)b * a.H * a.W * a.xp * 2;
+  const char* gb = a.gy + (long)b * a.H * a.W * a.gp * 2;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // staging items = (pixel pair, channel half).  x: pairs q = 0..65 <-> pixels px0 - 2 + 2q, +1 (threads 0..131); gy: pairs 0..63 <->
+  // pixels px0 + 2q, +1 (threads 128..255)
+  const bool does_x = tid < 132, does_g = tid >= 128;
+  const int xq = tid >> 1, xhalf = tid & 1, gq = (tid - 128) >> 1, ghalf = tid & 1;
+  auto load_px = [&](const char* base, long pitch, int row, int gx, int half) -> u32x4 {
+    const bool ok = row >= 0 && row < a.H && gx >= 0 && gx < a.W;
+    return ok ? *(const u32x4*)(base + (((long)row * a.W + gx) * pitch + half * 8) * 2) : zero4;
+  };
+  auto put_pair = [&](unsigned short* dst_row0, int pitch, int q_elem, const u32x4& v0, const u32x4& v1) {
+    // channel j of both pixels -> one 32-bit word at [half * 8 + j][q_elem, q_elem + 1]
+    const unsigned w0[4] = {v0[0], v0[1], v0[2], v0[3]}, w1[4] = {v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const unsigned lo = (w0[j >> 1] >> ((j & 1) * 16)) & 0xffffu, hi = (w1[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+      *(unsigned*)(dst_row0 + j * pitch + q_elem) = lo | (hi << 16);
+    }
+  };
+  auto stage_x = [&](int slot, const u32x4& v0, const u32x4& v1) {
+    if (does_x) put_pair(&s_x[slot][(xhalf * 8) * XPITCH], XPITCH, XH - 2 + 2 * xq, v0, v1);
+  };
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: x rows y_begin - 1 and y_begin into the ring
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int row = y_begin - 1 + r, slot = (row + 3) % 3;
+    if (does_x) stage_x(slot, load_px(xb, a.xp, row, px0 - 2 + 2 * xq, xhalf), load_px(xb, a.xp, row, px0 - 1 + 2 * xq, xhalf));
+  }
+  u32x4 nx0 = zero4, nx1 = zero4, ng0 = zero4, ng1 = zero4;
+  if (does_x) { nx0 = load_px(xb, a.xp, y_begin + 1, px0 - 2 + 2 * xq, xhalf); nx1 = load_px(xb, a.xp, y_begin + 1, px0 - 1 + 2 * xq, xhalf); }
+  if (does_g) { ng0 = load_px(gb, a.gp, y_begin, px0 + 2 * gq, ghalf); ng1 = load_px(gb, a.gp, y_begin, px0 + 2 * gq + 1, ghalf); }
+  // (raw barriers: __syncthreads() would also wait for the prefetched global loads)
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int y = y_begin; y < y_end; y++) {
+    lds_barrier();  // the previous row's fragment reads are done (gy buffer and the ring slot about to be overwritten)
+    stage_x((y + 1) % 3, nx0, nx1);
+    if (does_g) put_pair(&s_gy[(ghalf * 8) * PITCH], PITCH, 2 * gq, ng0, ng1);
+    if (y + 1 < y_end) {  // next step's loads in flight during this step's matrix work
+      if (does_x) { nx0 = load_px(xb, a.xp, y + 2, px0 - 2 + 2 * xq, xhalf); nx1 = load_px(xb, a.xp, y + 2, px0 - 1 + 2 * xq, xhalf); }
+      if (does_g) { ng0 = load_px(gb, a.gp, y + 1, px0 + 2 * gq, ghalf); ng1 = load_px(gb, a.gp, y + 1, px0 + 2 * gq + 1, ghalf); }
+    }
+    lds_barrier();
+    const bf16x8 af = *(const bf16x8*)(s_gy + n * PITCH + 32 * wave + 8 * kg);  // A[m = o][k = pixel]
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const unsigned short* xr = s_x[(y + ky - 1 + 3) % 3] + n * XPITCH + XH + 32 * wave + 8 * kg;  // B[k = pixel][n = i]
+      const u32x4 cur = *(const u32x4*)xr;
+      const unsigned prv = *(const unsigned*)(xr - 2), nxt = *(const unsigned*)(xr + 8);
+      const u32x4 left = {__builtin_amdgcn_alignbyte(cur[0], prv, 2), __builtin_amdgcn_alignbyte(cur[1], cur[0], 2),
+                          __builtin_amdgcn_alignbyte(cur[2], cur[1], 2), __builtin_amdgcn_alignbyte(cur[3], cur[2], 2)};   // x[pixel - 1]
+      const u32x4 right = {__builtin_amdgcn_alignbyte(cur[1], cur[0], 2), __builtin_amdgcn_alignbyte(cur[2], cur[1], 2),
+                           __builtin_amdgcn_alignbyte(cur[3], cur[2], 2), __builtin_amdgcn_alignbyte(nxt, cur[3], 2)};     // x[pixel + 1]
+      acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, left), acc[ky * 3 + 0], 0, 0, 0);
+      acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, cur), acc[ky * 3 + 1], 0, 0, 0);
+      acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, right), acc[ky * 3 + 2], 0, 0, 0);
+    }
+  }
+  // D[m = o = 4 kg + r][n = i] of this wave -> its workspace row (e = tap * 256 + o * 16 + i); a second, tiny launch totals the rows.
+  // (One atomic per (block, weight) measured 134 us for the whole kernel: the atomics of one cache line serialise.)
+  float* wrow = a.ws + ((long)blockIdx.x * 4 + wave) * 2304;
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) wrow[t * 256 + (4 * kg + r) * 16 + n] = acc[t][r];
+}
+
+// totals of the workspace rows: blockIdx.x = 256 of the 2304 weights (e = tap * 256 + o * 16 + i), blockIdx.y = a slice of the rows; one
+// float atomic per (slice, weight).  (One thread per weight walking all 2048 rows was 4 loads in flight x 512 dependent rounds: ~150 us.)
+__global__ __launch_bounds__(256) void conv3x3_c16_wgrad_total_kernel(const float* __restrict__ ws, int nrows, float* gw, long so, long si,
+                                                                      long sky, long skx) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int per = (nrows + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = min(nrows, k0 + per);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = k0;
+  for (; k + 7 < k1; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] += ws[(long)(k + u) * 2304 + e];
+  }
+  for (; k < k1; k++) v[0] += ws[(long)k * 2304 + e];
+  const int t = e >> 8, oi = e & 255, o = oi >> 4, i = oi & 15;
+  if (k1 > k0) atomicAdd(gw + o * so + i * si + (t / 3) * sky + (t % 3) * skx, ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+}
+}  // namespace c16
+}  // namespace ocf
+
+static void c16_wgrad_geometry(int B, int H, int W, int* strips, int* ysegs, int* rows_per_seg) {
+  *strips = (W + ocf::c16::SW - 1) / ocf::c16::SW;
+  // enough blocks for two per CU, at least 16 rows each
+  int ys = (int)((512 + (long)B * *strips - 1) / ((long)B * *strips));
+  if (ys > (H + 15) / 16) ys = (H + 15) / 16;
+  if (ys < 1) ys = 1;
+  *rows_per_seg = (H + ys - 1) / ys;
+  *ysegs = (H + *rows_per_seg - 1) / *rows_per_seg;
+}
+
+extern "C" int ocf_conv3x3_c16_wgrad_workspace_bytes(int B, int H, int W, int64_t* bytes) {
+  if (B <= 0 || H <= 0 || W <= 0 || !bytes) return OCF_EINVAL;
+  int strips, ysegs, rps;
+  c16_wgrad_geometry(B, H, W, &strips, &ysegs, &rps);
+  *bytes = (int64_t)B * strips * ysegs * 4 * 2304 * sizeof(float);
+  return OCF_OK;
+}
+
+extern "C" int ocf_conv3x3_c16_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t g_so, int64_t g_si, int64_t g_sky,
+                                     int64_t g_skx, void* workspace, int B, int H, int W, int dtype, void* stream) {
+  using namespace ocf;
+  clear_stale_error();
+  if (!x || !gy || !gw || !workspace || !x->data || !gy->data || B <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  if (dtype != OCF_BF16) return OCF_EUNSUPPORTED;
+  auto pitch = [&](const ocf_tensor4* t) { return W > 1 ? t->sw : (H > 1 ? t->sh : (B > 1 ? t->sb : (int64_t)16)); };
+  auto ok = [&](const ocf_tensor4* t) {
+    const int64_t p = pitch(t);
+    return t->sc == 1 && p >= 16 && p % 8 == 0 && (H == 1 || t->sh == p * W) && (B == 1 || t->sb == p * W * H) && (uintptr_t)t->data % 16 == 0;
+  };
+  if (!ok(x) || !ok(gy)) return OCF_EUNSUPPORTED;
+  c16::WArgs a;
+  a.x = (const char*)x->data; a.gy = (const char*)gy->data;
+  a.xp = pitch(x); a.gp = pitch(gy); a.B = B; a.H = H; a.W = W;
+  c16_wgrad_geometry(B, H, W, &a.strips, &a.ysegs, &a.rows_per_seg);
+  a.ws = (float*)workspace;
+  const long blocks = (long)B * a.strips * a.ysegs;
+  if (blocks > 0x7fffffffL) return OCF_EUNSUPPORTED;
+  LaunchProf lp;
+  lp.launch(false, c16::conv3x3_c16_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  lp.launch(true, c16::conv3x3_c16_wgrad_total_kernel, dim3(9, 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)blocks * 4, gw,
+            (long)g_so, (long)g_si, (long)g_sky, (long)g_skx);
+  return launch_status();
+}
+
 extern "C" int ocf_conv3x3_c16(const ocf_tensor4* x, const void* w, int64_t w_so, int64_t w_si, int64_t w_sky, int64_t w_skx, int w_is_f32,
                                const ocf_tensor4* y, int B, int H, int W, int transpose, int dtype, void* stream) {
   using namespace ocf;

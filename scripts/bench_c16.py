@@ -38,4 +38,15 @@ for B, H, W in ((16, 218, 512), (16, 109, 256)):
     t = [timeit(lambda: conv._c16_raw(x, w, False)), timeit(lambda: torch.ops.aten.convolution(x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1)),
          timeit(lambda: conv._c16_raw(gy, w, True)),
          timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [True, False, False]))]
+    gw = torch.zeros(16, 16, 3, 3, device=dev)
+    wsb = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
+    from ocflow_amd import _lib
+    from ocflow_amd.ops import _t4
+    import ctypes as C
+    def wg():
+        so, si, sky, skx = gw.stride()
+        _lib.check(_lib.load().ocf_conv3x3_c16_wgrad(_t4(x), _t4(gy), C.c_void_p(gw.data_ptr()), so, si, sky, skx, C.c_void_p(wsb.data_ptr()), B, H, W, _lib.OCF_BF16,
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "wgrad")
+    tw = [timeit(wg), timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False]))]
+    print(f"   wgrad ours {tw[0]:.1f} lib {tw[1]:.1f} us")
     print(f"{B}x16x{H}x{W}: fwd ours {t[0]:.1f} lib {t[1]:.1f} | dgrad ours {t[2]:.1f} lib {t[3]:.1f} us", flush=True)

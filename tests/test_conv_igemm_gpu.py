@@ -287,7 +287,7 @@ def test_packed_weights_follow_a_fused_optimizer_step(conv, dt):
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16], ids=["w32", "w16"])
-@pytest.mark.parametrize("B,H,W", [(2, 9, 37), (1, 1, 1), (3, 20, 16), (16, 218, 512), (1, 5, 130)])
+@pytest.mark.parametrize("B,H,W", [(2, 9, 37), (1, 1, 1), (3, 20, 16), (16, 218, 512), (1, 5, 130), (2, 40, 300), (1, 33, 128)])
 def test_c16_direct_kernel_forward_and_input_gradient(B, H, W, wdt):
     """ocf_conv3x3_c16 (the encoder's 16 -> 16 layer: B fragments straight from global memory) against the framework's fp32 convolution on
     the same bf16-rounded operands: forward 1e-2, input gradient 1e-2 (one bf16 rounding of an fp32 accumulation), partial 16-pixel
@@ -311,4 +311,4 @@ def test_c16_direct_kernel_forward_and_input_gradient(B, H, W, wdt):
     yr.backward(gy.float())
     _close(y, yr, "forward")
     _close(xd.grad, xr.grad, "input gradient")
-    assert _l2(m.weight.grad, wr.grad) < 1e-2
+    assert _l2(m.weight.grad, wr.grad) < 2e-3, _l2(m.weight.grad, wr.grad)  # (ocf_conv3x3_c16_wgrad: fp32 accumulation of bf16 products)
