@@ -647,3 +647,51 @@ class _ConvC16Fn(Function):
 def conv3x3_c16(x, weight):
     """`F.conv2d(x, weight, None, 1, 1)` for the 16 -> 16 layer; the caller checks `c16_eligible` first"""
     return _ConvC16Fn.apply(x, weight)
+
+
+# ---- the encoder's first layer (3 -> 16, stride 2): forward on csrc/conv_c16.hip's c3 kernel, weight gradient from the framework
+
+def c3_eligible(x, conv) -> bool:
+    w = conv.weight
+    if not (enabled() and os.environ.get("OCFLOW_NATIVE_C3", "1") != "0" and conv.bias is None):
+        return False
+    if tuple(w.shape) != (16, 3, 3, 3) or tuple(conv.stride) != (2, 2) or tuple(conv.padding) != (1, 1) or tuple(conv.dilation) != (1, 1) \
+            or conv.groups != 1 or conv.padding_mode != "zeros" or w.dtype not in (torch.bfloat16, torch.float32):
+        return False
+    return (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 3 and not x.requires_grad
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _ConvC3Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        B, _, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, 16, Ho, Wo), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        so, si, sky, skx = weight.stride()
+        with torch.cuda.device(x.device):
+            fn = lambda: _lib.check(_lib.load().ocf_conv3x3s2_c3(_t4(x), C.c_void_p(weight.data_ptr()), so, si, sky, skx,
+                                                                 int(weight.dtype == torch.float32), _t4(y), B, H, W, _lib.OCF_BF16, _stream(x)),
+                                    "ocf_conv3x3s2_c3")
+            ops._launch("conv3x3s2_c3", lambda: ops._meta(f"B{B}x3->16x{H}x{W}", B * (H * W * 6 + Ho * Wo * 32), 2 * B * Ho * Wo * 27 * 16), fn)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gg = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
+            gg = gg if gg.is_contiguous(memory_format=torch.channels_last) else gg.contiguous(memory_format=torch.channels_last)
+            gw = torch.ops.aten.convolution_backward(gg, x, _shape_like(weight, 3), None, (2, 2), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     [False, True, False])[1]
+            if gw.dtype != weight.dtype:
+                gw = gw.to(weight.dtype)
+        return None, gw
+
+
+def conv3x3s2_c3(x, weight):
+    """`F.conv2d(x, weight, None, 2, 1)` for the encoder's first layer; the caller checks `c3_eligible` first"""
+    return _ConvC3Fn.apply(x, weight)

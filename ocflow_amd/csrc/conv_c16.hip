@@ -272,6 +272,125 @@ extern "C" int ocf_conv3x3_c16_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy
   return launch_status();
 }
 
+namespace ocf {
+namespace c3 {
+// ---- the encoder's FIRST layer: Conv2d(3, 16, 3, stride 2, padding 1, bias=False) on the bf16 channels_last image pair batch (6-byte
+// pixels).  A tap ROW of an output pixel is 3 neighbouring input pixels x 3 channels = 9 CONTIGUOUS bf16; K is laid out as (row ky, 16
+// slots: 9 values + 7 zeros), i.e. 48 -> two 32-wide chunks, so that a lane's 8 K-values are one (unaligned) 16-byte load of a row
+// (slots 0-7) or its ninth value alone (slot 8): two loads and two v_mfma_f32_16x16x32_bf16 per 16 output pixels, no LDS for the pixels.
+// (The library: igemm_fwd 55 us + a 16 us fill of the output at 16 x 3 x 436 x 1024.)
+struct __attribute__((packed, aligned(2))) U16B { u32x4 v; };
+struct Args {
+  const char* x;  // [B][H][W][3] bf16 dense
+  char* y;        // [B][Ho][Wo][yp] bf16
+  const void* w;  // [16][3][3][3], element strides so / si / sky / skx, bf16 or fp32
+  long so, si, sky, skx, yp;
+  int B, H, W, Ho, Wo, w_f32, gpr;
+};
+
+__device__ __forceinline__ float wval(const Args& a, int o, int i, int ky, int kx) {
+  const long off = o * a.so + i * a.si + ky * a.sky + kx * a.skx;
+  const float v = a.w_f32 ? ((const float*)a.w)[off] : (float)((const bf16*)a.w)[off];
+  return (float)(bf16)v;
+}
+
+__global__ __launch_bounds__(256) void conv3x3s2_c3_kernel(const Args a) {
+  __shared__ bf16x8 s_w[2][64];
+  const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
+  for (int t = threadIdx.x; t < 128; t += 256) {
+    const int c = t >> 6, l = t & 63, m = l & 15, g4 = l >> 4;
+    const int ky = 2 * c + (g4 >> 1), e0 = (g4 & 1) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int e = e0 + j;  // slot of row ky: e = kx * 3 + ci for e < 9
+      v[j] = (bf16)((ky < 3 && e < 9) ? wval(a, m, e % 3, ky, e / 3) : 0.f);
+    }
+    s_w[c][l] = v;
+  }
+  __syncthreads();
+  const bf16x8 wa0 = s_w[0][lane], wa1 = s_w[1][lane];
+  // a block owns four consecutive output rows of one image (wave = row) and sweeps them left to right: the input rows two neighbouring
+  // output rows share come from L1
+  const int tiles_y = (a.Ho + 3) >> 2;
+  const int b = blockIdx.x / tiles_y, oy = (blockIdx.x - b * tiles_y) * 4 + (threadIdx.x >> 6);
+  if (oy >= a.Ho) return;
+  const char* xb = a.x + (long)b * a.H * a.W * 6;
+  const long row_bytes = (long)a.W * 6;
+  for (int xg = 0; xg < a.gpr; xg += 2) {
+    u32x4 bq[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int ox = (xg + u < a.gpr ? xg + u : xg) * 16 + n;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int ky = 2 * c + (kg >> 1);
+        const int iy = 2 * oy + ky - 1;
+        const long e0 = (long)(2 * ox - 1) * 3 + (kg & 1) * 8;  // first element of this lane's 8 slots within the input row
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ky < 3 && iy >= 0 && iy < a.H && ox < a.Wo) {
+          const char* src = xb + (long)iy * row_bytes + e0 * 2;
+          if ((kg & 1) == 0) {
+            // slots 0..7 = elements (2ox-1)*3 .. +7: whole row interior -> one unaligned 16-byte load; at the borders element by element
+            if (ox > 0 && (2 * ox + 1) * 3 + 2 < (long)a.W * 3 + 0 && e0 * 2 + 16 <= row_bytes) {
+              v = ((const U16B*)src)->v;
+            } else {
+              unsigned short ev[8];
+#pragma unroll
+              for (int j = 0; j < 8; j++) {
+                const long e = e0 + j;
+                ev[j] = (e >= 0 && e < (long)a.W * 3) ? *(const unsigned short*)(xb + (long)iy * row_bytes + e * 2) : (unsigned short)0;
+              }
+              v = u32x4{(unsigned)ev[0] | ((unsigned)ev[1] << 16), (unsigned)ev[2] | ((unsigned)ev[3] << 16), (unsigned)ev[4] | ((unsigned)ev[5] << 16),
+                        (unsigned)ev[6] | ((unsigned)ev[7] << 16)};
+            }
+          } else {
+            // slot 8 = channel 2 of pixel 2ox+1 (if inside the image); slots 9..15 are padding
+            const long e = e0;  // = (2ox-1)*3 + 8
+            if (e < (long)a.W * 3) v[0] = *(const unsigned short*)src;
+          }
+        }
+        bq[u][c] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int ox = (xg + u) * 16 + n;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa0, __builtin_bit_cast(bf16x8, bq[u][0]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1, __builtin_bit_cast(bf16x8, bq[u][1]), acc, 0, 0, 0);
+      if (xg + u < a.gpr && ox < a.Wo) {
+        const bf16x2 lo = {(bf16)acc[0], (bf16)acc[1]}, hi = {(bf16)acc[2], (bf16)acc[3]};
+        *(u32x2*)(a.y + ((((long)b * a.Ho + oy) * a.Wo + ox) * a.yp + 4 * kg) * 2) = u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+      }
+    }
+  }
+}
+}  // namespace c3
+}  // namespace ocf
+
+extern "C" int ocf_conv3x3s2_c3(const ocf_tensor4* x, const void* w, int64_t w_so, int64_t w_si, int64_t w_sky, int64_t w_skx, int w_is_f32,
+                                const ocf_tensor4* y, int B, int H, int W, int dtype, void* stream) {
+  using namespace ocf;
+  clear_stale_error();
+  if (!x || !y || !w || !x->data || !y->data || B <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  if (dtype != OCF_BF16) return OCF_EUNSUPPORTED;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;  // floor((H + 2 - 3) / 2) + 1
+  // x: dense channels_last [B,3,H,W]; y: pixel-major [B,16,Ho,Wo] with 8-byte aligned pixels
+  if (!(x->sc == 1 && (W == 1 || x->sw == 3) && (H == 1 || x->sh == 3L * W) && (B == 1 || x->sb == 3L * W * H))) return OCF_EUNSUPPORTED;
+  const int64_t yp = Wo > 1 ? y->sw : (Ho > 1 ? y->sh : (B > 1 ? y->sb : (int64_t)16));
+  if (!(y->sc == 1 && yp >= 16 && yp % 4 == 0 && (Ho == 1 || y->sh == yp * Wo) && (B == 1 || y->sb == yp * Wo * Ho) && (uintptr_t)y->data % 8 == 0))
+    return OCF_EUNSUPPORTED;
+  c3::Args a;
+  a.x = (const char*)x->data; a.y = (char*)y->data; a.w = w; a.so = w_so; a.si = w_si; a.sky = w_sky; a.skx = w_skx; a.yp = yp;
+  a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.w_f32 = w_is_f32; a.gpr = (Wo + 15) / 16;
+  const long blocks = (long)B * ((Ho + 3) / 4);
+  if (blocks > 0x7fffffffL || (long)H * W * 6 >= (1L << 40)) return OCF_EUNSUPPORTED;
+  LaunchProf lp;
+  lp.launch(true, c3::conv3x3s2_c3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
 extern "C" int ocf_conv3x3_c16(const ocf_tensor4* x, const void* w, int64_t w_so, int64_t w_si, int64_t w_sky, int64_t w_skx, int w_is_f32,
                                const ocf_tensor4* y, int B, int H, int W, int transpose, int dtype, void* stream) {
   using namespace ocf;

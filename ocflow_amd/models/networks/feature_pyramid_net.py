@@ -48,7 +48,11 @@ class DoubleConv(nn.Module):
 
     def forward(self, x, groups: int = 1):
         s = self.double_conv
-        x = _bn_act(s[1], s[2], s[0](x), groups)
+        if not torch.compiler.is_compiling() and os.environ.get("OCFLOW_NATIVE_FPN", "1") != "0" and nconv.c3_eligible(x, s[0]):
+            h = nconv.conv3x3s2_c3(x, s[0].weight)  # the first layer (3 -> 16, stride 2) on the direct matrix-core kernel
+        else:
+            h = s[0](x)
+        x = _bn_act(s[1], s[2], h, groups)
         return _bn_act(s[4], s[5], _conv3x3_same(s[3], x), groups)
 
 

@@ -312,3 +312,30 @@ def test_c16_direct_kernel_forward_and_input_gradient(B, H, W, wdt):
     _close(y, yr, "forward")
     _close(xd.grad, xr.grad, "input gradient")
     assert _l2(m.weight.grad, wr.grad) < 2e-3, _l2(m.weight.grad, wr.grad)  # (ocf_conv3x3_c16_wgrad: fp32 accumulation of bf16 products)
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16], ids=["w32", "w16"])
+@pytest.mark.parametrize("B,H,W", [(2, 9, 37), (1, 1, 1), (3, 20, 16), (2, 436, 1024), (1, 5, 130), (1, 2, 2), (1, 7, 33)])
+def test_c3_first_layer_forward(B, H, W, wdt):
+    """ocf_conv3x3s2_c3 (Conv2d(3, 16, 3, 2, 1) on 6-byte channels_last pixels: unaligned 16-byte row loads, K padded per tap row)
+    against the framework's fp32 convolution on the same bf16-rounded operands, odd and even sizes (left / right / bottom padding, partial
+    16-pixel groups), and the weight gradient the framework computes behind it"""
+    from ocflow_amd import conv as nconv
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, 3, H, W, generator=g).bfloat16()
+    w = (torch.randn(16, 3, 3, 3, generator=g) * 0.3).to(wdt)
+    m = torch.nn.Conv2d(3, 16, 3, 2, 1, bias=False).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(w.to(DEV))
+    m = m.to(wdt)
+    xd = _dev_cl(x)
+    assert nconv.c3_eligible(xd, m)
+    y = nconv.conv3x3s2_c3(xd, m.weight)
+    wr = w.bfloat16().float().requires_grad_(True)
+    yr = F.conv2d(x.float(), wr, None, 2, 1)
+    assert y.shape == yr.shape
+    _close(y, yr, "forward")
+    gy = torch.randn(yr.shape, generator=g).bfloat16()
+    y.backward(_dev_cl(gy))
+    yr.backward(gy.float())
+    assert _l2(m.weight.grad, wr.grad) < 1e-2
