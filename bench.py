@@ -245,7 +245,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak of an MI355X (MI355X_MI
 def kernel_rooflines(summ: dict, peak: float) -> dict:
     """per-kernel {launches, avg_us, achieved GB/s, frac} from a KernelTimer summary; the convolution kernels (names conv3x3_*: the
     estimator / context / encoder layers on the repo's implicit-GEMM kernels) are matrix-core bound and carry achieved TFLOP/s against the
-    dense bf16 MFMA peak instead"""
+    dense bf16 MFMA peak instead (the encoder's two narrow level-1 layers, enc16_* / enc3_*, are HBM-bound and stay in GB/s)"""
     out = {}
     for name, v in summ.items():
         if v["ms_total"] <= 0:

@@ -602,7 +602,7 @@ def _c16_raw(x, weight, transpose: bool):
         fn = lambda: _lib.check(_lib.load().ocf_conv3x3_c16(_t4(x), C.c_void_p(weight.data_ptr()), so, si, sky, skx,
                                                             int(weight.dtype == torch.float32), _t4(y), B, H, W, int(transpose), _lib.OCF_BF16,
                                                             _stream(x)), "ocf_conv3x3_c16")
-        ops._launch("conv3x3_c16", lambda: ops._meta(f"B{B}x16->16x{H}x{W}", B * H * W * 64, 2 * B * H * W * 9 * 256), fn)
+        ops._launch("enc16_conv", lambda: ops._meta(f"B{B}x16->16x{H}x{W}", B * H * W * 64, 2 * B * H * W * 9 * 256), fn)
     return y
 
 
@@ -632,7 +632,7 @@ class _ConvC16Fn(Function):
                 fn = lambda: _lib.check(_lib.load().ocf_conv3x3_c16_wgrad(_t4(x), _t4(gg), C.c_void_p(acc.data_ptr()), so, si, sky, skx,
                                                                           C.c_void_p(ws.data_ptr()), B, H, W, _lib.OCF_BF16, _stream(x)),
                                         "ocf_conv3x3_c16_wgrad")
-                ops._launch("conv3x3_c16_wgrad", lambda: ops._meta(f"B{B}x16->16x{H}x{W}", B * H * W * 64, 2 * B * H * W * 9 * 256), fn)
+                ops._launch("enc16_wgrad", lambda: ops._meta(f"B{B}x16->16x{H}x{W}", B * H * W * 64, 2 * B * H * W * 9 * 256), fn)
             gw = None if sink else acc
         elif ctx.needs_input_grad[1]:
             ggc = gg if gg.is_contiguous(memory_format=torch.channels_last) else gg.contiguous(memory_format=torch.channels_last)
@@ -673,7 +673,7 @@ class _ConvC3Fn(Function):
             fn = lambda: _lib.check(_lib.load().ocf_conv3x3s2_c3(_t4(x), C.c_void_p(weight.data_ptr()), so, si, sky, skx,
                                                                  int(weight.dtype == torch.float32), _t4(y), B, H, W, _lib.OCF_BF16, _stream(x)),
                                     "ocf_conv3x3s2_c3")
-            ops._launch("conv3x3s2_c3", lambda: ops._meta(f"B{B}x3->16x{H}x{W}", B * (H * W * 6 + Ho * Wo * 32), 2 * B * Ho * Wo * 27 * 16), fn)
+            ops._launch("enc3_conv_s2", lambda: ops._meta(f"B{B}x3->16x{H}x{W}", B * (H * W * 6 + Ho * Wo * 32), 2 * B * Ho * Wo * 27 * 16), fn)
         ctx.save_for_backward(x, weight)
         return y
 
