@@ -394,9 +394,15 @@ int ocf_conv3x3_c16_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw
 /* ---- the encoder's first layer: Conv2d(3, 16, 3, stride 2, padding 1, bias=False) (feature_pyramid_net.py:21-33 `layer1.double_conv.0`),
  * forward.  x: DENSE channels_last bf16 [B,3,H,W] (6-byte pixels: what ocf_pair_input writes); y: pixel-major bf16 [B,16,Ho,Wo],
  * Ho = (H - 1) / 2 + 1; w = the module's [16,3,3,3] weight (element strides, fp32 or bf16).
- * replaces: F.conv2d for that layer [the library: 55 us + a 16 us fill at 16 x 3 x 436 x 1024]; gradients stay with the framework */
+ * replaces: F.conv2d for that layer [the library: 55 us + a 16 us fill at 16 x 3 x 436 x 1024] (the input image needs no gradient) */
 int ocf_conv3x3s2_c3(const ocf_tensor4* x, const void* w, int64_t w_so, int64_t w_si, int64_t w_sky, int64_t w_skx, int w_is_f32,
                      const ocf_tensor4* y, int B, int H, int W, int dtype, void* stream);
+/* weight gradient of that layer: gw (fp32 [16][3][3][3], element strides, ADDED to) += sum over output pixels of gy[p][o] * x[2p + tap][ci];
+ * x as above, gy pixel-major bf16 [B,16,Ho,Wo] with 16-byte aligned pixels; workspace of ocf_conv3x3s2_c3_wgrad_workspace_bytes() bytes.
+ * replaces: the weight half of the layer's autograd [the library: 88 us + a fill and a cast launch] */
+int ocf_conv3x3s2_c3_wgrad_workspace_bytes(int B, int H, int W, int64_t* bytes);
+int ocf_conv3x3s2_c3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t g_so, int64_t g_si, int64_t g_sky, int64_t g_skx,
+                           void* workspace, int B, int H, int W, int dtype, void* stream);
 
 /* ---- the two images of a pair as one bf16 channels_last batch: x fp32 [B, 6, H, W] (any strides; channels 0-2 / 3-5 = the two images),
  * out bf16 dense channels_last [2B, 3, H, W] (8-byte aligned): out[b] = x[b, 0:3], out[B + b] = x[b, 3:6], rounded to bf16.

@@ -91,6 +91,8 @@ SIGNATURES = {
     "ocf_conv3x3_c16_wgrad_workspace_bytes": [_i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_conv3x3_c16_wgrad": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _i, _i, _i, _i, _vp],
     "ocf_conv3x3s2_c3": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _T4P, _i, _i, _i, _i, _vp],
+    "ocf_conv3x3s2_c3_wgrad_workspace_bytes": [_i, _i, _i, C.POINTER(C.c_int64)],
+    "ocf_conv3x3s2_c3_wgrad": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _i, _i, _i, _i, _vp],
     "ocf_adam_flat": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _f, C.c_double, C.c_double, _f, _f, _vp, _vp],
     "ocf_bias_act_fwd": [_T4P, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ocf_bias_act_bwd": [_T4P, _T4P, _T4P, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],

@@ -682,7 +682,23 @@ class _ConvC3Fn(Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and os.environ.get("OCFLOW_NATIVE_C3_WGRAD", "1") != "0":
+            gg = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
+            if not _pixel_major(gg, 16):
+                gg = gg.contiguous(memory_format=torch.channels_last)
+            acc, sink = _grad_target(weight, gy.device)
+            B, _, H, W = x.shape
+            so, si, sky, skx = acc.stride()
+            nb = C.c_int64(0)
+            _lib.check(_lib.load().ocf_conv3x3s2_c3_wgrad_workspace_bytes(B, H, W, C.byref(nb)), "ocf_conv3x3s2_c3_wgrad_workspace_bytes")
+            ws = torch.empty(nb.value, device=x.device, dtype=torch.uint8)
+            with torch.cuda.device(x.device):
+                fn = lambda: _lib.check(_lib.load().ocf_conv3x3s2_c3_wgrad(_t4(x), _t4(gg), C.c_void_p(acc.data_ptr()), so, si, sky, skx,
+                                                                           C.c_void_p(ws.data_ptr()), B, H, W, _lib.OCF_BF16, _stream(x)),
+                                        "ocf_conv3x3s2_c3_wgrad")
+                ops._launch("enc3_wgrad", lambda: ops._meta(f"B{B}x3->16x{H}x{W}", B * (H * W * 6 + gg.shape[2] * gg.shape[3] * 32), 0), fn)
+            gw = None if sink else acc
+        elif ctx.needs_input_grad[1]:
             gg = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
             gg = gg if gg.is_contiguous(memory_format=torch.channels_last) else gg.contiguous(memory_format=torch.channels_last)
             gw = torch.ops.aten.convolution_backward(gg, x, _shape_like(weight, 3), None, (2, 2), (1, 1), (1, 1), False, (0, 0), 1,

@@ -369,6 +369,174 @@ __global__ __launch_bounds__(256) void conv3x3s2_c3_kernel(const Args a) {
 }  // namespace c3
 }  // namespace ocf
 
+namespace ocf {
+namespace c3 {
+// ---- weight gradient of the first layer: dW[o][ci][ky][kx] = sum over output pixels of gy[p][o] * x[2p + (ky - 1, kx - 1)][ci].  M = o (16),
+// N = (ky, kx, ci) = 27 -> two 16-column tiles, K = output pixels.  As in the 16 -> 16 kernel a block walks down a strip of 128 output
+// columns: gy rows are scattered channel-major into LDS (aligned A fragments); the input rows stay PIXEL-major in LDS (6-byte pixels, three
+// rows alive, two new ones per step) and a B fragment -- 8 consecutive output pixels of one (ky, kx, ci) column -- is eight ds_read_u16 at
+// a 12-byte stride.  Wave sums to a workspace, a second launch totals them.  (The library: 88 us + a fill and a cast launch.)
+constexpr int SW = 128, GPITCH = SW + 8, XROW = (2 * SW + 1) * 3, XCH = (XROW * 2 + 15) / 16, XPITCH = XCH * 8;  // 97 chunks of 16 bytes per row
+
+struct WArgs {
+  const char* x;   // [B][H][W][3] bf16 dense
+  const char* gy;  // [B][Ho][Wo][gp] bf16
+  float* ws;       // [blocks][4 waves][512]
+  long gp;
+  int B, H, W, Ho, Wo, strips, ysegs, rows_per_seg;
+};
+
+__global__ __launch_bounds__(256) void conv3x3s2_c3_wgrad_kernel(const WArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_gy[16 * GPITCH];
+  __shared__ __attribute__((aligned(16))) unsigned short s_x[3][XPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kg = lane >> 4;
+  int bid = blockIdx.x;
+  const int strip = bid % a.strips; bid /= a.strips;
+  const int seg = bid % a.ysegs, b = bid / a.ysegs;
+  const int px0 = strip * SW, y_begin = seg * a.rows_per_seg, y_end = min(a.Ho, y_begin + a.rows_per_seg);
+  const char* xb = a.x + (long)b * a.H * a.W * 6;
+  const char* gb = a.gy + (long)b * a.Ho * a.Wo * a.gp * 2;
+  const long row_elems = (long)a.W * 3, e_origin = (long)(2 * px0 - 1) * 3;  // LDS element 0 of an input row = this element of the image row
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // input-row chunk `ch` (8 elements) of image row iy: whole chunks inside the row with one unaligned 16-byte load, edge chunks by element
+  auto load_xchunk = [&](int iy, int ch) -> u32x4 {
+    if (iy < 0 || iy >= a.H) return zero4;
+    const long e0 = e_origin + 8L * ch;
+    const char* rowp = xb + (long)iy * row_elems * 2;
+    if (e0 >= 0 && e0 + 8 <= row_elems) return ((const U16B*)(rowp + e0 * 2))->v;
+    unsigned short ev[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) ev[j] = (e0 + j >= 0 && e0 + j < row_elems) ? *(const unsigned short*)(rowp + (e0 + j) * 2) : (unsigned short)0;
+    return u32x4{(unsigned)ev[0] | ((unsigned)ev[1] << 16), (unsigned)ev[2] | ((unsigned)ev[3] << 16), (unsigned)ev[4] | ((unsigned)ev[5] << 16),
+                 (unsigned)ev[6] | ((unsigned)ev[7] << 16)};
+  };
+  auto load_g = [&](int oy, int ox, int half) -> u32x4 {
+    const bool ok = oy < a.Ho && ox < a.Wo;
+    return ok ? *(const u32x4*)(gb + (((long)oy * a.Wo + ox) * a.gp + half * 8) * 2) : zero4;
+  };
+  // staging roles: x = 2 rows x 97 chunks (threads 0..193: row tid / 97, chunk tid % 97); gy = 64 pixel pairs x 2 halves (threads 128..255)
+  const bool does_x = tid < 2 * XCH, does_g = tid >= 128;
+  const int xr_i = tid / XCH, xch = tid - xr_i * XCH, gq = (tid - 128) >> 1, ghalf = tid & 1;
+
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  // this lane's two B columns: nn = 16 T + n -> (ky, e = kx * 3 + ci)
+  int bky[2], be[2];
+#pragma unroll
+  for (int T = 0; T < 2; T++) {
+    const int nn = 16 * T + n;
+    bky[T] = nn < 27 ? nn / 9 : -1;
+    be[T] = nn < 27 ? nn % 9 : 0;
+  }
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // prologue: input row 2 y_begin - 1 (the previous step's second row)
+  if (tid < XCH) *(u32x4*)(s_x[(2 * y_begin - 1 + 3) % 3] + 8 * tid) = load_xchunk(2 * y_begin - 1, tid);
+  u32x4 nx = zero4, ng0 = zero4, ng1 = zero4;
+  if (does_x) nx = load_xchunk(2 * y_begin + xr_i, xch);
+  if (does_g) { ng0 = load_g(y_begin, px0 + 2 * gq, ghalf); ng1 = load_g(y_begin, px0 + 2 * gq + 1, ghalf); }
+  for (int oy = y_begin; oy < y_end; oy++) {
+    lds_barrier();
+    if (does_x) *(u32x4*)(s_x[(2 * oy + xr_i) % 3] + 8 * xch) = nx;
+    if (does_g) {
+      const unsigned w0[4] = {ng0[0], ng0[1], ng0[2], ng0[3]}, w1[4] = {ng1[0], ng1[1], ng1[2], ng1[3]};
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const unsigned lo = (w0[j >> 1] >> ((j & 1) * 16)) & 0xffffu, hi = (w1[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+        *(unsigned*)(s_gy + (ghalf * 8 + j) * GPITCH + 2 * gq) = lo | (hi << 16);
+      }
+    }
+    if (oy + 1 < y_end) {
+      if (does_x) nx = load_xchunk(2 * (oy + 1) + xr_i, xch);
+      if (does_g) { ng0 = load_g(oy + 1, px0 + 2 * gq, ghalf); ng1 = load_g(oy + 1, px0 + 2 * gq + 1, ghalf); }
+    }
+    lds_barrier();
+    const bf16x8 af = *(const bf16x8*)(s_gy + n * GPITCH + 32 * wave + 8 * kg);  // A[m = o][k = output pixel]
+#pragma unroll
+    for (int T = 0; T < 2; T++) {
+      u32x4 bv = zero4;
+      if (bky[T] >= 0) {
+        const unsigned short* xr = s_x[(2 * oy + bky[T] - 1 + 3) % 3] + 6 * (32 * wave + 8 * kg) + be[T];  // B[k][nn]: 6 elements per output pixel
+        unsigned short ev[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) ev[j] = xr[6 * j];
+        bv = u32x4{(unsigned)ev[0] | ((unsigned)ev[1] << 16), (unsigned)ev[2] | ((unsigned)ev[3] << 16), (unsigned)ev[4] | ((unsigned)ev[5] << 16),
+                   (unsigned)ev[6] | ((unsigned)ev[7] << 16)};
+      }
+      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[T], 0, 0, 0);
+    }
+  }
+  float* wrow = a.ws + ((long)blockIdx.x * 4 + wave) * 512;
+#pragma unroll
+  for (int T = 0; T < 2; T++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) wrow[T * 256 + (4 * kg + r) * 16 + n] = acc[T][r];
+}
+
+// totals: thread e = T * 256 + o * 16 + n of 512, blockIdx.y = a slice of the rows
+__global__ __launch_bounds__(256) void conv3x3s2_c3_wgrad_total_kernel(const float* __restrict__ ws, int nrows, float* gw, long so, long si,
+                                                                       long sky, long skx) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int per = (nrows + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = min(nrows, k0 + per);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  int k = k0;
+  for (; k + 3 < k1; k += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] += ws[(long)(k + u) * 512 + e];
+  }
+  for (; k < k1; k++) v[0] += ws[(long)k * 512 + e];
+  const int T = e >> 8, o = (e & 255) >> 4, nn = 16 * T + (e & 15);
+  if (nn < 27 && k1 > k0) {
+    const int ky = nn / 9, ee = nn % 9, kx = ee / 3, ci = ee % 3;
+    atomicAdd(gw + o * so + ci * si + ky * sky + kx * skx, (v[0] + v[1]) + (v[2] + v[3]));
+  }
+}
+}  // namespace c3
+}  // namespace ocf
+
+static void c3_wgrad_geometry(int B, int Ho, int Wo, int* strips, int* ysegs, int* rows_per_seg) {
+  *strips = (Wo + ocf::c3::SW - 1) / ocf::c3::SW;
+  int ys = (int)((512 + (long)B * *strips - 1) / ((long)B * *strips));
+  if (ys > (Ho + 15) / 16) ys = (Ho + 15) / 16;
+  if (ys < 1) ys = 1;
+  *rows_per_seg = (Ho + ys - 1) / ys;
+  *ysegs = (Ho + *rows_per_seg - 1) / *rows_per_seg;
+}
+
+extern "C" int ocf_conv3x3s2_c3_wgrad_workspace_bytes(int B, int H, int W, int64_t* bytes) {
+  if (B <= 0 || H <= 0 || W <= 0 || !bytes) return OCF_EINVAL;
+  int strips, ysegs, rps;
+  c3_wgrad_geometry(B, (H - 1) / 2 + 1, (W - 1) / 2 + 1, &strips, &ysegs, &rps);
+  *bytes = (int64_t)B * strips * ysegs * 4 * 512 * sizeof(float);
+  return OCF_OK;
+}
+
+extern "C" int ocf_conv3x3s2_c3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* gw, int64_t g_so, int64_t g_si, int64_t g_sky,
+                                      int64_t g_skx, void* workspace, int B, int H, int W, int dtype, void* stream) {
+  using namespace ocf;
+  clear_stale_error();
+  if (!x || !gy || !gw || !workspace || !x->data || !gy->data || B <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
+  if (dtype != OCF_BF16) return OCF_EUNSUPPORTED;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (!(x->sc == 1 && (W == 1 || x->sw == 3) && (H == 1 || x->sh == 3L * W) && (B == 1 || x->sb == 3L * W * H))) return OCF_EUNSUPPORTED;
+  const int64_t gp = Wo > 1 ? gy->sw : (Ho > 1 ? gy->sh : (B > 1 ? gy->sb : (int64_t)16));
+  if (!(gy->sc == 1 && gp >= 16 && gp % 8 == 0 && (Ho == 1 || gy->sh == gp * Wo) && (B == 1 || gy->sb == gp * Wo * Ho) && (uintptr_t)gy->data % 16 == 0))
+    return OCF_EUNSUPPORTED;
+  c3::WArgs a;
+  a.x = (const char*)x->data; a.gy = (const char*)gy->data; a.ws = (float*)workspace; a.gp = gp;
+  a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+  c3_wgrad_geometry(B, Ho, Wo, &a.strips, &a.ysegs, &a.rows_per_seg);
+  const long blocks = (long)B * a.strips * a.ysegs;
+  if (blocks > 0x7fffffffL) return OCF_EUNSUPPORTED;
+  LaunchProf lp;
+  lp.launch(false, c3::conv3x3s2_c3_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  lp.launch(true, c3::conv3x3s2_c3_wgrad_total_kernel, dim3(2, 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)blocks * 4, gw,
+            (long)g_so, (long)g_si, (long)g_sky, (long)g_skx);
+  return launch_status();
+}
+
 extern "C" int ocf_conv3x3s2_c3(const ocf_tensor4* x, const void* w, int64_t w_so, int64_t w_si, int64_t w_sky, int64_t w_skx, int w_is_f32,
                                 const ocf_tensor4* y, int B, int H, int W, int dtype, void* stream) {
   using namespace ocf;

@@ -315,7 +315,7 @@ def test_c16_direct_kernel_forward_and_input_gradient(B, H, W, wdt):
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16], ids=["w32", "w16"])
-@pytest.mark.parametrize("B,H,W", [(2, 9, 37), (1, 1, 1), (3, 20, 16), (2, 436, 1024), (1, 5, 130), (1, 2, 2), (1, 7, 33)])
+@pytest.mark.parametrize("B,H,W", [(2, 9, 37), (1, 1, 1), (3, 20, 16), (2, 436, 1024), (1, 5, 130), (1, 2, 2), (1, 7, 33), (2, 70, 600), (1, 64, 256)])
 def test_c3_first_layer_forward(B, H, W, wdt):
     """ocf_conv3x3s2_c3 (Conv2d(3, 16, 3, 2, 1) on 6-byte channels_last pixels: unaligned 16-byte row loads, K padded per tap row)
     against the framework's fp32 convolution on the same bf16-rounded operands, odd and even sizes (left / right / bottom padding, partial
@@ -338,4 +338,4 @@ def test_c3_first_layer_forward(B, H, W, wdt):
     gy = torch.randn(yr.shape, generator=g).bfloat16()
     y.backward(_dev_cl(gy))
     yr.backward(gy.float())
-    assert _l2(m.weight.grad, wr.grad) < 1e-2
+    assert _l2(m.weight.grad, wr.grad) < 2e-3, _l2(m.weight.grad, wr.grad)  # (ocf_conv3x3s2_c3_wgrad: fp32 accumulation of bf16 products)
