@@ -268,6 +268,53 @@ def kernel_rooflines(summ: dict, peak: float) -> dict:
     return out
 
 
+LINE_LIMIT = 7800  # the driver keeps an ~8.7 KB tail of stdout: a longer line is cut at the FRONT and parses as nothing (round 4)
+
+
+def compact_kernels(detail: dict) -> dict:
+    """ONE number per kernel group for the stdout line: its roofline fraction (HBM or MFMA, see `kernel_rooflines`); the
+    per-shape tables go to the side file / stderr (`write_kernel_detail`)"""
+    return {name: v["frac"] for name, v in detail.items()}
+
+
+def write_kernel_detail(detail: dict, extra: dict) -> str:
+    """per-shape tables of every kernel group -> profiles/bench_kernels_latest.json (and stderr, for the driver's log)"""
+    blob = dict(extra)
+    blob["kernels"] = detail
+    path = os.path.join(ROOT, "profiles", "bench_kernels_latest.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(blob, f, indent=1)
+    except OSError as e:
+        path = f"(not written: {e})"
+    print("[bench] kernel detail: " + json.dumps(blob), file=sys.stderr, flush=True)
+    return path
+
+
+def fit_line(line: dict, limit: int = LINE_LIMIT) -> dict:
+    """the ONE stdout line must stay parseable from the driver's tail: drop optional detail, least important first, until
+    `json.dumps(line)` fits `limit` bytes.  The contract keys, `roofline` {bound, achieved, peak, unit, frac, traffic} and
+    `cpu_baseline` {value, unit, cores, kind, sample} are never dropped."""
+    drops = [("cpu_baseline", "compute_cost_volume_levels_b1_fp32"), ("roofline", "event_regime"), ("config", "network_execution"),
+             ("roofline", "kernels"), ("roofline", "per_level"), ("cpu_baseline", "cfg3_pwc_b8_384x512"), ("roofline", "fused_op"),
+             ("distributed", None), ("cfg3", None), ("unsupervised", None)]
+    dropped = []
+    for top, key in drops:
+        if len(json.dumps(line)) <= limit:
+            break
+        if key is None:
+            if line.get(top) is not None:
+                line[top] = None
+                dropped.append(top)
+        elif isinstance(line.get(top), dict) and key in line[top]:
+            del line[top][key]
+            dropped.append(f"{top}.{key}")
+    if dropped:
+        line["dropped_for_length"] = dropped
+    return line
+
+
 _SPIN = {}
 
 
@@ -545,6 +592,7 @@ def main():
 
     # ---- roofline of the dominant hot-path kernel, from the launches of the timed region itself
     all_k = kernel_rooflines(timer.summary(), HBM_PEAK_GBPS)
+    kernel_detail = {}
     summ = timer.summary().get("corr_fwd", None)
     roofline = None
     if summ and summ["ms_total"] > 0:
@@ -558,13 +606,12 @@ def main():
                     "launches": summ["launches"], "avg_launch_us": round(1e3 * summ["ms_total"] / summ["launches"], 2),
                     "algorithmic_bytes_per_launch": int(summ["bytes_total"] / summ["launches"]),
                     "tflops": round(summ["flops_total"] / (summ["ms_total"] * 1e-3) / 1e12, 2), "per_level": per_level,
-                    "event_regime": ("eager steps enqueued behind a spin kernel: the step's kernels run back to back, as in the timed hipGraph "
-                                     "replay (dispatch-stamped HIP events, the spin kernel is outside every interval)") if (use_graph and args.preload)
-                    else ("plain eager loop" if use_graph else "the timed steps themselves")}
+                    "event_regime": ("eager steps behind a spin kernel (kernels back to back as in the timed replay; dispatch-stamped HIP events)"
+                                     if (use_graph and args.preload) else ("plain eager loop" if use_graph else "the timed steps themselves"))}
 
     if roofline is not None:
         roofline.update(pmc_traffic_per_launch())
-        roofline["kernels"] = {k: v for k, v in all_k.items() if k != "corr_fwd"}
+        kernel_detail = {k: v for k, v in all_k.items() if k != "corr_fwd"}
 
     # ---- several ranks: what RCCL saw, and what the gradient exchange costs by itself (the first multi-GPU run describes itself)
     dist_info = None
@@ -593,7 +640,7 @@ def main():
             unsup, usumm = unsupervised_leg(args, env, args.unsup_steps)
             if roofline is not None:
                 for k, v in kernel_rooflines(usumm, HBM_PEAK_GBPS).items():
-                    roofline["kernels"].setdefault(k if k not in all_k else k + "_unsupervised", v)
+                    kernel_detail.setdefault(k if k not in all_k else k + "_unsupervised", v)
                 roofline["fused_op"] = fused_op_roofline(usumm, HBM_PEAK_GBPS)
         except Exception as e:  # noqa: BLE001 - the headline numbers stay valid
             unsup = {"error": f"{type(e).__name__}: {e}"}
@@ -635,16 +682,21 @@ def main():
                        "final_loss": round(loss_val, 5),
                        "optimizer": "adam(fused)" if args.fused_adam else "adam(foreach)",
                        "weights": "fp32 masters + bf16 compute copies" if weights_master else "fp32 (autocast casts per use)",
-                       "network_execution": ("reference layers and parameters; same arithmetic, regrouped launches: "
-                                             + ("encoder of both images as one batch with two BatchNorm statistics groups"
-                                                if os.environ.get("OCFLOW_UNPAIRED_FPN", "0") != "1" else "encoder called once per image")
-                                             + "; " + ("decoder-input concatenations zero-padded to a multiple of 32 channels"
-                                                       if os.environ.get("OCFLOW_UNPADDED_CAT", "0") != "1" else "unpadded concatenations")
-                                             + " (DESIGN.md section 10)")},
+                       "network_execution": ("reference layers / parameters; "
+                                             + ("paired encoder (2 BatchNorm groups)" if os.environ.get("OCFLOW_UNPAIRED_FPN", "0") != "1"
+                                                else "encoder per image")
+                                             + ", " + ("decoder inputs padded to 32 channels" if os.environ.get("OCFLOW_UNPADDED_CAT", "0") != "1"
+                                                       else "unpadded concatenations") + " (DESIGN.md 10)")},
             "roofline": roofline, "unsupervised": unsup, "cfg3": cfg3, "cpu_baseline": cpu,
         }
         if dist_info is not None:
             line["distributed"] = dist_info
+        if roofline is not None:
+            # ONE fraction per kernel group on the line; the per-shape tables go to the side file and stderr
+            roofline["kernels"] = compact_kernels(kernel_detail)
+            roofline["kernels_detail"] = os.path.relpath(
+                write_kernel_detail(kernel_detail, {"value": line["value"], "ms_per_step": line["ms_per_step"], "corr_fwd": all_k.get("corr_fwd")}), ROOT)
+        line = fit_line(line)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
