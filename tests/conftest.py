@@ -12,6 +12,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+if os.environ.get("OCF_ABRT_TRACE_FILE"):
+    # diagnostics (tools/diag/abrt_trace.c is LD_PRELOADed): Python tracebacks of every thread into a file of their own at a fatal
+    # signal; faulthandler then restores the handler it found -- the preloaded one -- and re-raises, so the native trace follows.
+    # Run pytest with `-p no:faulthandler` (its plugin would write into the captured stderr).
+    import faulthandler
+    _FH = open(os.environ["OCF_ABRT_TRACE_FILE"] + ".python.txt", "w")
+    faulthandler.enable(file=_FH, all_threads=True)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
