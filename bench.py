@@ -366,7 +366,7 @@ def unsupervised_leg(args, env, steps):
     dt = (time.perf_counter() - t0) / steps
     loss_val = float(loss)
     timer = KernelTimer(enabled=True)
-    stepper._graph = None
+    stepper.disable_graph()
     t_e = time.perf_counter()
     stepper.step(batch, 0)
     torch.cuda.synchronize()
@@ -382,7 +382,9 @@ def unsupervised_leg(args, env, steps):
            "workload": f"FlowStageModel('flownet', occ_aware) full training step, {args.batch} x {args.height}x{args.width}, {args.dtype}"}
     if not (loss_val == loss_val and abs(loss_val) < 1e6):
         res["invalid"] = f"loss {loss_val}"
-    return res, timer.summary()
+    summ = timer.summary()
+    stepper.close()
+    return res, summ
 
 
 def fused_op_roofline(summ: dict, peak: float):
@@ -442,6 +444,7 @@ def cfg3_leg(args, env, steps):
            "workload": "FlowStageModel('pwc', occ_aware) full training step, 8 x 384x512, " + args.dtype}
     if not (float(loss) == float(loss) and abs(float(loss)) < 1e6):
         res["invalid"] = f"loss {float(loss)}"
+    stepper.close()
     return res
 
 
@@ -536,6 +539,7 @@ def main():
             print(f"[bench] rank {env.rank}: hipGraph capture failed ({failure or 'on another rank'}); using the eager loop",
                   file=sys.stderr, flush=True)
             use_graph = False
+            stepper.close()
             del stepper
             torch.cuda.empty_cache()
             stepper = build_stepper(args, env, dp_mode="ddp")
@@ -550,7 +554,7 @@ def main():
                 print(f"[bench] rank {env.rank}: hipGraph replay {1e3 * t_graph:.1f} ms/step vs eager {1e3 * t_eager:.1f} ms/step; "
                       "using the eager loop (same stepper, gradients through the flat buffer)", file=sys.stderr, flush=True)
                 use_graph = False
-                stepper._graph = stepper._graph_opt = None
+                stepper.disable_graph()
     for i in range(args.preroll):
         stepper.step(batch)
         if env.is_main and i in (0, args.preroll - 1):  # the first step loads/JITs kernels on a fresh box: show progress
@@ -580,7 +584,7 @@ def main():
     if use_graph:
         # roofline leg: the SAME step, eager, right after the timed replays (identical kernels and shapes), with the
         # correlation launches bracketed by HIP events on the launch stream
-        stepper._graph = None
+        stepper.disable_graph()
         timer.enabled = True
         for i in range(min(args.steps, 10)):
             preload_queue(1.3e3 * t_eager if args.preload else 0.0)  # (see preload_queue: kernels back to back, as in the replay)
@@ -635,6 +639,7 @@ def main():
     unsup = cfg3 = None
     if env.is_main and env.world_size == 1 and args.unsup_steps > 0 and args.model in ("flowoccnet", "pwoc"):
         try:
+            stepper.close()
             del stepper
             torch.cuda.empty_cache()
             unsup, usumm = unsupervised_leg(args, env, args.unsup_steps)

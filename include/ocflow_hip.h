@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define OCF_ABI_VERSION 2 /* 2: per-call kernel policies replace the process-wide ocf_*_select switches of version 1 */
+#define OCF_ABI_VERSION 3 /* 2: per-call kernel policies replace the process-wide ocf_*_select switches of version 1;
+                             3: ocf_corr_fwd takes `leaky_slope`; ocf_conv3x3_igemm_ex, ocf_conv3x3_wgrad_plan added */
 #define OCF_MAX_DISPLACEMENT 4
 
 enum ocf_dtype { OCF_F32 = 0, OCF_BF16 = 1 };
@@ -72,10 +73,14 @@ int ocf_stream_capture_id(void* stream, unsigned long long* id);
  *           CostVolumeLayer.forward    models/networks/cost_volume_net.py (missing module; call
  *                                      sites flow_occ_net.py:168, cost_volume_flow_occ_net.py:188)
  *           warp -> [*occ] -> corr     flow_net.py:110-112, cost_volume_flow_occ_net.py:204-206
- * d <= OCF_MAX_DISPLACEMENT.  out has (2d+1)^2 channels and element type `dtype`. */
+ *           ... -> LeakyReLU(0.1)      cost_volume_flow_net.py:173,189, cost_volume_flow_occ_net.py:189, pwc_net.py:158
+ * d <= OCF_MAX_DISPLACEMENT.  out has (2d+1)^2 channels and element type `dtype`.
+ * leaky_slope: 0 = none; otherwise out = LeakyReLU(out, leaky_slope) applied in the kernel's store epilogue (0 < leaky_slope <= 1).  The
+ * gradient of such a volume w.r.t. the un-activated one is grad * (out > 0 ? 1 : leaky_slope): ocf_bias_act_bwd does that in one pass, or the
+ * consumer's input-gradient epilogue does it for free (ocf_conv3x3_igemm_ex, `act_channels`). */
 int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                  const ocf_tensor4* out, int B, int C, int H, int W, int d, float flow_scale, int align_corners,
-                 int dtype, int policy /* enum ocf_corr_policy */, void* stream);
+                 float leaky_slope, int dtype, int policy /* enum ocf_corr_policy */, void* stream);
 
 /* Kernel selection of ocf_corr_fwd for bf16, PER CALL (results are the same under every policy, only the kernel differs -- for A/B
  * measurements and for testing the kernels the automatic choice would not pick). */
@@ -327,6 +332,17 @@ int ocf_conv3x3_plan(int Cout, int B, int H, int W, int dilation, int* m_tiles, 
 int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int w_rows, int w_k, const ocf_tensor4* y, const float* bias,
                       const ocf_tensor4* act, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope, float mask_slope,
                       int dtype, int policy, void* stream);
+/* The same launch with a RESIDUAL in the epilogue, for layers whose output is added into a buffer other layers also add into (the input
+ * gradients of a DenseNet block, cost_volume_flow_net.py:176-180: every layer reads a channel range of ONE buffer, so every input gradient
+ * adds into a channel range of ONE gradient buffer):
+ *     m = (act && c < act_channels && act[b,c,y,x] <= 0) ? mask_slope : 1
+ *     y = res_premask ? (lrelu(conv + bias) + res) * m : lrelu(conv + bias) * m + res
+ * res: [B, Cout, H, W] like y (may BE y: in-place accumulation); act_channels: the mask applies to output channels below it (the block's
+ * own activations; the channels behind them are the block's input, whose gradient passes unmasked).  Needs Cout % 8 == 0 and 16-byte
+ * aligned pixels of y / act / res; res == NULL && act_channels >= Cout is exactly ocf_conv3x3_igemm. */
+int ocf_conv3x3_igemm_ex(const ocf_tensor4* x, const void* w_packed, int w_rows, int w_k, const ocf_tensor4* y, const float* bias,
+                         const ocf_tensor4* act, const ocf_tensor4* res, int res_premask, int act_channels, int B, int Cin, int Cout, int H,
+                         int W, int dilation, float negative_slope, float mask_slope, int dtype, int policy, void* stream);
 /* Weight packing for ocf_conv3x3_igemm, every layer of a network in ONE launch: descriptor i says "src (any-strided [Co][Ci][3][3], fp32 or
  * bf16) -> dst (bf16 [rows_pad][9][k_pad]; the kernel writes the valid region, the caller zeroes dst ONCE when it allocates it)"; transpose = 0: rows = Co, k = Ci; transpose = 1: rows = Ci, k = Co, taps flipped.
  * ocf_conv3x3_pack_describe fills descriptor `index` of a HOST array (ocf_conv3x3_pack_bytes(n) bytes) and chains the flat element index
@@ -348,10 +364,16 @@ int ocf_conv3x3_pack_weights(const void* device_descs, int n, int64_t total_elem
  * replaces: the weight and bias halves of autograd's convolution_backward + sum((0,2,3)) for the layers listed above. */
 int ocf_conv3x3_wgrad_bias(const ocf_tensor4* x, const ocf_tensor4* dz, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky, int64_t gw_skx,
                            float* gbias, int B, int Ci, int Co, int H, int W, int dilation, int dtype, int policy, void* stream);
+/* The launch geometry ocf_conv3x3_wgrad_bias uses for a request (host only, no GPU touched): `workgroups` = chunks x tiles, `tiles` = 3 tap
+ * rows x (co, ci) blocks, `chunks` = pixel chunks (each adds a full copy of its tiles with float atomics), `segments_per_chunk` row segments
+ * per chunk, `chunks_capped` = 1 when the map is so small that the chunk count was cut below one workgroup per compute unit (the two
+ * regimes the parity tests assert).  Any output pointer may be NULL. */
+int ocf_conv3x3_wgrad_plan(int B, int Ci, int Co, int H, int W, int dilation, int policy, int* workgroups, int* chunks, int* tiles,
+                           int* segments_per_chunk, int* chunks_capped);
 
 /* ---- channel concatenation of the decoder inputs: out[:, c0_k : c0_k + channels[k]] = parts[k], out[:, sum(channels):Cout] = 0, one launch.
- * parts: n <= 6 pixel-major (channel stride 1, one pixel pitch) bf16 views of [B, channels[k], H, W]; out: dense channels_last
- * [B, Cout, H, W], Cout % 8 == 0, 16-byte aligned.  Anything else: OCF_EUNSUPPORTED (the caller keeps the framework's cat).
+ * parts: n <= 6 pixel-major (channel stride 1, one pixel pitch) bf16 views of [B, channels[k], H, W]; out: channels_last
+ * [B, Cout, H, W] or a channel slice of a wider channels_last tensor (pixel pitch a multiple of 8), Cout % 8 == 0, 16-byte aligned.  Anything else: OCF_EUNSUPPORTED (the caller keeps the framework's cat).
  * replaces: torch.cat((corr, f1, flow_up, feat_up), 1) / torch.cat((f1, warped2, occ_feat_up, occ_up), 1) of flow_net.py:104-121,
  *           flow_occ_net.py:153-176 [aten cat's generic gather kernel + the zero block of the channel alignment] */
 int ocf_concat_channels(const ocf_tensor4* const* parts, const int* channels, int n, const ocf_tensor4* out, int Cout, int B, int H, int W, int dtype,

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order, not an API dependency: the C ABI has no
 
 from . import build as _build
 
-ABI_VERSION = 2  # include/ocflow_hip.h OCF_ABI_VERSION
+ABI_VERSION = 3  # include/ocflow_hip.h OCF_ABI_VERSION
 OCF_F32, OCF_BF16 = 0, 1
 # per-call kernel policies (enum ocf_corr_policy, ocf_corr_bwd_policy, ocf_warp_bwd_policy, ocf_range_policy of the header)
 CORR_AUTO, CORR_BAND_ONLY, CORR_NO_WAVE, CORR_WAVE = 0, 1, 2, 3
@@ -44,7 +44,7 @@ SIGNATURES = {
     "ocf_device_info": [C.c_char_p, _i, C.POINTER(_i)],
     "ocf_profile_next_launch": [_vp, _vp],
     "ocf_stream_capture_id": [_vp, C.POINTER(C.c_ulonglong)],
-    "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
+    "ocf_corr_fwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _f, _i, _f, _i, _i, _vp],
     "ocf_corr_fwd_variant": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i],
     "ocf_corr_bwd": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_corr_bwd_variant": [_T4P, _T4P, _T4P, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i],
@@ -75,11 +75,13 @@ SIGNATURES = {
     "ocf_conv3x3_wgrad": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_conv3x3_plan": [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "ocf_conv3x3_igemm": [_T4P, _vp, _i, _i, _T4P, _vp, _T4P, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp],
+    "ocf_conv3x3_igemm_ex": [_T4P, _vp, _i, _i, _T4P, _vp, _T4P, _T4P, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp],
     "ocf_conv3x3_pack_bytes": [_i, C.POINTER(C.c_int64)],
     "ocf_conv3x3_pack_describe": [_vp, _i, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _vp, _i, _i, _i, C.c_int64,
                                   C.POINTER(C.c_int64)],
     "ocf_conv3x3_pack_weights": [_vp, _i, C.c_int64, _vp],
     "ocf_conv3x3_wgrad_bias": [_T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_conv3x3_wgrad_plan": [_i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "ocf_concat_channels": [C.POINTER(_T4P), C.POINTER(_i), _i, _T4P, _i, _i, _i, _i, _i, _vp],
     "ocf_deconv3x3s2_fwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _vp, _T4P, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_deconv3x3s2_bwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _T4P, _T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _T4P,

@@ -35,6 +35,14 @@ def plan(cout: int, b: int, h: int, w: int, dilation: int) -> Tuple[int, int, in
     return mt.value, tw.value, rows.value
 
 
+def wgrad_plan(b: int, ci: int, co: int, h: int, w: int, dilation: int = 1, policy: int = 0) -> Dict[str, int]:
+    """launch geometry of ocf_conv3x3_wgrad_bias for a request: {workgroups, chunks, tiles, segments_per_chunk, chunks_capped}"""
+    out = [C.c_int(0) for _ in range(5)]
+    _lib.check(_lib.load().ocf_conv3x3_wgrad_plan(int(b), int(ci), int(co), int(h), int(w), int(dilation), int(policy), *[C.byref(o) for o in out]),
+               "ocf_conv3x3_wgrad_plan")
+    return dict(zip(("workgroups", "chunks", "tiles", "segments_per_chunk", "chunks_capped"), (o.value for o in out)))
+
+
 def _rows_pad(n: int) -> int:
     """rows of a packed weight: enough for every split of the output channels into equal blocks of <= 8 tiles of 16 rows that
     ocf_conv3x3_plan may choose (it depends on the image size; the packed copy does not)"""
@@ -57,7 +65,12 @@ class WeightPacker:
         self.entries: Dict[Tuple[int, int], _Packed] = {}
         self._order: List[_Packed] = []
         self._dev_descs: Optional[torch.Tensor] = None
-        self._retired: List[torch.Tensor] = []
+        # descriptor tables a captured graph may still replay a pack launch on: (table, owners) -- owners = weak references to the
+        # objects that captured such a launch (`capture_owner`); None = captured by someone unknown: kept for the life of the process.
+        # A table no capture ever saw is dropped as soon as it is replaced.
+        self._retired: List[Tuple[torch.Tensor, Optional[list]]] = []
+        self._table_owners: Optional[list] = []   # owners of the CURRENT table ([]: never captured, None: captured, owner unknown)
+        self._capturing_owner = None
         self._total = 0
         self._stamp = -1          # ops-level "weights changed" counter seen by the last refresh
         self._capture_seen = 0
@@ -74,19 +87,67 @@ class WeightPacker:
         e.src_ref = weakref.ref(w)  # (weak: the packer must not keep the weights of every model a process ever built alive)
         self.entries[(id(w), int(transpose), int(min_rows))] = e
         self._order.append(e)
-        if self._dev_descs is not None:
-            self._retired.append(self._dev_descs)
-        self._dev_descs = None  # descriptor table is rebuilt on the next refresh
+        self._retire_table()  # descriptor table is rebuilt on the next refresh
         return e
+
+    # ---- lifetime of descriptor tables (`_retired` grew for the life of the process)
+    def _retire_table(self):
+        if self._dev_descs is not None:
+            owners = self._table_owners
+            if owners is None:
+                self._retired.append((self._dev_descs, None))
+            else:
+                live = [r for r in owners if r() is not None]
+                if live:
+                    self._retired.append((self._dev_descs, live))
+        self._dev_descs = None
+        self._table_owners = []
+
+    def _sweep_retired(self):
+        self._retired = [(t, o) for t, o in self._retired if o is None or any(r() is not None for r in o)]
+
+    class _OwnerScope:
+        def __init__(self, packer, owner):
+            self.packer, self.owner = packer, owner
+
+        def __enter__(self):
+            self.prev = self.packer._capturing_owner
+            self.packer._capturing_owner = weakref.ref(self.owner)
+            return self
+
+        def __exit__(self, *exc):
+            self.packer._capturing_owner = self.prev
+            return False
+
+    def capture_owner(self, owner):
+        """`with PACKER.capture_owner(obj):` around a graph capture: the descriptor tables the captured pack launches read stay alive
+        until `obj` is released (`release_owner`) or garbage-collected"""
+        return WeightPacker._OwnerScope(self, owner)
+
+    def release_owner(self, owner):
+        """the graphs `owner` captured are gone: tables only they could replay are freed"""
+        def strip(owners):
+            return None if owners is None else [r for r in owners if r() is not None and r() is not owner]
+        self._retired = [(t, strip(o)) for t, o in self._retired]
+        self._table_owners = strip(self._table_owners)
+        self._sweep_retired()
+
+    def _note_capture(self):
+        """a pack launch reading the current table is being captured"""
+        if self._table_owners is None:
+            return
+        if self._capturing_owner is None or self._capturing_owner() is None:
+            self._table_owners = None
+        elif not any(r() is self._capturing_owner() for r in self._table_owners):
+            self._table_owners.append(self._capturing_owner)
 
     def _purge(self):
         """drop the entries whose weight has been garbage-collected (a later tensor may re-use the id)"""
         if any(e.src_ref() is None for e in self._order):
             self._order = [e for e in self._order if e.src_ref() is not None]
             self.entries = {k: e for k, e in self.entries.items() if e.src_ref() is not None}
-            if self._dev_descs is not None:
-                self._retired.append(self._dev_descs)
-            self._dev_descs = None
+            self._retire_table()
+        self._sweep_retired()
 
     def _build_table(self, device):
         live = [(e, e.src_ref()) for e in self._order]
@@ -105,8 +166,7 @@ class WeightPacker:
             first = nxt
         self._total = first.value
         t = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).clone()
-        if self._dev_descs is not None:
-            self._retired.append(self._dev_descs)  # a captured graph may still replay a launch that reads the old table
+        self._retire_table()  # a captured graph may still replay a launch that reads the old table
         self._dev_descs = t.to(device)
         self._ptrs = [(w.data_ptr(), w.dtype) for _, w in live]
 
@@ -122,6 +182,8 @@ class WeightPacker:
                                    "step once eagerly first")
             self._build_table(device)
             live = [e.src_ref() for e in self._order]
+        if torch.cuda.is_current_stream_capturing():
+            self._note_capture()
         with torch.cuda.device(device):
             _lib.check(_lib.load().ocf_conv3x3_pack_weights(C.c_void_p(self._dev_descs.data_ptr()), len(self._order), self._total,
                                                             C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "ocf_conv3x3_pack_weights")
@@ -208,9 +270,13 @@ def igemm_raw(x, packed: _Packed, cout: int, bias=None, act=None, dilation: int 
 # ---- gradient sinks: a training loop that keeps ONE flat fp32 gradient buffer (runtime.TrainStepper) hands the views of that buffer in;
 # the weight / bias gradient kernels then accumulate straight into them and autograd sees no gradient for those parameters at all (no
 # bf16 round trip, no per-parameter copy into the flat buffer).  The owner zeroes the buffer at the start of every step.
-GRAD_SINK: Dict[int, torch.Tensor] = {}   # id(parameter) -> fp32 view with the parameter's shape and strides
-SEEN_NATIVE: set = set()                  # ids of the parameters whose gradients the kernels of this module produced (see record_native)
+# The sinks belong to ONE owner (the stepper that is capturing) and exist only inside its `grad_sinks(...)` block; an entry is keyed by
+# id(parameter) but carries a weak reference to the parameter and is honoured only for THAT tensor with THAT shape, so neither a stale
+# entry nor a re-used id can route a gradient into someone else's buffer (ADVICE medium).
+GRAD_SINK: Dict[int, Tuple["weakref.ref", torch.Tensor]] = {}   # id(parameter) -> (weakref(parameter), fp32 view: its shape and strides)
+SEEN_NATIVE: Dict[int, "weakref.ref"] = {}  # parameters whose gradients the kernels of this module produced (see record_native)
 _RECORD = [False]
+_SINK_OWNER = [None]  # weakref to the owner of the installed sinks
 
 
 def record_native(flag: bool):
@@ -220,26 +286,56 @@ def record_native(flag: bool):
         SEEN_NATIVE.clear()
 
 
-def install_grad_sinks(params, views) -> set:
+def _seen(p) -> bool:
+    r = SEEN_NATIVE.get(id(p))
+    return r is not None and r() is p
+
+
+def install_grad_sinks(params, views, owner=None) -> set:
     """register `views[i]` as the accumulation target of `params[i]` for every parameter seen by the native backward; returns their ids"""
     GRAD_SINK.clear()
     for p, v in zip(params, views):
-        if id(p) in SEEN_NATIVE and v.dtype == torch.float32 and v.shape == p.shape:
-            GRAD_SINK[id(p)] = v
+        if _seen(p) and v.dtype == torch.float32 and v.shape == p.shape and v.device == p.device:
+            GRAD_SINK[id(p)] = (weakref.ref(p), v)
+    _SINK_OWNER[0] = weakref.ref(owner) if owner is not None else None
     return set(GRAD_SINK)
 
 
-def clear_grad_sinks():
+def clear_grad_sinks(owner=None):
+    """drop the sinks (`owner` given: only if they are that owner's)"""
+    if owner is not None and _SINK_OWNER[0] is not None and _SINK_OWNER[0]() is not owner:
+        return
     GRAD_SINK.clear()
+    _SINK_OWNER[0] = None
+
+
+class grad_sinks:
+    """`with grad_sinks(params, views, owner):` -- the sinks exist inside the block only, whatever leaves it (a capture that raises
+    must not leave them armed for the next model of the process)"""
+
+    def __init__(self, params, views, owner=None, enabled=True):
+        self.args, self.owner, self.enabled, self.ids = (params, views), owner, enabled, set()
+
+    def __enter__(self):
+        if self.enabled:
+            self.ids = install_grad_sinks(*self.args, owner=self.owner)
+        return self.ids
+
+    def __exit__(self, *exc):
+        clear_grad_sinks(self.owner)
+        return False
 
 
 def _grad_target(p, device):
     """(fp32 tensor to accumulate the gradient of parameter `p` into, is_sink)"""
     if _RECORD[0]:
-        SEEN_NATIVE.add(id(p))
-    sink = GRAD_SINK.get(id(p))
-    if sink is not None:
-        return sink, True
+        SEEN_NATIVE[id(p)] = weakref.ref(p)
+    ent = GRAD_SINK.get(id(p))
+    if ent is not None:
+        ref, sink = ent
+        if ref() is p and sink.shape == p.shape and sink.device == p.device:
+            return sink, True
+        del GRAD_SINK[id(p)]  # the id of a dead parameter re-used by this one: not its sink
     return ops._take_zeros(p.numel(), device).as_strided(p.shape, p.stride()), False
 
 
@@ -257,9 +353,26 @@ def wgrad_bias_raw(x, dz, gw, gbias=None, dilation: int = 1, policy: int = 0):
     return gw
 
 
+_MAX_ELEMS = 1 << 30  # the kernels index a tensor with 32-bit in-image offsets: B*H*W*pitch below 2^30 elements (csrc/conv_igemm.hip,
+                      # conv_wgrad3.hip return OCF_EUNSUPPORTED beyond; the predicates below say False first, so callers fall back)
+
+
+def _pitch(t) -> int:
+    B, C_, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    return sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C_))
+
+
+def _offsets_fit(t, other_channels: int = 0) -> bool:
+    B, _, H, W = t.shape
+    return B * H * W * max(_pitch(t), int(other_channels)) < _MAX_ELEMS
+
+
 def wgrad_eligible(x, dz, ci: int, co: int) -> bool:
     """operands ocf_conv3x3_wgrad_bias takes: bf16 pixel-major views with 16-byte aligned pixels that hold the channel counts rounded up to 8"""
     if not (x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and _pixel_major(x, 16) and _pixel_major(dz, 16)):
+        return False
+    if not (_offsets_fit(x) and _offsets_fit(dz)):
         return False
 
     def pitch(t):
@@ -281,7 +394,7 @@ def eligible(x, weight, stride, padding, dilation, groups) -> bool:
     extra = x.shape[1] - weight.shape[1]  # alignment channels of `cat_aligned` (zeros)
     if x.shape[1] % 8 != 0 or extra < 0 or extra >= 32:
         return False
-    return _pixel_major(x, 16)
+    return _pixel_major(x, 16) and _offsets_fit(x, weight.shape[0])
 
 
 def _pixel_major(t, align: int) -> bool:

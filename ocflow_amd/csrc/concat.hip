@@ -23,7 +23,8 @@ struct Args {
   int c0[MAXP + 1];  // first output channel of part k; c0[n] = total channels
   int vec[MAXP];     // part k can be read in aligned 16-byte units
   char* out;
-  int n, Cout;       // Cout % 8 == 0, dense output
+  int n, Cout;       // Cout % 8 == 0
+  long opitch;       // elements between consecutive output pixels (>= Cout, a multiple of 8: the output may be a channel slice)
   long npix;
 };
 
@@ -88,8 +89,17 @@ __global__ __launch_bounds__(256) void concat_kernel(const Args a) {
     }
   }
   __syncthreads();
-  u32x4* dst = (u32x4*)(a.out + pix0 * a.Cout * 2);
-  for (int i = tid; i < np * G; i += 256) dst[i] = s_tile[i];
+  if (a.opitch == a.Cout) {
+    u32x4* dst = (u32x4*)(a.out + pix0 * a.Cout * 2);
+    for (int i = tid; i < np * G; i += 256) dst[i] = s_tile[i];
+  } else {  // channel slice of a wider channels_last buffer (the dense block's input range): one run of G units per pixel
+    const long og = a.opitch >> 3;
+    u32x4* dst = (u32x4*)(a.out) + pix0 * og;
+    for (int i = tid; i < np * G; i += 256) {
+      const int px = i / G, g = i - px * G;
+      dst[px * og + g] = s_tile[i];
+    }
+  }
 }
 }  // namespace cc
 }  // namespace ocf
@@ -119,8 +129,8 @@ extern "C" int ocf_concat_channels(const ocf_tensor4* const* parts, const int* c
   for (int k = n; k <= cc::MAXP; k++) a.c0[k] = c;
   for (int k = n; k < cc::MAXP; k++) { a.p[k] = a.p[0]; a.pitch[k] = 0; a.vec[k] = 0; }
   if (c > Cout) return OCF_EINVAL;
-  if (!pixel_major(out, Cout) || pitch(out, Cout) != Cout || (uintptr_t)out->data % 16 != 0) return OCF_EUNSUPPORTED;
-  a.out = (char*)out->data; a.n = n; a.Cout = Cout; a.npix = (long)B * H * W;
+  if (!pixel_major(out, Cout) || pitch(out, Cout) % 8 != 0 || (uintptr_t)out->data % 16 != 0) return OCF_EUNSUPPORTED;
+  a.out = (char*)out->data; a.n = n; a.Cout = Cout; a.opitch = pitch(out, Cout); a.npix = (long)B * H * W;
   const long blocks = (a.npix + cc::NP - 1) / cc::NP;
   const size_t lds = (size_t)cc::NP * Cout * 2;
   if (blocks > 0x7fffffffL || lds > 48 * 1024) return OCF_EUNSUPPORTED;  // (Cout <= 768)

@@ -19,7 +19,9 @@ struct Args {
   char* y;
   const float* bias;
   const char* act;
-  long xp, yp, ap;
+  const char* res;  // residual (see conv_igemm.hip): Cout % 4 == 0 form only
+  long xp, yp, ap, rp;
+  int act_ch, res_premask;
   int B, H, W, Cin, Cout, wK, d, nfx, nfrag, ngroup;
   float slope, mslope;
 };
@@ -144,7 +146,19 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const Args a) {
         v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
       }
       if (full) {
-        if (a.act) {
+        if (a.res) {
+          const int cs = cb < a.Cout ? cb : 0;
+          u32x2 mv = {0u, 0u};
+          if (a.act) mv = *(const u32x2*)(a.act + (pix * a.ap + cs) * 2);
+          const u32x2 rv = *(const u32x2*)(a.res + (pix * a.rp + cs) * 2);
+          const float r[4] = {bf_lo(rv[0]), bf_hi(rv[0]), bf_lo(rv[1]), bf_hi(rv[1])};
+          const float mm[4] = {bf_lo(mv[0]), bf_hi(mv[0]), bf_lo(mv[1]), bf_hi(mv[1])};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float m = (a.act && cb + e < a.act_ch && !(mm[e] > 0.f)) ? mslope : 1.f;
+            v[e] = a.res_premask ? (v[e] + r[e]) * m : v[e] * m + r[e];
+          }
+        } else if (a.act) {
           const u32x2 mv = *(const u32x2*)(a.act + (pix * a.ap + (cb < a.Cout ? cb : 0)) * 2);
           v[0] *= bf_lo(mv[0]) > 0.f ? 1.f : mslope; v[1] *= bf_hi(mv[0]) > 0.f ? 1.f : mslope;
           v[2] *= bf_lo(mv[1]) > 0.f ? 1.f : mslope; v[3] *= bf_hi(mv[1]) > 0.f ? 1.f : mslope;
@@ -179,12 +193,13 @@ static kern_t pick(int mt) {
 
 // Launcher used by ocf_conv3x3_igemm for small maps (policy 256 forces it, 512 forbids it); same arguments, same results.
 int ocf_conv3x3_direct_launch(const void* x, long xp, const void* w_packed, int w_rows, int w_k, void* y, long yp, const float* bias, const void* act,
-                              long ap, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope, float mask_slope, void* stream) {
+                              long ap, const void* res, long rp, int res_premask, int act_channels, int B, int Cin, int Cout, int H, int W,
+                              int dilation, float negative_slope, float mask_slope, void* stream) {
   using namespace ocf;
   const long npix = (long)B * H * W;
   dc::Args a;
-  a.x = (const char*)x; a.w = (const char*)w_packed; a.y = (char*)y; a.bias = bias; a.act = (const char*)act;
-  a.xp = xp; a.yp = yp; a.ap = ap;
+  a.x = (const char*)x; a.w = (const char*)w_packed; a.y = (char*)y; a.bias = bias; a.act = (const char*)act; a.res = (const char*)res;
+  a.xp = xp; a.yp = yp; a.ap = ap; a.rp = rp; a.act_ch = act_channels; a.res_premask = res_premask;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.wK = w_k; a.d = dilation;
   a.nfx = (W + 15) / 16;
   a.nfrag = B * H * a.nfx;

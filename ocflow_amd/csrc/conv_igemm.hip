@@ -4,6 +4,9 @@
 //
 //   y[b,y,x,m] = epi( sum_{ky,kx,k} Wp[m][ky*3+kx][k] * x[b, y + (ky-1) d, x + (kx-1) d, k] )          (zero outside the image)
 //   epi(v)     = lrelu(v + bias[m], slope) * (act[b,y,x,m] > 0 ? 1 : mask_slope)
+//   with a residual (ocf_conv3x3_igemm_ex: the DenseNet blocks of cost_volume_flow_net.py:176-180, whose layers all read -- and whose input
+//   gradients all add into -- channel ranges of ONE buffer):  mask m only on channels < act_channels, and
+//       y = res_premask ? (epi0(v) + res) * m : epi0(v) * m + res            (res may be y itself: every element is read, then written, by one lane)
 //
 // The SAME kernel is the forward pass (Wp = the weight, epilogue = bias + LeakyReLU: the framework's conv + `add_` + `leaky_relu` in one
 // launch) and the input gradient (x := grad_out, Wp = the weight with taps flipped and channels transposed, packed by
@@ -37,7 +40,10 @@ struct Args {
   char* y;            // [B][H][W][yp] bf16, channels [0, Cout) written
   const float* bias;  // [Cout] or null
   const char* act;    // [B][H][W][ap] bf16 or null
-  long xp, yp, ap;    // pixel pitches, elements
+  const char* res;    // [B][H][W][rp] bf16 or null: residual added in the epilogue (row-store epilogue only)
+  long xp, yp, ap, rp;  // pixel pitches, elements
+  int act_ch;         // the mask applies to output channels < act_ch
+  int res_premask;    // 1: (v + res) * mask, 0: v * mask + res
   int B, H, W, Cin, Cout, wK, d, tiles_x, tiles_y;
   int rows_epi;  // 1: row-store epilogue through LDS (Cout % 8 == 0, 16-byte aligned output pixels)
   int tune;  // ablation (policy bits 1024 / 2048 / 4096): no fragment reads + MFMAs / no DMA / no epilogue stores
@@ -122,7 +128,7 @@ __device__ __forceinline__ void epilogue(const Args& a, const f32x4 (&acc)[MT][4
 // bytes).  Here bias + LeakyReLU are applied in registers, the wave's 64 x (16 MT) tile goes through its own LDS slab
 // ([pixel][channel], pitch 32 MT + 16 bytes: the ds_write_b64 of 16 pixels and the ds_read_b128 of a row are both conflict-free) and
 // is stored 16 bytes per lane, 16 MT / 8 lanes per pixel row; the activation-derivative mask is read the same way.
-template <int MT, int TW, bool ACT>
+template <int MT, int TW, bool ACT, bool RES = false>
 __device__ __forceinline__ void epilogue_rows(const Args& a, const f32x4 (&acc)[MT][4], char* slab, int wave, int lane, int mrow0, int b, int x0,
                                               int y0) {
   constexpr int FC = TW / 16, PITCH = MT * 32 + 16, CPR = MT * 2;  // 16-byte chunks per pixel row
@@ -157,7 +163,27 @@ __device__ __forceinline__ void epilogue_rows(const Args& a, const f32x4 (&acc)[
     const bool ok = idx < 64 * CPR && yy < a.H && xx < a.W && cb < a.Cout;
     const long pix = ok ? ((long)b * a.H + yy) * a.W + xx : 0;
     u32x4 v = *(const u32x4*)(slab + (ok ? row : 0) * PITCH + (ok ? chunk : 0) * 16);
-    if (ACT) {
+    if (RES) {
+      // (both loads from always-valid addresses, issued together, before any use)
+      u32x4 mv = {0u, 0u, 0u, 0u};
+      if (ACT) mv = *(const u32x4*)(a.act + (pix * a.ap + (ok ? cb : 0)) * 2);
+      const u32x4 rv = *(const u32x4*)(a.res + (pix * a.rp + (ok ? cb : 0)) * 2);
+      const bool pre = a.res_premask != 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float lo = bf_lo(v[e]), hi = bf_hi(v[e]);
+        const float rlo = bf_lo(rv[e]), rhi = bf_hi(rv[e]);
+        float mlo = 1.f, mhi = 1.f;
+        if (ACT) {
+          mlo = (cb + 2 * e < a.act_ch && !(bf_lo(mv[e]) > 0.f)) ? mslope : 1.f;
+          mhi = (cb + 2 * e + 1 < a.act_ch && !(bf_hi(mv[e]) > 0.f)) ? mslope : 1.f;
+        }
+        lo = pre ? (lo + rlo) * mlo : lo * mlo + rlo;
+        hi = pre ? (hi + rhi) * mhi : hi * mhi + rhi;
+        const bf16x2 p2 = {(bf16)lo, (bf16)hi};
+        v[e] = __builtin_bit_cast(unsigned, p2);
+      }
+    } else if (ACT) {
       const u32x4 mv = *(const u32x4*)(a.act + (pix * a.ap + (ok ? cb : 0)) * 2);
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -292,7 +318,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_igemm_kernel(const Args a) {
   if (a.rows_epi) {
     __syncthreads();  // every wave is done reading the last stage's buffer: the slabs overlay the stage buffers
     char* slab = smem + wave * (64 * (MT * 32 + 16));
-    if (a.act) epilogue_rows<MT, TW, true>(a, acc, slab, wave, lane, mrow0, b, x0, y0);
+    if (a.res) {
+      if (a.act) epilogue_rows<MT, TW, true, true>(a, acc, slab, wave, lane, mrow0, b, x0, y0);
+      else epilogue_rows<MT, TW, false, true>(a, acc, slab, wave, lane, mrow0, b, x0, y0);
+    } else if (a.act) epilogue_rows<MT, TW, true>(a, acc, slab, wave, lane, mrow0, b, x0, y0);
     else epilogue_rows<MT, TW, false>(a, acc, slab, wave, lane, mrow0, b, x0, y0);
     return;
   }
@@ -422,15 +451,25 @@ extern "C" int ocf_conv3x3_plan(int Cout, int B, int H, int W, int dilation, int
 }
 
 int ocf_conv3x3_direct_launch(const void* x, long xp, const void* w_packed, int w_rows, int w_k, void* y, long yp, const float* bias, const void* act,
-                              long ap, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope, float mask_slope, void* stream);
+                              long ap, const void* res, long rp, int res_premask, int act_channels, int B, int Cin, int Cout, int H, int W,
+                              int dilation, float negative_slope, float mask_slope, void* stream);
 
 extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int w_rows, int w_k, const ocf_tensor4* y, const float* bias,
                                  const ocf_tensor4* act, int B, int Cin, int Cout, int H, int W, int dilation, float negative_slope,
                                  float mask_slope, int dtype, int policy, void* stream) {
+  return ocf_conv3x3_igemm_ex(x, w_packed, w_rows, w_k, y, bias, act, nullptr, 0, Cout, B, Cin, Cout, H, W, dilation, negative_slope, mask_slope,
+                              dtype, policy, stream);
+}
+
+extern "C" int ocf_conv3x3_igemm_ex(const ocf_tensor4* x, const void* w_packed, int w_rows, int w_k, const ocf_tensor4* y, const float* bias,
+                                    const ocf_tensor4* act, const ocf_tensor4* res, int res_premask, int act_channels, int B, int Cin, int Cout,
+                                    int H, int W, int dilation, float negative_slope, float mask_slope, int dtype, int policy, void* stream) {
   using namespace ocf;
   clear_stale_error();
   if (!x || !y || !w_packed || !x->data || !y->data) return OCF_EINVAL;
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || dilation < 1 || policy < 0) return OCF_EINVAL;
+  if ((res && !res->data) || act_channels < 0 || (res_premask != 0 && res_premask != 1)) return OCF_EINVAL;
+  if (act_channels > Cout) act_channels = Cout;
   if (dtype != OCF_BF16 || Cin % 8 != 0 || w_k % 8 != 0 || w_k < Cin) return OCF_EUNSUPPORTED;
   int mt, tw, rows_pad;
   const int st = ocf_conv3x3_plan(Cout, B, H, W, dilation, &mt, &tw, &rows_pad);
@@ -449,20 +488,27 @@ extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int
   const int oal = Cout % 4 == 0 ? 8 : 2;
   if (!cl(x, Cin, 16) || !cl(y, Cout, oal) || (act && (!act->data || !cl(act, Cout, oal)))) return OCF_EUNSUPPORTED;
   if ((uintptr_t)w_packed % 16 != 0) return OCF_EUNSUPPORTED;
+  // the residual / partial-mask epilogue exists in the 16-byte row form only: whole aligned 8-channel chunks of output, mask and residual
+  if (act && act_channels < Cout && !res) return OCF_EUNSUPPORTED;  // (a partial mask exists in the residual epilogue only)
+  const bool ex = res != nullptr;
+  if (ex && (Cout % 8 != 0 || !cl(y, Cout, 16) || (act && !cl(act, Cout, 16)) || (res && !cl(res, Cout, 16)) || (policy & 8192))) return OCF_EUNSUPPORTED;
   // small maps (fewer than ~8 staged patches): the barrier-free kernel that loads its fragments straight from L2 (conv_direct.hip).
   // Measured under graph replay (profiles/r4_h_bench_conv_small_maps.txt), 8 pairs: ahead of the staged kernel and of the library at
   // 14 x 32 and 7 x 16, behind the staged kernel at 28 x 64 (28.5 vs 16.5 us for 128 -> 128)
   const bool direct = (policy & 256) || (!(policy & 512) && (long)B * H * W <= 4096);
   if (direct)
     return ocf_conv3x3_direct_launch(x->data, pitch(x, Cin), w_packed, w_rows, w_k, y->data, pitch(y, Cout), bias, act ? act->data : nullptr,
-                                     act ? pitch(act, Cout) : 0, B, Cin, Cout, H, W, dilation, negative_slope, mask_slope, stream);
+                                     act ? pitch(act, Cout) : 0, res ? res->data : nullptr, res ? pitch(res, Cout) : 0, res_premask,
+                                     act_channels, B, Cin, Cout, H, W, dilation, negative_slope, mask_slope, stream);
   if (w_rows < rows_pad) return OCF_EINVAL;
   if ((long)B * H * W * (pitch(x, Cin) > pitch(y, Cout) ? pitch(x, Cin) : pitch(y, Cout)) >= (1L << 30)) return OCF_EUNSUPPORTED;  // 32-bit in-image offsets
   const int th = 512 / tw;
   ig::Args a;
   a.x = (const char*)x->data; a.w = (const char*)w_packed; a.y = (char*)y->data; a.bias = bias;
   a.act = act ? (const char*)act->data : nullptr;
-  a.xp = pitch(x, Cin); a.yp = pitch(y, Cout); a.ap = act ? pitch(act, Cout) : 0;
+  a.res = res ? (const char*)res->data : nullptr;
+  a.xp = pitch(x, Cin); a.yp = pitch(y, Cout); a.ap = act ? pitch(act, Cout) : 0; a.rp = res ? pitch(res, Cout) : 0;
+  a.act_ch = act_channels; a.res_premask = res_premask;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.wK = w_k; a.d = dilation;
   a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
   a.slope = negative_slope; a.mslope = mask_slope; a.tune = tune;
@@ -471,6 +517,7 @@ extern "C" int ocf_conv3x3_igemm(const ocf_tensor4* x, const void* w_packed, int
   size_t lds = 2 * ((size_t)npi * 1024 + 3 * (size_t)mt * 1024);
   auto al16 = [&](const ocf_tensor4* t, int C) { return (uintptr_t)t->data % 16 == 0 && (pitch(t, C) * 2) % 16 == 0; };
   a.rows_epi = (Cout % 8 == 0 && al16(y, Cout) && (!act || al16(act, Cout)) && (!bias || (uintptr_t)bias % 16 == 0) && !(policy & 8192)) ? 1 : 0;
+  if (ex && !a.rows_epi) return OCF_EUNSUPPORTED;  // (an unaligned bias pointer)
   if (a.rows_epi) {
     const size_t slabs = (size_t)ig::NWAVE * 64 * ((size_t)mt * 32 + 16);
     if (slabs > lds) lds = slabs;

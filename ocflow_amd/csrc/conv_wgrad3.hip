@@ -320,6 +320,67 @@ static bool lds_attr_done(kern_t k) {
 }  // namespace wg3
 }  // namespace ocf
 
+namespace ocf {
+namespace wg3 {
+// launch geometry of ocf_conv3x3_wgrad_bias for a request (shared by the launcher and ocf_conv3x3_wgrad_plan)
+struct Plan {
+  int wm, wn, wk, seg, nseg_x, nseg, n_co_blk, n_ci_blk, ntile, chunks, segs_per_chunk, n_x, n_dz, capped;
+  size_t lds;
+};
+static int make_plan(Plan& p, int B, int Ci, int Co, int H, int W, int dilation, int policy) {
+  // policy (tuning): chunks + 1000 * (ci waves: 1 / 2) + 10000 * (co waves: 1 / 2 / 4); 0 = automatic
+  const int p_chunks = policy % 1000, p_wn = (policy / 1000) % 10, p_wm = (policy / 10000) % 10;
+  if ((p_wn != 0 && p_wn != 1 && p_wn != 2) || (p_wm != 0 && p_wm != 1 && p_wm != 2 && p_wm != 4)) return OCF_EINVAL;
+  p.wm = p_wm ? p_wm : (Co <= 32 ? 1 : (Co <= 64 ? 2 : 4));
+  p.wn = p_wn ? p_wn : 1;  // (64-ci tiles: half the atomic bytes of 128-ci tiles; 103 vs 127 us at 8 x 128 -> 128 x 109 x 256)
+  p.wk = 8 / (p.wm * p.wn);
+  p.seg = p.wk <= 2 ? 64 : 32;
+  p.nseg_x = (W + p.seg - 1) / p.seg;
+  p.nseg = B * H * p.nseg_x;
+  p.n_co_blk = (Co + 32 * p.wm - 1) / (32 * p.wm);
+  p.n_ci_blk = (Ci + 64 * p.wn - 1) / (64 * p.wn);
+  p.ntile = 3 * p.n_ci_blk * p.n_co_blk;
+  // pixel chunks: about one workgroup per compute unit (every chunk adds a full copy of its tiles with float atomics); at least two
+  // stages per workgroup so that the DMA of one overlaps the matrix work of the other
+  const int stages_total = (p.nseg + p.wk - 1) / p.wk;
+  // (512-thread workgroups with ~190 registers: ONE is resident per compute unit, so a 257th workgroup would run as a second round)
+  int chunks = p_chunks > 0 ? p_chunks : (256 / p.ntile) / 8 * 8;
+  if (chunks < 8) chunks = 8;
+  p.capped = 0;
+  if (chunks > stages_total / 2) { chunks = stages_total / 2 > 0 ? stages_total / 2 : 1; p.capped = 1; }  // small maps: fewer chunks than CUs
+  int spc = ((p.nseg + chunks - 1) / chunks + p.wk - 1) / p.wk * p.wk;
+  chunks = ((p.nseg + spc - 1) / spc + 7) / 8 * 8;  // a multiple of 8 for the block -> chunk map (surplus chunks own no segments)
+  p.chunks = chunks;
+  p.segs_per_chunk = spc;
+  p.n_x = ((p.seg + 2 * dilation) * 128 * p.wn + 1023) / 1024;
+  p.n_dz = p.seg * 64 * p.wm / 1024;
+  if (p.n_dz + p.n_x > DMA_ITERS * p.wm * p.wn) return OCF_EUNSUPPORTED;
+  const size_t buf_bytes = (size_t)p.wk * (size_t)(p.n_dz + p.n_x) * 1024;
+  const size_t red = p.wk > 1 ? (size_t)(p.wk / 2) * p.wm * p.wn * 28 * 1024 : 0;
+  p.lds = 2 * buf_bytes;
+  if (red > p.lds) p.lds = red;
+  if (p.lds > 160 * 1024) return OCF_EUNSUPPORTED;
+  return OCF_OK;
+}
+}  // namespace wg3
+}  // namespace ocf
+
+extern "C" int ocf_conv3x3_wgrad_plan(int B, int Ci, int Co, int H, int W, int dilation, int policy, int* workgroups, int* chunks, int* tiles,
+                                      int* segments_per_chunk, int* chunks_capped) {
+  using namespace ocf;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || dilation < 1 || policy < 0) return OCF_EINVAL;
+  if (dilation > 16) return OCF_EUNSUPPORTED;
+  wg3::Plan p;
+  const int st = wg3::make_plan(p, B, Ci, Co, H, W, dilation, policy);
+  if (st != OCF_OK) return st;
+  if (workgroups) *workgroups = p.chunks * p.ntile;
+  if (chunks) *chunks = p.chunks;
+  if (tiles) *tiles = p.ntile;
+  if (segments_per_chunk) *segments_per_chunk = p.segs_per_chunk;
+  if (chunks_capped) *chunks_capped = p.capped;
+  return OCF_OK;
+}
+
 extern "C" int ocf_conv3x3_wgrad_bias(const ocf_tensor4* x, const ocf_tensor4* dz, float* gw, int64_t gw_so, int64_t gw_si, int64_t gw_sky,
                                       int64_t gw_skx, float* gbias, int B, int Ci, int Co, int H, int W, int dilation, int dtype, int policy,
                                       void* stream) {
@@ -338,39 +399,20 @@ extern "C" int ocf_conv3x3_wgrad_bias(const ocf_tensor4* x, const ocf_tensor4* d
   // (the alignment channels of a concatenation: their products land beyond Ci / Co and are never added)
   if (!cl(x, Ci) || !cl(dz, Co) || pitch(x, Ci) < (Ci + 7) / 8 * 8 || pitch(dz, Co) < (Co + 7) / 8 * 8) return OCF_EUNSUPPORTED;
   if ((long)B * H * W * (pitch(x, Ci) > pitch(dz, Co) ? pitch(x, Ci) : pitch(dz, Co)) >= (1L << 30)) return OCF_EUNSUPPORTED;
-  // policy (tuning): chunks + 1000 * (ci waves: 1 / 2) + 10000 * (co waves: 1 / 2 / 4); 0 = automatic
-  const int p_chunks = policy % 1000, p_wn = (policy / 1000) % 10, p_wm = (policy / 10000) % 10, p_tune = policy / 100000;
-  if ((p_wn != 0 && p_wn != 1 && p_wn != 2) || (p_wm != 0 && p_wm != 1 && p_wm != 2 && p_wm != 4)) return OCF_EINVAL;
-  const int wm = p_wm ? p_wm : (Co <= 32 ? 1 : (Co <= 64 ? 2 : 4)), wn = p_wn ? p_wn : 1;  // (64-ci tiles: half the atomic bytes of 128-ci tiles; 103 vs 127 us at 8 x 128 -> 128 x 109 x 256)
-  const int wk = 8 / (wm * wn), seg = wk <= 2 ? 64 : 32;
+  wg3::Plan p;
+  const int pst = wg3::make_plan(p, B, Ci, Co, H, W, dilation, policy % 100000);
+  if (pst != OCF_OK) return pst;
+  const int wm = p.wm, wn = p.wn;
   wg3::Args a;
   a.x = (const char*)x->data; a.dz = (const char*)dz->data; a.gw = gw; a.gbias = gbias;
   a.so = gw_so; a.si = gw_si; a.sky = gw_sky; a.skx = gw_skx; a.xp = pitch(x, Ci); a.zp = pitch(dz, Co);
-  a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.d = dilation; a.tune = p_tune;
-  a.nseg_x = (W + seg - 1) / seg;
-  a.nseg = B * H * a.nseg_x;
-  a.n_co_blk = (Co + 32 * wm - 1) / (32 * wm);
-  a.n_ci_blk = (Ci + 64 * wn - 1) / (64 * wn);
-  const int ntile = 3 * a.n_ci_blk * a.n_co_blk;
-  // pixel chunks: about one workgroup per compute unit (every chunk adds a full copy of its tiles with float atomics); at least two
-  // stages per workgroup so that the DMA of one overlaps the matrix work of the other
-  const int stages_total = (a.nseg + wk - 1) / wk;
-  // (512-thread workgroups with ~190 registers: ONE is resident per compute unit, so a 257th workgroup would run as a second round)
-  int chunks = p_chunks > 0 ? p_chunks : (256 / ntile) / 8 * 8;
-  if (chunks < 8) chunks = 8;
-  if (chunks > stages_total / 2) chunks = stages_total / 2 > 0 ? stages_total / 2 : 1;
-  int spc = ((a.nseg + chunks - 1) / chunks + wk - 1) / wk * wk;
-  chunks = ((a.nseg + spc - 1) / spc + 7) / 8 * 8;  // a multiple of 8 for the block -> chunk map (surplus chunks own no segments)
-  a.segs_per_chunk = spc;
-  const int n_x = ((seg + 2 * dilation) * 128 * wn + 1023) / 1024;
-  const int n_dz = seg * 64 * wm / 1024;
-  if (n_dz + n_x > wg3::DMA_ITERS * wm * wn) return OCF_EUNSUPPORTED;
-  const size_t buf_bytes = (size_t)wk * (size_t)(n_dz + n_x) * 1024;
-  const size_t red = wk > 1 ? (size_t)(wk / 2) * wm * wn * 28 * 1024 : 0;
+  a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.d = dilation; a.tune = policy / 100000;
+  a.nseg_x = p.nseg_x;
+  a.nseg = p.nseg;
+  a.n_co_blk = p.n_co_blk;
+  a.n_ci_blk = p.n_ci_blk;
+  a.segs_per_chunk = p.segs_per_chunk;
   a.nbuf = 2;
-  size_t lds = 2 * buf_bytes;
-  if (red > lds) lds = red;
-  if (lds > 160 * 1024) return OCF_EUNSUPPORTED;
   wg3::kern_t k = nullptr;
   if (wm == 4 && wn == 2) k = wg3::conv3x3_wgrad3_kernel<4, 2>;
   else if (wm == 4 && wn == 1) k = wg3::conv3x3_wgrad3_kernel<4, 1>;
@@ -380,6 +422,6 @@ extern "C" int ocf_conv3x3_wgrad_bias(const ocf_tensor4* x, const ocf_tensor4* d
   else k = wg3::conv3x3_wgrad3_kernel<1, 1>;
   if (!wg3::lds_attr_done(k)) return OCF_ELAUNCH;
   LaunchProf lp;
-  lp.launch(true, k, dim3((unsigned)(chunks * ntile)), dim3(wg3::NTHR), lds, (hipStream_t)stream, a);
+  lp.launch(true, k, dim3((unsigned)(p.chunks * p.ntile)), dim3(wg3::NTHR), p.lds, (hipStream_t)stream, a);
   return launch_status();
 }

@@ -50,7 +50,7 @@ __device__ __forceinline__ void row_item(int it, int& u, int& xl) {
 template <typename T, int VEC, int MODE, int D>
 __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C,
                                                                   int H, int W, float fs, WarpGeom wg, int tiles_x,
-                                                                  int tiles_y, int out_mode) {
+                                                                  int tiles_y, int out_mode, float lrelu) {
   using G = Geo<D>;
   constexpr int U = Unit<T>::U;
   constexpr int ES = (int)sizeof(T);
@@ -182,8 +182,15 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2,
     __syncthreads();
   }
 
-  // ---------------- epilogue: scale by 1/C and store ---------------------------------------------
+  // ---------------- epilogue: scale by 1/C (+ optional LeakyReLU) and store ---------------------------------------------
   const float invC = 1.f / (float)C;
+#pragma unroll
+  for (int i = 0; i < PX; i++)
+#pragma unroll
+    for (int dxi = 0; dxi < G::N; dxi++) {
+      const float t = acc[i][dxi] * invC;
+      acc[i][dxi] = t > 0.f ? t : t * lrelu;  // (lrelu = 1: the plain mean over channels, bit for bit)
+    }
   const int y = ty0 + ry, x0 = tx0 + PX * sx;
   if ((ablate & 4) && acc[0][0] != 123.f) return;
   if (out_mode == OUT_LDS || out_mode == OUT_LDS_VEC) {
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2,
 #pragma unroll
         for (int i = 0; i < PX; i++)
 #pragma unroll
-          for (int dxi = 0; dxi < G::N; dxi++) dst[i * G::NK + dxi] = (T)(acc[i][dxi] * invC);
+          for (int dxi = 0; dxi < G::N; dxi++) dst[i * G::NK + dxi] = (T)(acc[i][dxi]);
       }
       __syncthreads();
       const int nrows = min(ROWS, vrows - r0);
@@ -236,11 +243,11 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2,
     for (int dxi = 0; dxi < G::N; dxi++) {
       const long o = ob + (long)(wave * G::N + dxi) * out.sc + x0;
       if (sizeof(T) == 4) {
-        f32x4 v = {acc[0][dxi] * invC, acc[1][dxi] * invC, acc[2][dxi] * invC, acc[3][dxi] * invC};
+        f32x4 v = {acc[0][dxi], acc[1][dxi], acc[2][dxi], acc[3][dxi]};
         *(f32x4*)(out.p + o * 4) = v;
       } else {
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        bf16x4 v = {(bf16)(acc[0][dxi] * invC), (bf16)(acc[1][dxi] * invC), (bf16)(acc[2][dxi] * invC), (bf16)(acc[3][dxi] * invC)};
+        bf16x4 v = {(bf16)(acc[0][dxi]), (bf16)(acc[1][dxi]), (bf16)(acc[2][dxi]), (bf16)(acc[3][dxi])};
         *(bf16x4*)(out.p + o * 2) = v;
       }
     }
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(64 * (2 * D + 1)) void corr_fwd_tiled(T4 f1, T4 f2,
       const long o = ob + (long)(wave * G::N + dxi) * out.sc;
 #pragma unroll
       for (int i = 0; i < PX; i++)
-        if (x0 + i < W) stf<T>(out.p, o + (long)(x0 + i) * out.sw, acc[i][dxi] * invC);
+        if (x0 + i < W) stf<T>(out.p, o + (long)(x0 + i) * out.sw, acc[i][dxi]);
     }
   }
 }
@@ -585,7 +592,7 @@ static int launch_fwd_d(const T4& f1, const T4& f2, const T4& flow, const T4& oc
 #define OCF_LAUNCH_D(DD)                                                                                   \
   case DD:                                                                                                 \
     hipLaunchKernelGGL((corr_fwd_tiled<T, VEC, MODE, DD>), grid, dim3(64 * (2 * DD + 1)), 0, st, f1, f2, flow, occ, out, \
-                       B, C, H, W, fs, wg, tx, ty, out_mode);                                              \
+                       B, C, H, W, fs, wg, tx, ty, out_mode, corr_fwd_lrelu());                            \
     break;
   switch (d) {
     OCF_LAUNCH_D(1) OCF_LAUNCH_D(2) OCF_LAUNCH_D(3) OCF_LAUNCH_D(4)
@@ -698,8 +705,11 @@ static int corr_bwd_t(const ocf_tensor4* f1, const ocf_tensor4* w2, const ocf_te
 
 extern "C" int ocf_corr_fwd(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                             const ocf_tensor4* out, int B, int C, int H, int W, int d, float flow_scale, int align_corners,
-                            int dtype, int policy, void* stream) {
+                            float leaky_slope, int dtype, int policy, void* stream) {
   ocf::clear_stale_error();
+  if (!(leaky_slope >= 0.f) || leaky_slope > 1.f) return OCF_EINVAL;
+  // 0 = no activation: the kernels take the slope itself, 1 = identity
+  ocf::ScopedCorrLrelu epi(leaky_slope == 0.f ? 1.f : leaky_slope);
   if (!f1 || !f2 || !out || !f1->data || !f2->data || !out->data) return OCF_EINVAL;
   if ((flow && !flow->data) || (occ && !occ->data)) return OCF_EINVAL;
   if (policy < OCF_CORR_POLICY_AUTO || policy > OCF_CORR_POLICY_WAVE) return OCF_EINVAL;

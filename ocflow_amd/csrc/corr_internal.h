@@ -4,6 +4,17 @@
 #include "ocflow_hip.h"
 
 namespace ocf {
+// LeakyReLU slope the forward kernels apply to the scaled cost volume (1 = none): set by ocf_corr_fwd for the duration of ONE call on the
+// calling thread and read by the launch functions of that call (host side only; the kernels take it as an argument)
+inline float& corr_fwd_lrelu() {
+  static thread_local float slope = 1.f;
+  return slope;
+}
+struct ScopedCorrLrelu {
+  float prev;
+  explicit ScopedCorrLrelu(float s) : prev(corr_fwd_lrelu()) { corr_fwd_lrelu() = s; }
+  ~ScopedCorrLrelu() { corr_fwd_lrelu() = prev; }
+};
 // bf16 forward on the matrix cores (corr_mfma.hip)
 int corr_fwd_bf16_mfma(const ocf_tensor4* f1, const ocf_tensor4* f2, const ocf_tensor4* flow, const ocf_tensor4* occ,
                        const ocf_tensor4* out, int B, int C, int H, int W, int d, float fs, int ac, int policy, hipStream_t st);

@@ -72,7 +72,7 @@ enum { MOUT_GENERIC = 0, MOUT_CL_VEC = 1 };
 template <int VEC, int MODE, int D, bool MULTI, int TH>
 __global__ __launch_bounds__(64 * (2 * D + 1), (D == 1 || (MODE == 2 && D == 3)) ? 2 : ((MULTI || TH > 4) ? 3 : 5)) void corr_fwd_mfma(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H,
                                                                  int W, float fs, WarpGeom wg, int tiles_x, int tiles_y,
-                                                                 int out_mode) {
+                                                                 int out_mode, float lrelu) {
   using namespace mf;
   using GG = G<D, TH>;
   typedef bf16 T;
@@ -231,6 +231,8 @@ __global__ __launch_bounds__(64 * (2 * D + 1), (D == 1 || (MODE == 2 && D == 3))
         v = v * o;
       }
       v = v * invC;
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : v[r] * lrelu;
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       const bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
       *(bf16x4*)((char*)s_out + (ry * TW + 16 * s) * GG::S * ES + boff) = h;
@@ -430,10 +432,10 @@ static int launch_mfma_th(const T4& f1, const T4& f2, const T4& flow, const T4& 
     hipEvent_t e0 = ps.start, e1 = ps.stop;
     ps.start = nullptr; ps.stop = nullptr;
     hipExtLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, MULTI, TH>), dim3((unsigned)g), block, lds, st, e0, e1, 0, f1, f2, flow, occ, out, B, C,
-                          H, W, fs, wg, tx, ty, out_mode);
+                          H, W, fs, wg, tx, ty, out_mode, corr_fwd_lrelu());
   } else {
     hipLaunchKernelGGL((corr_fwd_mfma<VEC, MODE, D, MULTI, TH>), dim3((unsigned)g), block, lds, st, f1, f2, flow, occ, out, B, C, H, W, fs,
-                       wg, tx, ty, out_mode);
+                       wg, tx, ty, out_mode, corr_fwd_lrelu());
   }
   return launch_status();
 }

@@ -73,7 +73,7 @@ __device__ u32x4 g_zero16[2];  // zero-initialised; deliberately NOT const (a co
 // issued one halo row (3-5 units per lane) at a time at the top of a tile -- three workgroups per CU cover each other's waits.
 template <int KB, int TH, int WPR, int MODE, int P = 1, bool GATHER = false>
 __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(T4 f1, T4 f2, T4 occ, T4 out, int B, int C, int H, int W, int tiles_x,
-                                                                   int tiles_y, int ablate, T4 flow, float fs, WarpGeom wg) {
+                                                                   int tiles_y, int ablate, T4 flow, float fs, WarpGeom wg, float lrelu) {
 #ifndef OCF_TUNING_BUILD
   ablate = 0;  // phase-skipping switches (wrong results) exist only in the tuning build tools/kbench makes for itself
 #endif
@@ -325,6 +325,8 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
             f32x4 v = is_b ? acc[2 * s + 1] : acc[2 * s];
             if (MODE) v = v * (is_b ? o[s + 1] : o[s]);
             v = v * invC;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : v[r] * lrelu;  // (ocf_corr_fwd's leaky_slope; 1 = none)
             if (ablate & 2) { if (v[0] + v[1] + v[2] + v[3] == 123.456f) dstp[s][0][0] = 1; continue; }
             // two packed converts; the four 2-byte stores take the low / high halves (ds_write_b16 / ds_write_b16_d16_hi); N * i is an immediate
             typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(64 * TH * WPR, KB == 1 ? 3 : 2) void corr_fwd_rows(
 // ---------------------------------------------------------------------------------------------------------------------------------
 // (waves per SIMD: a nine-wave workgroup puts three waves on one SIMD)
 template <int KB, int STRIPS, int VEC, int MODE>
-__global__ __launch_bounds__(64 * rw::N) void corr_fwd_direct(T4 f1, T4 f2, T4 occ, T4 out, int B, int C, int H, int W, int tiles_x) {
+__global__ __launch_bounds__(64 * rw::N) void corr_fwd_direct(T4 f1, T4 f2, T4 occ, T4 out, int B, int C, int H, int W, int tiles_x, float lrelu) {
   using namespace rw;
   typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
   constexpr int TWD = 16 * STRIPS, ROW_E = TWD * NK;
@@ -467,6 +469,8 @@ __global__ __launch_bounds__(64 * rw::N) void corr_fwd_direct(T4 f1, T4 f2, T4 o
     if (MODE) v = v * (is_b ? o[s + 1] : o[s]);
     v = v * invC;
 #pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : v[r] * lrelu;
+#pragma unroll
     for (int r = 0; r < 4; r++) {
       const int dx = (is_b ? q + 16 : q) - r;
       unsigned short* dst = (dx >= 0 && dx < N) ? s_out + 1296 * s + 320 * g + 80 * r + N * dy + j + (is_b ? 16 : 0) : s_trash + lane;
@@ -491,9 +495,9 @@ static int launch_direct(const T4& f1, const T4& f2, const T4& occ, const T4& ou
   if (ps.start && ps.stop) {
     hipEvent_t e0 = ps.start, e1 = ps.stop;
     ps.start = nullptr; ps.stop = nullptr;
-    hipExtLaunchKernelGGL((corr_fwd_direct<KB, STRIPS, VEC, MODE>), grid, block, 0, st, e0, e1, 0, f1, f2, occ, out, B, C, H, W, tx);
+    hipExtLaunchKernelGGL((corr_fwd_direct<KB, STRIPS, VEC, MODE>), grid, block, 0, st, e0, e1, 0, f1, f2, occ, out, B, C, H, W, tx, corr_fwd_lrelu());
   } else {
-    hipLaunchKernelGGL((corr_fwd_direct<KB, STRIPS, VEC, MODE>), grid, block, 0, st, f1, f2, occ, out, B, C, H, W, tx);
+    hipLaunchKernelGGL((corr_fwd_direct<KB, STRIPS, VEC, MODE>), grid, block, 0, st, f1, f2, occ, out, B, C, H, W, tx, corr_fwd_lrelu());
   }
   return launch_status();
 }
@@ -565,7 +569,7 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
     hipEvent_t e0 = ps.start, e1 = ps.stop;
     ps.start = nullptr; ps.stop = nullptr;
     hipExtLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE, P, GATHER>), grid, block, lds, st, e0, e1, 0, f1, f2, occ, out, B, C, H, W, tx, ty, 0, flow, fs,
-                          WarpGeom(H, W, ac));
+                          WarpGeom(H, W, ac), corr_fwd_lrelu());
   } else {
     int ablate = 0;
 #ifdef OCF_TUNING_BUILD
@@ -580,7 +584,7 @@ static int launch_rows(const T4& f1, const T4& f2, const T4& occ, const T4& out,
     }
 #endif
     hipLaunchKernelGGL((corr_fwd_rows<KB, TH, WPR, MODE, P, GATHER>), grid, block, lds, st, f1, f2, occ, out, B, C, H, W, tx, ty, ablate, flow, fs,
-                       WarpGeom(H, W, ac));
+                       WarpGeom(H, W, ac), corr_fwd_lrelu());
   }
   return launch_status();
 }

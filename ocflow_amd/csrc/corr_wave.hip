@@ -32,7 +32,7 @@ __device__ u32x4 g_wave_zero16[2];  // out-of-image taps of the gather read zero
 
 template <int KB, int S, int VEC, bool OCC, bool GATHER>
 __global__ __launch_bounds__(64 * wv::WAVES) void corr_fwd_wave(T4 f1, T4 f2, T4 flow, T4 occ, T4 out, int B, int C, int H, int W,
-                                                                 int tiles_x, int nunits, float fs, WarpGeom wg) {
+                                                                 int tiles_x, int nunits, float fs, WarpGeom wg, float lrelu) {
   using namespace wv;
   typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -194,6 +194,8 @@ __global__ __launch_bounds__(64 * wv::WAVES) void corr_fwd_wave(T4 f1, T4 f2, T4
     if (OCC) v = v * (is_b ? o[s + 1] : o[s]);
     v = v * invC;
 #pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : v[r] * lrelu;
+#pragma unroll
     for (int r = 0; r < 4; r++)
       if (ooff[s][r] >= 0) *(unsigned short*)(orow + ooff[s][r]) = __builtin_bit_cast(unsigned short, (bf16)v[r]);
   }
@@ -208,7 +210,7 @@ static int launch_wave(const T4& f1, const T4& f2, const T4& flow, const T4& occ
   const dim3 grid((unsigned)((nunits + wv::WAVES - 1) / wv::WAVES)), block(64 * wv::WAVES);
   LaunchProf lp;
   lp.launch(true, corr_fwd_wave<KB, S, VEC, OCC, GATHER>, grid, block, 0, st, f1, f2, flow, occ, out, B, C, H, W, tx, (int)nunits, fs,
-            WarpGeom(H, W, ac));
+            WarpGeom(H, W, ac), corr_fwd_lrelu());
   return launch_status();
 }
 

@@ -259,9 +259,9 @@ def _fuse_warp(f1, f2, flow, occ, out, d, needs_grad) -> bool:
     return v in _lib.CORR_VARIANTS_WITH_GATHER
 
 
-def _corr_warp_fwd_raw(f1, f2, flow, occ, d, flow_scale, align_corners, out, needs_grad):
+def _corr_warp_fwd_raw(f1, f2, flow, occ, d, flow_scale, align_corners, out, needs_grad, leaky_slope: float = 0.0):
     """-> (cost volume, warped second operand or None).  Stateless launch sequence shared by the autograd Function below and by the
-    registered operator torch.ops.ocflow.corr_warp (torch_ops.py)."""
+    registered operator torch.ops.ocflow.corr_warp (torch_ops.py).  leaky_slope != 0: LeakyReLU applied in the kernel's store epilogue."""
     B, C_, H, W = f1.shape
     n = 2 * d + 1
     if out is None:
@@ -280,7 +280,7 @@ def _corr_warp_fwd_raw(f1, f2, flow, occ, d, flow_scale, align_corners, out, nee
     def launch():
         with torch.cuda.device(f1.device):
             _lib.check(_lib.load().ocf_corr_fwd(_t4(f1), _t4(op2), _t4(opflow), _t4(occ), _t4(out), B, C_, H, W, d,
-                                                float(flow_scale), int(bool(align_corners)), _dtype_code(f1), policy,
+                                                float(flow_scale), int(bool(align_corners)), float(leaky_slope), _dtype_code(f1), policy,
                                                 _stream(f1)), "ocf_corr_fwd")
 
     if _KERNEL_TIMER is not None:
@@ -364,11 +364,31 @@ def _corr_warp_bwd_raw(f1, f2, flow, occ, w2_saved, gout, d, fs, ac, needs, bwd_
     return g1, g2, gflow, gocc
 
 
+def _leaky_mask(gout, y, slope: float):
+    """gout * (y > 0 ? 1 : slope): the gradient of LeakyReLU taken at its OUTPUT y (same sign as its input for slope > 0), one HIP pass
+    (ocf_bias_act_bwd; its bias-gradient by-product goes to a pooled scratch row)"""
+    B, C_, H, W = y.shape
+    if gout.dtype != y.dtype:
+        gout = gout.to(y.dtype)
+    dz = torch.empty_like(y)
+    gb = _take_zeros(C_, y.device)
+    with torch.cuda.device(y.device):
+        st = _lib.load().ocf_bias_act_bwd(_t4(y), _t4(gout), _t4(dz), C.c_void_p(gb.data_ptr()), B, C_, H, W, float(slope), 1, _dtype_code(y),
+                                          _stream(y))
+    if st == _lib.OCF_EUNSUPPORTED:  # a layout the epilogue kernel does not take
+        return gout * torch.where(y > 0, 1.0, float(slope)).to(gout.dtype)
+    _lib.check(st, "ocf_bias_act_bwd")
+    return dz
+
+
 class _CorrWarpFn(Function):
     @staticmethod
-    def forward(ctx, f1, f2, flow, occ, d, flow_scale, align_corners, out):
-        out, w2 = _corr_warp_fwd_raw(f1, f2, flow, occ, d, flow_scale, align_corners, out, any(ctx.needs_input_grad[:4]))
-        ctx.save_for_backward(f1, f2, flow, occ, w2)
+    def forward(ctx, f1, f2, flow, occ, d, flow_scale, align_corners, out, leaky_slope=0.0, grad_premasked=False):
+        out, w2 = _corr_warp_fwd_raw(f1, f2, flow, occ, d, flow_scale, align_corners, out, any(ctx.needs_input_grad[:4]), leaky_slope)
+        # (grad_premasked: the consumer hands the gradient over already multiplied by the activation's derivative --
+        # conv.conv3x3_dense_block's input-gradient epilogue --, so the activated volume need not be kept)
+        ctx.leaky = float(leaky_slope) if (leaky_slope and not grad_premasked) else 0.0
+        ctx.save_for_backward(f1, f2, flow, occ, w2, out if ctx.leaky else None)
         ctx.cfg = (d, float(flow_scale), bool(align_corners))
         ctx.bwd_policy = POLICY.corr_bwd
         ctx.warp_bwd_policy = POLICY.warp_bwd
@@ -377,15 +397,23 @@ class _CorrWarpFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        f1, f2, flow, occ, w2_saved = ctx.saved_tensors
+        f1, f2, flow, occ, w2_saved, y = ctx.saved_tensors
         d, fs, ac = ctx.cfg
+        if ctx.leaky:
+            gout = _leaky_mask(gout, y, ctx.leaky)
         g1, g2, gflow, gocc = _corr_warp_bwd_raw(f1, f2, flow, occ, w2_saved, gout, d, fs, ac, ctx.needs_input_grad[:4], ctx.bwd_policy,
                                                  ctx.warp_bwd_policy)
-        return g1, g2, gflow, gocc, None, None, None, None
+        return g1, g2, gflow, gocc, None, None, None, None, None, None
 
 
-def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flow_scale=1.0, align_corners=False, out=None):
+def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flow_scale=1.0, align_corners=False, out=None, *,
+              leaky_slope=0.0, grad_premasked=False):
     """Cost volume of features1 against  warp(features2, flow*flow_scale) [* occ].
+
+    leaky_slope != 0: `LeakyReLU(leaky_slope)` of the volume, applied in the kernel's store epilogue (cost_volume_flow_net.py:173,189:
+    `self.leakyRELU(corr)` as a separate pass over the 81-channel volume).  Its backward multiplies the incoming gradient by the
+    activation's derivative in one HIP pass -- unless `grad_premasked`, a promise of the consumer that the gradient it sends back is
+    already so multiplied (conv.conv3x3_dense_block does that in the epilogue of its input-gradient kernels).
 
     With a flow: a forward that records a gradient is TWO launches -- ocf_warp_fwd materialises the warped operand (backward consumes
     it), then ocf_corr_fwd with the mask applied to the band outputs; so is a no-grad forward by default (measured faster); with
@@ -427,18 +455,20 @@ def corr_warp(features1, features2, flow=None, occ=None, max_displacement=4, flo
             raise ValueError(f"out must be a [{B},{n * n},{H},{W}] {f1.dtype} tensor with unit channel stride on {f1.device}")
         if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (f1, f2, flow, occ, out)):
             raise RuntimeError("corr_warp(out=...) is a forward-only form: call it under torch.no_grad() or on detached tensors")
-        return _corr_warp_fwd_raw(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners, out, False)[0]
+        return _corr_warp_fwd_raw(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners, out, False, leaky_slope)[0]
     if _tracing() and out is None:
         from . import torch_ops  # noqa: F401
-        return torch.ops.ocflow.corr_warp(f1, f2, _f32(flow), _f32(occ), d, float(flow_scale), bool(align_corners))[0]
-    return _CorrWarpFn.apply(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners, out)
+        cv = torch.ops.ocflow.corr_warp(f1, f2, _f32(flow), _f32(occ), d, float(flow_scale), bool(align_corners))[0]
+        return torch.nn.functional.leaky_relu(cv, float(leaky_slope)) if leaky_slope else cv
+    return _CorrWarpFn.apply(f1, f2, _f32(flow), _f32(occ), d, flow_scale, align_corners, out, float(leaky_slope), bool(grad_premasked))
 
 
-def compute_cost_volume(features1, features2, max_displacement=4):
+def compute_cost_volume(features1, features2, max_displacement=4, *, leaky_slope=0.0, grad_premasked=False):
     """Drop-in for models/networks/correlation_layer.py:7-40.
 
-    out[b, (dy+d)(2d+1)+(dx+d), y, x] = mean_c features1[b,c,y,x] * features2[b,c,y+dy,x+dx]   (zero outside)."""
-    return corr_warp(features1, features2, None, None, max_displacement)
+    out[b, (dy+d)(2d+1)+(dx+d), y, x] = mean_c features1[b,c,y,x] * features2[b,c,y+dy,x+dx]   (zero outside).
+    leaky_slope / grad_premasked: see corr_warp (the activation the PWC-style nets apply right after it, fused into the launch)."""
+    return corr_warp(features1, features2, None, None, max_displacement, leaky_slope=leaky_slope, grad_premasked=grad_premasked)
 
 
 # ---------------------------------------------------------------------------------------------------- warp
@@ -993,9 +1023,16 @@ class _ConcatFn(Function):
         return (None, *grads)
 
 
-def concat_channels_eligible(parts) -> bool:
-    """operands ocf_concat_channels takes: up to six bf16 pixel-major [B, C_k, H, W] tensors on one HIP device"""
+CONCAT_MAX_CHANNELS = 768  # ocf_concat_channels assembles 32-pixel rows in 48 KB of LDS (csrc/concat.hip)
+
+
+def concat_channels_eligible(parts, cout=None) -> bool:
+    """operands ocf_concat_channels takes: up to six bf16 pixel-major [B, C_k, H, W] tensors on one HIP device, at most 768 output
+    channels (`cout`: the padded channel count the caller will ask for; default the sum rounded up to 32)"""
     if not (1 <= len(parts) <= 6):
+        return False
+    total = sum(int(t.shape[1]) for t in parts)
+    if max((total + 31) // 32 * 32, int(cout or 0)) > CONCAT_MAX_CHANNELS:
         return False
     x0 = parts[0]
     for t in parts:

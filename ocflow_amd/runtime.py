@@ -394,9 +394,13 @@ class TrainStepper:
         in_group = {id(t) for t in g["params"]}
         if any(t.dtype != torch.float32 or id(t) not in in_group or t not in opt.state or "exp_avg" not in opt.state[t] for t in targets):
             return None
+        dev = self.env.device
+        # (every check BEFORE the first storage is re-homed: a None from here must leave the optimizer and the packer's tables untouched)
+        if any(not torch.is_tensor(opt.state[t].get("step")) or opt.state[t]["step"].device != dev or opt.state[t]["step"].dtype != torch.float32
+               for t in targets):
+            return None
         pad = lambda n: (n + 63) & ~63  # (the layout of _flat_views)
         total = sum(pad(t.numel()) for t in targets)
-        dev = self.env.device
         fp, fm, fv = (torch.zeros(total, device=dev, dtype=torch.float32) for _ in range(3))
         fb = torch.zeros(total, device=dev, dtype=torch.bfloat16) if self._masters else None
         steps, off = [], 0
@@ -418,8 +422,6 @@ class TrainStepper:
                     p.data = v
                 steps.append(st["step"])
                 off += pad(n)
-        if any(not torch.is_tensor(s_) or s_.device != dev or s_.dtype != torch.float32 for s_ in steps):
-            return None
         return {"p": fp, "m": fm, "v": fv, "b": fb, "steps": steps, "n": total, "lr": float(g["lr"]), "betas": tuple(map(float, g["betas"])),
                 "eps": float(g["eps"]), "wd": float(g["weight_decay"])}
 
@@ -501,20 +503,27 @@ class TrainStepper:
             mode = "thread_local"
             time.sleep(1.0)
         graph = torch.cuda.CUDAGraph()
+        from ocflow_amd import conv as nconv
         if not self._manual:
-            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
-                self._static_loss = self._eager_step(self._static_batch, 0)
+            try:
+                with nconv.PACKER.capture_owner(self), torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
+                    self._static_loss = self._eager_step(self._static_batch, 0)
+            except BaseException:
+                nconv.PACKER.release_owner(self)
+                nconv.weights_changed()
+                raise
             self._graph = graph
             return self
         split = self._reduce  # an all-reduce sits between backward and the optimizer
-        from ocflow_amd import conv as nconv
         nconv.clear_grad_sinks()
         nconv.record_native(True)   # one more eager step: which parameters get their gradients from the repo's convolution kernels?
-        with torch.cuda.stream(side):
-            self._eager_step(self._static_batch, warmup)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        nconv.record_native(False)
+        try:
+            with torch.cuda.stream(side):
+                self._eager_step(self._static_batch, warmup)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        finally:
+            nconv.record_native(False)
         params = self._grad_params()  # after the warm-up steps: exactly the parameters that reach the loss
         self._flat, views = self._flat_views(params)
         # those kernels accumulate straight into the flat fp32 buffer (zeroed at the top of every replay): autograd produces no gradient
@@ -523,33 +532,78 @@ class TrainStepper:
         if self._flat_adam is not None:
             nconv.PACKER.refresh()  # the bf16 weights moved: rebuild the packer's descriptor table outside the capture
             torch.cuda.synchronize()
-        sinks = nconv.install_grad_sinks(params, views) if os.environ.get("OCFLOW_GRAD_SINKS", "1") != "0" else set()
-        self._sink_ids = sinks
-        with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
-            if sinks:
-                self._flat.zero_()
-            self._static_loss = self._forward_backward(self._static_batch, 0)
-            got = [p for p in self.raw.parameters() if p.grad is not None or id(p) in sinks]
-            if len(got) != len(params) or any(a is not b for a, b in zip(got, params)):
-                raise RuntimeError("TrainStepper.enable_graph: the set of parameters with gradients changed between steps")
-            rest = [i for i, p in enumerate(params) if id(p) not in sinks]
-            self._gather([views[i] for i in rest], [params[i].grad for i in rest])
-            for i, p in enumerate(params):  # a sink parameter that ALSO received a framework gradient (another call site): add it
-                if id(p) in sinks and p.grad is not None:
-                    views[i].add_(p.grad)
-            if not split:
+        opt_graph = None
+        try:
+            # the sinks (process-global in ocflow_amd.conv, owned by this stepper) exist inside this block only: a capture that raises
+            # must not leave them armed for the next model of the process
+            with nconv.grad_sinks(params, views, owner=self, enabled=os.environ.get("OCFLOW_GRAD_SINKS", "1") != "0") as sinks, \
+                    nconv.PACKER.capture_owner(self):
+                self._sink_ids = sinks
+                with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
+                    if sinks:
+                        self._flat.zero_()
+                    self._static_loss = self._forward_backward(self._static_batch, 0)
+                    got = [p for p in self.raw.parameters() if p.grad is not None or id(p) in sinks]
+                    if len(got) != len(params) or any(a is not b for a, b in zip(got, params)):
+                        raise RuntimeError("TrainStepper.enable_graph: the set of parameters with gradients changed between steps")
+                    rest = [i for i, p in enumerate(params) if id(p) not in sinks]
+                    self._gather([views[i] for i in rest], [params[i].grad for i in rest])
+                    for i, p in enumerate(params):  # a sink parameter that ALSO received a framework gradient (another call site): add it
+                        if id(p) in sinks and p.grad is not None:
+                            views[i].add_(p.grad)
+                    if not split:
+                        self._attach(params, views)
+                        self._optimizer_step()
+            # (the captured launches keep their pointers; eager steps outside the graph use autograd's own gradients)
+            if split:
+                # (no collective in here: a rank whose capture raised must not leave the others waiting inside one)
                 self._attach(params, views)
-                self._optimizer_step()
-        nconv.clear_grad_sinks()  # the captured launches keep their pointers; eager steps outside the graph use autograd's own gradients
+                opt_graph = torch.cuda.CUDAGraph()
+                with nconv.PACKER.capture_owner(self), torch.cuda.graph(opt_graph, pool=self._graph_pool, capture_error_mode=mode):
+                    self._optimizer_step()
+        except BaseException:
+            # nothing half-captured survives: no graph, no flat buffer a stale sink could have pointed at
+            self._graph = self._graph_opt = None
+            self._flat = None
+            self._sink_ids = set()
+            nconv.PACKER.release_owner(self)
+            nconv.weights_changed()
+            raise
         self._graph = graph
-        if split:
-            # (no collective in here: a rank whose capture raised must not leave the others waiting inside one)
-            self._attach(params, views)
-            opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(opt_graph, pool=self._graph_pool, capture_error_mode=mode):
-                self._optimizer_step()
-            self._graph_opt = opt_graph
+        self._graph_opt = opt_graph
         return self
+
+    def disable_graph(self):
+        """back to the eager loop on the same parameters / optimizer state (the flat buffers the optimizer was re-homed into stay)"""
+        from ocflow_amd import conv as nconv
+        self._graph = self._graph_opt = None
+        nconv.clear_grad_sinks(owner=self)
+        nconv.PACKER.release_owner(self)
+        nconv.weights_changed()
+        return self
+
+    def close(self):
+        """release what this stepper owns outside itself: its graphs and their pool, the flat buffers, its gradient sinks (if a capture
+        of its own is what installed them) and the packer's descriptor tables only its graphs could replay.  Idempotent; also run by
+        the destructor."""
+        try:
+            from ocflow_amd import conv as nconv
+            nconv.clear_grad_sinks(owner=self)
+            self._graph = self._graph_opt = None
+            self._static_batch = self._static_loss = None
+            self._flat = None
+            self._graph_pool = None
+            nconv.PACKER.release_owner(self)
+        except Exception:  # noqa: BLE001 - interpreter shutdown: modules may already be gone
+            pass
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def _weights_changed():
+        from ocflow_amd import conv as nconv
+        nconv.weights_changed()
 
     def _replay(self, batch) -> torch.Tensor:
         if batch is not self._static_batch:
@@ -560,6 +614,9 @@ class TrainStepper:
         if self._graph_opt is not None:
             dist.all_reduce(self._flat)
             self._graph_opt.replay()
+        # the captured optimizer updated the weights without moving a version counter or running an optimizer hook: the packed copies
+        # the NEXT eager forward (validation, an eager step) would read are one update behind (the replay itself re-packs at its top)
+        self._weights_changed()
         self.raw.global_step = getattr(self.raw, "global_step", 0) + 1
         return self._static_loss
 

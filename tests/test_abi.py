@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in include/ocflow_hip.h but not exported"
-    assert lib.ocf_abi_version() == 2
+    assert lib.ocf_abi_version() == 3
     assert set(_lib.SIGNATURES) | {"ocf_status_string"} == set(declared_functions())
     assert lib.ocf_status_string(0) == b"ok" and lib.ocf_status_string(-2) == b"unsupported configuration"
 
@@ -49,12 +49,12 @@ def test_argument_validation_without_device():
     lib = _lib.load()
     t = _lib.Tensor4(0, 0, 0, 0, 0)
     good = _lib.Tensor4(16, 1, 1, 1, 1)
-    assert lib.ocf_corr_fwd(None, None, None, None, None, 1, 1, 1, 1, 4, 1.0, 0, 0, 0, None) == -1
-    assert lib.ocf_corr_fwd(C.byref(t), C.byref(t), None, None, C.byref(t), 1, 1, 1, 1, 4, 1.0, 0, 0, 0, None) == -1  # null data
-    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 9, 1.0, 0, 0, 0, None) == -2  # d > 4
-    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 0, 1, 1, 1, 4, 1.0, 0, 0, 0, None) == -1
+    assert lib.ocf_corr_fwd(None, None, None, None, None, 1, 1, 1, 1, 4, 1.0, 0, 0.0, 0, 0, None) == -1
+    assert lib.ocf_corr_fwd(C.byref(t), C.byref(t), None, None, C.byref(t), 1, 1, 1, 1, 4, 1.0, 0, 0.0, 0, 0, None) == -1  # null data
+    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 9, 1.0, 0, 0.0, 0, 0, None) == -2  # d > 4
+    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 0, 1, 1, 1, 4, 1.0, 0, 0.0, 0, 0, None) == -1
     # kernel policies are per-call arguments (ABI version 2: the library holds no selection state); values outside their enum are rejected
-    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 4, 1.0, 0, 0, 9, None) == -1
+    assert lib.ocf_corr_fwd(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 4, 1.0, 0, 0.0, 0, 9, None) == -1
     assert lib.ocf_corr_fwd_variant(C.byref(good), C.byref(good), None, None, C.byref(good), 1, 1, 1, 1, 4, 1, 9) == -1
     assert lib.ocf_corr_bwd(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 4, 0, 3, None) == -1
     assert lib.ocf_corr_bwd_variant(C.byref(good), C.byref(good), C.byref(good), C.byref(good), None, 1, 1, 1, 1, 4, 0, 3) == -1

@@ -45,6 +45,42 @@ def test_config1_flowoccnet_at_436x1024(golden):
         assert abs(float(oc.mean()) - float(g["flowoccnet_436x1024_occ_mean"])) < 1e-4
 
 
+# what the benchmark's configuration (bf16 autocast, channels_last, this repo's convolution kernels) costs against the reference's fp32
+# outputs at the benchmark size; measured on MI355X (round 5): see the numbers printed by the test and README.  Bars = 2 x measured.
+BF16_EPE_BAR, BF16_OCC_BAR = 3.1e-4, 2.6e-3  # measured 1.53e-4 px / 1.28e-3 (gpurun_out/r5d_new_tests.txt)
+
+
+def test_config1_flowoccnet_bf16_native_convolutions_gap_to_the_reference(golden):
+    """every <= 1e-4 golden test runs fp32, where each layer goes to the library.  This one runs the configuration
+    the benchmark times -- FlowOccModel('flowoccnet'), eval, bf16 autocast, channels_last, native convolution / concatenation / BatchNorm
+    kernels -- at 1 x 436 x 1024 against the reference's fp32 golden (tests/golden/fullsize.npz) and holds the gap (bf16 cannot meet 1e-4:
+    SURVEY 9 measured 9e-3 px from rounding the correlation's I/O alone; parity is claimed in fp32, this is the throughput mode's error)."""
+    from ocflow_amd import ops
+    from ocflow_amd.models.flow_occ_model import FlowOccModel
+    g = golden("fullsize")
+    x = T(smooth_field((1, 6, 436, 1024), seed=71, amp=1.0)).float().clamp(-1, 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    m = rngfree_fill(FlowOccModel({"learning_rate": 1e-3, "model": "flowoccnet"})).to(DEV).eval().to(memory_format=torch.channels_last)
+    calls = []
+
+    class Spy:
+        def launch(self, name, meta, fn):
+            calls.append(name)
+            return fn()
+
+    ops.set_kernel_timer(Spy())
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            fl, oc = m(x)
+    finally:
+        ops.set_kernel_timer(None)
+    assert calls.count("conv3x3_igemm") >= 40 and "corr_fwd" in calls and "warp_fwd" in calls, sorted(set(calls))
+    e = epe(fl[..., ::4, ::4], g["flowoccnet_436x1024_flow_sub4"])
+    o = float((oc[..., ::4, ::4].float().cpu() - T(g["flowoccnet_436x1024_occ_sub4"])).abs().mean())
+    print(f"bf16 + native convolutions vs the reference's fp32 golden at 1x436x1024: flow EPE {e:.3e} px, occlusion L1 {o:.3e} "
+          f"({calls.count('conv3x3_igemm')} implicit-GEMM launches)")
+    assert e < BF16_EPE_BAR and o < BF16_OCC_BAR, (e, o)
+
+
 def test_config1_flownetcv_at_448x1024(golden):
     from ocflow_amd.models.flow_model import FlowModel
     g = golden("fullsize")
@@ -244,14 +280,15 @@ def test_launcher_runs_the_shipped_two_stage_configuration(tmp_path):
         flow_io.save_flow(str(root / f"{i:07d}-flow_01.flo"), fl)
         Image.fromarray(((rs.rand(140, 200) < 0.2) * 255).astype(np.uint8)).save(root / f"{i:07d}-occ_01.png")
     cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "unsupervised_twostage.yml")
-    # the launcher as a user starts it: `python -m ocflow_amd.train <config> ...` in its own process (it also keeps this run apart from
-    # whatever graphs, pools and library handles the tests before it left in the pytest process)
+    # In the pytest process (round 4 ran it as `python -m ocflow_amd.train` in a process of its own after an unexplained abort in one test
+    # order; round 5: the order passes with and without output capture, and the runtime's process-global state now has owners --
+    # DESIGN.md 13.2).  OCFLOW_TEST_LAUNCHER_SUBPROCESS=1 runs the launcher as a user starts it.
     import json
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     argv = [cfg, "--steps", "13", "--override", f"root={root}", "batch_size=4", "num_workers=0", "log_every_n_steps=4", "--out", str(tmp_path / "out")]
-    if os.environ.get("OCFLOW_TEST_LAUNCHER_INPROC") == "1":  # (diagnostics: the same run inside the pytest process)
+    if os.environ.get("OCFLOW_TEST_LAUNCHER_SUBPROCESS") != "1":
         train.main(argv)
     else:
         run = subprocess.run([sys.executable, "-m", "ocflow_amd.train"] + argv, cwd=repo, capture_output=True, text=True, timeout=600)

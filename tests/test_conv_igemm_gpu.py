@@ -166,6 +166,63 @@ def test_bench_shapes_forward(conv, ci, co, H, W, d):
     _close(got, want, f"bench shape {ci}->{co} {H}x{W} d{d}")
 
 
+BENCH_LAYERS = [(128, 128, 109, 256, 1), (128, 96, 109, 256, 8), (96, 64, 109, 256, 16), (64, 32, 109, 256, 1), (32, 2, 109, 256, 1),
+                (160, 128, 55, 128, 1), (192, 128, 28, 64, 1), (224, 128, 14, 32, 1), (288, 128, 7, 16, 1)]
+
+
+def _bench_operands(ci, co, H, W, seed):
+    """x [8, ci, H, W] and the output gradient dz [8, co8, H, W] (co8 = co rounded up to 8: the 2-channel prediction layer's gradient sits
+    in a zero-padded 8-channel tensor, as conv._ConvBiasActFn.backward forms it), both bf16 channels_last on the GPU"""
+    g = torch.Generator().manual_seed(seed)
+    x = _dev_cl(torch.randn(8, ci, H, W, generator=g).bfloat16())
+    co8 = (co + 7) // 8 * 8
+    dz = torch.zeros(8, co8, H, W, dtype=torch.bfloat16)
+    dz[:, :co] = torch.randn(8, co, H, W, generator=g).bfloat16()
+    return x, _dev_cl(dz)
+
+
+@pytest.mark.parametrize("ci,co,H,W,d", BENCH_LAYERS)
+def test_bench_shapes_weight_and_bias_gradient(ci, co, H, W, d):
+    """ocf_conv3x3_wgrad_bias at the layers the benchmark times (8 pairs at 436 x 1024, pyramid levels 2..6; VERDICT r4 weak 1a: the
+    kernel was only value-checked up to 14 k pixels, the benchmark runs 223 k) against the fp32 weight gradient of the SAME bf16-rounded
+    operands.  The reference is computed on the GPU in fp32 (the framework's convolution backward; on the CPU these sizes take minutes):
+    both accumulate in fp32, so the bar is summation order, 2e-3 of the gradient's scale.  Both chunk regimes of the launcher are
+    reached and asserted through ocf_conv3x3_wgrad_plan: one pixel chunk set per compute unit (levels 2..5) and the capped form of a map
+    with fewer stages than that (level 6)."""
+    from ocflow_amd import conv
+    x, dz = _bench_operands(ci, co, H, W, seed=ci + co + H + d)
+    plan = conv.wgrad_plan(8, ci, co, H, W, d)
+    assert plan["chunks_capped"] == (1 if H * W <= 7 * 16 else 0), plan
+    assert plan["workgroups"] == plan["chunks"] * plan["tiles"] and 128 <= plan["workgroups"] <= 256, plan
+    assert plan["chunks"] * plan["segments_per_chunk"] >= 8 * H * ((W + 63) // 64), plan  # every row segment belongs to a chunk
+    dzv = dz[:, :co]
+    assert conv.wgrad_eligible(x, dzv, ci, co)
+    gw = torch.zeros(co, ci, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    gb = torch.zeros(co, device=DEV)
+    conv.wgrad_bias_raw(x, dzv, gw, gb, d)
+    want_w = torch.nn.grad.conv2d_weight(x.float(), (co, ci, 3, 3), dzv.float().contiguous(memory_format=torch.channels_last), 1, d, d)
+    want_b = dzv.float().sum((0, 2, 3))
+    _close(gw, want_w, f"bench weight gradient {ci}->{co} {H}x{W} d{d}", 2e-3, 2e-3)
+    _close(gb, want_b, f"bench bias gradient {ci}->{co} {H}x{W} d{d}", 2e-3, 2e-3)
+
+
+@pytest.mark.parametrize("ci,co,H,W,d", BENCH_LAYERS)
+def test_bench_shapes_input_gradient_with_activation_mask(conv, ci, co, H, W, d):
+    """the input-gradient half of ocf_conv3x3_igemm (flipped / transposed packed weight) with the previous layer's LeakyReLU derivative in
+    its epilogue (`act` = that layer's output) at the benchmark's layers, against fp32 conv2d_input x mask on the GPU (same bf16-rounded
+    operands; the kernel rounds its result to bf16 once: 2e-2 of the scale, as the small-shape test of this epilogue)"""
+    x, dz = _bench_operands(ci, co, H, W, seed=3 * ci + co + H + d)
+    w = _dev_cl((torch.randn(co, ci, 3, 3, generator=torch.Generator().manual_seed(co)) * (2.0 / (9 * co)) ** 0.5).bfloat16())
+    pkt = conv.PACKER.get(w, True, ci)
+    got = conv.igemm_raw(dz, pkt, ci, None, x, d, 1.0, 0.1)
+    want = torch.nn.grad.conv2d_input(x.shape, w.float(), dz[:, :co].float().contiguous(memory_format=torch.channels_last), 1, d, d)
+    want = want * torch.where(x.float() > 0, 1.0, 0.1)
+    _close(got, want, f"bench masked input gradient {ci}->{co} {H}x{W} d{d}", 2e-2, 2e-2)
+    # and without the mask (the first layer of a chain)
+    got = conv.igemm_raw(dz, pkt, ci, None, None, d, 1.0, 1.0)
+    _close(got, want / torch.where(x.float() > 0, 1.0, 0.1), "bench input gradient", 2e-2, 2e-2)
+
+
 WG_CASES = [
     # B, ci, co, H, W, d  -- every (co waves, ci waves) configuration of the kernel, partial segments, channel tails, several chunks
     (2, 128, 128, 20, 70, 1), (1, 64, 128, 17, 33, 1), (2, 128, 64, 9, 70, 2), (1, 64, 64, 33, 40, 1), (2, 128, 32, 21, 35, 1),

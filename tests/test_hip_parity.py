@@ -169,7 +169,7 @@ def test_corr_bf16_output_into_concat_buffer(ops):
     T4 = lambda t: C.byref(_lib.Tensor4(t.data_ptr(), *t.stride()))
     for policy in (_lib.CORR_AUTO, _lib.CORR_BAND_ONLY):  # the wave kernel (any pixel pitch) and the band kernel's generic epilogue
         buf.zero_()
-        st = _lib.load().ocf_corr_fwd(T4(a), T4(b), None, None, T4(dst), 2, 32, 16, 48, 4, 1.0, 0, _lib.OCF_BF16, policy,
+        st = _lib.load().ocf_corr_fwd(T4(a), T4(b), None, None, T4(dst), 2, 32, 16, 48, 4, 1.0, 0, 0.0, _lib.OCF_BF16, policy,
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert st == 0
         torch.cuda.synchronize()

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
     const int var_nowave = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt, OCF_CORR_POLICY_NO_WAVE);
     const int var_band = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &to, B, C, H, W, 4, dt, OCF_CORR_POLICY_BAND_ONLY);
     auto fwd = [&](const ocf_tensor4* occp, int policy, const ocf_tensor4* outp) {
-      return time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, occp, outp, B, C, H, W, 4, 1.f, 0, dt, policy, st); }, st);
+      return time_us([&] { ocf_corr_fwd(&t1, &t2, nullptr, occp, outp, B, C, H, W, 4, 1.f, 0, 0.f, dt, policy, st); }, st);
     };
     const float a_band = fwd(nullptr, OCF_CORR_POLICY_BAND_ONLY, &to), b_band = fwd(&tc, OCF_CORR_POLICY_BAND_ONLY, &to);
     std::vector<unsigned char> ref(no * es), got(no * es);
@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
     const int var_wide = ocf_corr_fwd_variant(&t1, &t2, nullptr, &tc, &tw, B, C, H, W, 4, dt, OCF_CORR_POLICY_AUTO);
     // K1+K2 in one launch (flow given) vs the warp kernel alone
     const int var_fused = ocf_corr_fwd_variant(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, dt, OCF_CORR_POLICY_AUTO);
-    float c = time_us([&] { ocf_corr_fwd(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, 1.25f, 0, dt, OCF_CORR_POLICY_AUTO, st); }, st);
+    float c = time_us([&] { ocf_corr_fwd(&t1, &t2, &tf, &tc, &to, B, C, H, W, 4, 1.25f, 0, 0.f, dt, OCF_CORR_POLICY_AUTO, st); }, st);
     float d = time_us([&] { ocf_warp_fwd(&t2, &tf, &tg1, B, C, H, W, 1.25f, 0, dt, st); }, st);
     printf("  +occ into a 128-channel buffer: variant %d %.1f us | fused warp+corr(+occ): variant %d %.1f us vs warp %.1f + corr %.1f = %.1f us\n", var_wide,
            b_wide, var_fused, c, d, b, d + b);
