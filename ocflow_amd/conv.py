@@ -244,8 +244,9 @@ IGEMM_POLICY = int(os.environ.get("OCFLOW_CONV_POLICY", "0"))
 
 
 def igemm_raw(x, packed: _Packed, cout: int, bias=None, act=None, dilation: int = 1, negative_slope: float = 1.0, mask_slope: float = 1.0,
-              out=None, policy: Optional[int] = None):
-    """ocf_conv3x3_igemm on a channels_last bf16 view `x` [B,Cin,H,W] with a packed weight; returns `out` (allocated channels_last when None)"""
+              out=None, policy: Optional[int] = None, res=None, res_premask: bool = False, act_channels: Optional[int] = None):
+    """ocf_conv3x3_igemm on a channels_last bf16 view `x` [B,Cin,H,W] with a packed weight; returns `out` (allocated channels_last when None).
+    res / res_premask / act_channels: the residual epilogue of ocf_conv3x3_igemm_ex (`res` may be `out` itself)"""
     _require_hip(x)
     B, cin, H, W = x.shape
     cin = min(cin, packed.k)  # channels past the packed weight's k (alignment channels of a concatenation) meet no weight
@@ -259,9 +260,16 @@ def igemm_raw(x, packed: _Packed, cout: int, bias=None, act=None, dilation: int 
         if b32.dtype != torch.float32:
             b32 = b32.float()
     with torch.cuda.device(x.device):
-        fn = lambda: _lib.check(_lib.load().ocf_conv3x3_igemm(_t4(x), C.c_void_p(packed.dst.data_ptr()), packed.rows, packed.k, _t4(out), _ptr(b32),
-                                                               _t4(act), B, cin, cout, H, W, int(dilation), float(negative_slope), float(mask_slope),
-                                                               _lib.OCF_BF16, int(policy), _stream(x)), "ocf_conv3x3_igemm")
+        if res is None and act_channels is None:
+            fn = lambda: _lib.check(_lib.load().ocf_conv3x3_igemm(_t4(x), C.c_void_p(packed.dst.data_ptr()), packed.rows, packed.k, _t4(out), _ptr(b32),
+                                                                   _t4(act), B, cin, cout, H, W, int(dilation), float(negative_slope),
+                                                                   float(mask_slope), _lib.OCF_BF16, int(policy), _stream(x)), "ocf_conv3x3_igemm")
+        else:
+            ach = int(cout if act_channels is None else act_channels)
+            fn = lambda: _lib.check(_lib.load().ocf_conv3x3_igemm_ex(_t4(x), C.c_void_p(packed.dst.data_ptr()), packed.rows, packed.k, _t4(out),
+                                                                      _ptr(b32), _t4(act), _t4(res), int(bool(res_premask)), ach, B, cin, cout, H, W,
+                                                                      int(dilation), float(negative_slope), float(mask_slope), _lib.OCF_BF16,
+                                                                      int(policy), _stream(x)), "ocf_conv3x3_igemm_ex")
         ops._launch("conv3x3_igemm", lambda: ops._meta(f"B{B}x{cin}->{cout}x{H}x{W}d{dilation}", B * H * W * 2 * (cin + cout),
                                                        2 * B * H * W * 9 * cin * cout), fn)
     return out
@@ -599,6 +607,135 @@ def chain_eligible(x, convs) -> bool:
             return False
         cin = w.shape[0]
     return True
+
+
+class _DenseBlockFn(Function):
+    """DenseNet block `for j: x = cat(lrelu(conv_j(x)), x)` (cost_volume_flow_net.py:58-75,176-180 and the pwoc twin) on ONE channels_last
+    buffer  [conv_{n-1} | ... | conv_0 | part_0 | part_1 | ... | zeros to a multiple of 32]  as ONE autograd node:
+
+    forward : ocf_concat_channels writes the parts (+ alignment zeros) into the buffer's tail, then layer j reads the channel range
+              behind its own output and writes its output in front of it (ocf_conv3x3_igemm on slices): no torch.cat, no copy.
+    backward: ONE gradient buffer G of the same layout.  Layer n-1's output gradient = incoming[:, :w] * lrelu'  (one small elementwise
+              pass, which also reduces that layer's bias gradient).  Then for j = n-1 .. 0: weight + bias gradient
+              (ocf_conv3x3_wgrad_bias) and the input gradient by ocf_conv3x3_igemm_ex, whose epilogue ADDS into G[:, off_j:] -- the first
+              of them takes the incoming gradient as its residual -- and multiplies the channels that are activations of this block
+              (and the first `lead_mask_channels` of part 0: a cost volume whose LeakyReLU was fused into ocf_corr_fwd) by the
+              activation's derivative.  autograd's five cat-backward slicings and gradient-accumulation adds are gone."""
+
+    @staticmethod
+    def forward(ctx, n_parts, slope, lead_mask, *args):
+        parts, rest = args[:n_parts], args[n_parts:]
+        n = len(rest) // 2
+        ws, bs = rest[:n], rest[n:]
+        B, _, H, W = parts[0].shape
+        widths = [int(w.shape[0]) for w in ws]
+        tot = sum(widths)
+        cin = sum(int(p.shape[1]) for p in parts)
+        cin_al = (cin + 31) // 32 * 32
+        buf = torch.empty((B, tot + cin_al, H, W), device=parts[0].device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        ops.concat_raw(parts, buf[:, tot:], cin_al)
+        off = tot
+        for j in range(n):
+            igemm_raw(buf[:, off:], PACKER.get(ws[j], False), widths[j], bs[j], None, 1, slope, 1.0, out=buf[:, off - widths[j]:off])
+            off -= widths[j]
+        ctx.save_for_backward(buf, *ws, *bs)
+        ctx.cfg = (n_parts, float(slope), int(lead_mask), [int(p.shape[1]) for p in parts], widths)
+        return buf
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        n_parts, slope, lead_mask, part_ch, widths = ctx.cfg
+        n = len(widths)
+        saved = ctx.saved_tensors
+        buf, ws, bs = saved[0], saved[1:1 + n], saved[1 + n:]
+        dev = gy.device
+        B, ctot, H, W = buf.shape
+        tot = sum(widths)
+        g0 = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)
+        if not (_pixel_major(g0, 16) and g0.shape[1] == ctot):
+            g0 = g0.contiguous(memory_format=torch.channels_last)
+        G = torch.empty_like(buf)
+        need_w = [ctx.needs_input_grad[3 + n_parts + j] for j in range(n)]
+        need_b = [ctx.needs_input_grad[3 + n_parts + n + j] for j in range(n)]
+        gws, gbs = [None] * n, [None] * n
+        # the newest layer's output gradient: nothing but the consumers of the block adds into it.  ocf_bias_act_bwd wants dense
+        # operands beside the (sliced) incoming gradient: a 32-channel copy of that layer's output, a dense dz
+        wl = widths[-1]
+        y_last = buf[:, :wl].contiguous(memory_format=torch.channels_last)
+        dz_last = torch.empty_like(y_last)
+        gb_t, b_sink = _grad_target(bs[-1], dev) if need_b[-1] else (ops._take_zeros(wl, dev), False)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y_last), _t4(g0[:, :wl]), _t4(dz_last), C.c_void_p(gb_t.data_ptr()), B, wl, H, W,
+                                                    slope, 1, _lib.OCF_BF16, _stream(g0)), "ocf_bias_act_bwd")
+        if need_b[-1]:
+            gbs[-1] = None if b_sink else gb_t
+        off = 0  # start of layer j's OUTPUT range; its input range starts at off + widths[j]
+        for j in range(n - 1, -1, -1):
+            o_in = off + widths[j]
+            x_j, dz_j = buf[:, o_in:], (dz_last if j == n - 1 else G[:, off:o_in])
+            if need_w[j] or need_b[j]:
+                gw_t, w_sink = _grad_target(ws[j], dev)
+                gb2, b_sink = (None, False)
+                if need_b[j] and j != n - 1:
+                    gb2, b_sink = _grad_target(bs[j], dev)
+                wgrad_bias_raw(x_j, dz_j, gw_t, gb2, 1)
+                gws[j] = None if w_sink else gw_t
+                if gb2 is not None:
+                    gbs[j] = None if b_sink else gb2
+            cout = ctot - o_in
+            first = j == n - 1
+            igemm_raw(dz_j, PACKER.get(ws[j], True, cout), cout, None, buf[:, o_in:], 1, 1.0, slope, out=G[:, o_in:],
+                      res=(g0[:, o_in:] if first else G[:, o_in:]), res_premask=first, act_channels=(tot - o_in) + lead_mask)
+            off = o_in
+        gbs = [g if (g is None or g.dtype == b.dtype) else g.to(b.dtype) for g, b in zip(gbs, bs)]
+        gparts, c0 = [], tot
+        for i, c in enumerate(part_ch):
+            gparts.append(G[:, c0:c0 + c] if ctx.needs_input_grad[3 + i] else None)
+            c0 += c
+        return (None, None, None, *gparts, *gws, *gbs)
+
+
+def dense_block_eligible(parts, convs, lead_channels: int = 0, like=None) -> bool:
+    """the block runs on the slice kernels forward AND backward: bf16 pixel-major parts on a HIP device, 3x3 / stride-1 / padding-1
+    layers with bias and a multiple of 8 output channels whose input widths follow the dense pattern.  lead_channels: channels of a
+    part 0 that is not computed yet (the cost volume: a dense channels_last tensor with the batch / map size of `like`) and will be put
+    in front of `parts` (which may then be empty: level 6)"""
+    if not (enabled() and _native_wgrad() and os.environ.get("OCFLOW_NATIVE_DENSE", "1") != "0"):
+        return False
+    parts = list(parts)
+    ref = parts[0] if parts else like
+    if ref is None or not (torch.is_tensor(ref) and ref.is_cuda and ref.dim() == 4) or (not parts and not lead_channels):
+        return False
+    if lead_channels and not (like is not None and like.is_cuda and like.dtype == torch.bfloat16 and like.shape[0] == ref.shape[0]
+                              and like.shape[2:] == ref.shape[2:]):
+        return False
+    if len(parts) + (1 if lead_channels else 0) > 6 or (parts and not ops.concat_channels_eligible(parts)):
+        return False
+    cin = sum(int(p.shape[1]) for p in parts) + int(lead_channels)
+    if (cin + 31) // 32 * 32 > ops.CONCAT_MAX_CHANNELS:
+        return False
+    tot = sum(int(c.weight.shape[0]) for c in convs)
+    B, _, H, W = ref.shape
+    if B * H * W * (tot + (cin + 31) // 32 * 32) >= _MAX_ELEMS:
+        return False
+    for c in convs:
+        w = c.weight
+        if c.bias is None or c.padding_mode != "zeros" or w.shape[0] % 8 != 0 or tuple(w.shape[2:]) != (3, 3) or c.groups != 1 \
+                or tuple(c.stride) != (1, 1) or tuple(c.dilation) != (1, 1) or tuple(c.padding) != (1, 1) or w.shape[1] != cin \
+                or w.dtype not in (torch.bfloat16, torch.float32):
+            return False
+        cin += int(w.shape[0])
+    return True
+
+
+def conv3x3_dense_block(parts, convs, negative_slope: float = 0.1, lead_mask_channels: int = 0):
+    """[conv_{n-1}(..) | ... | conv_0(cat(parts)) | cat(parts) | alignment zeros] -- the value of `for c in convs: x = cat(lrelu(c(x)), x)`
+    with zero channels appended up to a multiple of 32 -- as one autograd node on one buffer; the caller checks `dense_block_eligible`.
+    lead_mask_channels: the first that many channels of parts[0] are the output of a LeakyReLU (same slope) whose derivative this
+    node applies to their gradient (ops.compute_cost_volume(..., leaky_slope, grad_premasked=True))."""
+    return _DenseBlockFn.apply(len(parts), float(negative_slope), int(lead_mask_channels), *parts, *[c.weight for c in convs],
+                               *[c.bias for c in convs])
 
 
 def conv3x3_bias_act(x, weight, bias=None, negative_slope: float = 1.0, dilation: int = 1):

@@ -245,6 +245,188 @@ __global__ __launch_bounds__(64 * NW) void deconv_bwd_weight_kernel(const Args a
     atomicAdd(a.gbias + threadIdx.x, v);
   }
 }
+
+// ---- backward in ONE launch (round 5): input gradient + weight gradient + bias gradient -----------------------------------------------
+// The two-kernel form above spent 29-63 us per layer on megabytes of data (16 layers, 0.48 ms per step): its weight-gradient kernel gave
+// a wave 64 / Ci pixels per trip (two at Ci = 32) behind nine dependent 4-byte loads, and every one of up to 256 blocks of 1024 threads
+// ended in 9 Co Ci same-address atomics; the data-gradient kernel re-read the same nine taps with 2-byte loads.
+// Here a thread owns (input pixel, CPT channels) and walks the grid's share of them: per trip it loads the pixel's CPT channels (one
+// 16-byte load) and its nine output taps ONCE (Co channels each: one 4-byte load when Co = 2), forms the CPT input gradients from the
+// weights in LDS and adds its CPT x 9 Co products to register accumulators.  At the end the lanes that hold the same channel group
+// (lane % (Ci / CPT)) are summed by shuffles, the four waves through LDS, and a block adds its 9 Co Ci sums with one atomic each --
+// at most 128 blocks.  The bias gradient is the sum of the taps (ky, kx) in {1, 2}^2 -- every output pixel is exactly one of those --
+// taken by the threads of channel group 0.
+template <int CO, int CPT, int CG>
+__global__ __launch_bounds__(256) void deconv_bwd_fused_kernel(const Args a, int need_gx) {
+  constexpr int cg = CG;  // channel groups per pixel = Ci / CPT (compile time: the shuffle tree below must unroll into independent chains)
+  extern __shared__ float smem[];  // [9][CO][Ci] weights, then [4][9 CO Ci] wave sums
+  __shared__ float redb[4][CO];
+  const int n = 9 * CO * a.Ci;
+  float* sw = smem;
+  float* red = smem + ((n + 3) & ~3);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (need_gx) stage_w(a, sw);
+  const unsigned npix = (unsigned)(a.B * a.H * a.W), nitem = npix * (unsigned)cg;
+  const bool pair = CO == 2 && (a.gyp & 1) == 0 && ((uintptr_t)a.gy & 3) == 0 && (!a.act || ((a.yap & 1) == 0 && ((uintptr_t)a.ya & 3) == 0));
+  float acc[CPT][9 * CO];
+#pragma unroll
+  for (int j = 0; j < CPT; j++)
+#pragma unroll
+    for (int t = 0; t < 9 * CO; t++) acc[j][t] = 0.f;
+  float bsum[CO];
+#pragma unroll
+  for (int co = 0; co < CO; co++) bsum[co] = 0.f;
+  const unsigned stride = gridDim.x * 256u;
+  const unsigned trips = (nitem + stride - 1) / stride;  // the same for every thread: the shuffles below need whole waves
+  for (unsigned it = 0; it < trips; it++) {
+    const unsigned i = it * stride + blockIdx.x * 256u + tid;
+    const bool valid = i < nitem;
+    const unsigned iv = valid ? i : 0u;
+    const unsigned p = iv / (unsigned)cg;
+    const int c0 = (int)(iv - p * cg) * CPT;
+    const unsigned row = p / (unsigned)a.W;
+    const int ix = (int)(p - row * a.W), b = (int)(row / (unsigned)a.H), iy = (int)(row - b * a.H);
+    // ---- loads: all issued before the first use, from always-valid addresses (masked by `ok`)
+    float xv[CPT];
+    const bf16* xr = a.x + (long)p * a.xp + c0;
+    if (CPT == 8) {
+      const uint4 v = *(const uint4*)xr;
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) { xv[(2 * j) % CPT] = __uint_as_float(u[j] << 16); xv[(2 * j + 1) % CPT] = __uint_as_float(u[j] & 0xffff0000u); }
+    } else if (CPT == 4) {
+      const uint2 v = *(const uint2*)xr;
+      const unsigned u[2] = {v.x, v.y};
+#pragma unroll
+      for (int j = 0; j < 2; j++) { xv[(2 * j) % CPT] = __uint_as_float(u[j] << 16); xv[(2 * j + 1) % CPT] = __uint_as_float(u[j] & 0xffff0000u); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CPT; j++) xv[j] = (float)xr[j];
+    }
+    unsigned graw[9], yraw[9];
+    bool okt[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const int oy = 2 * iy - 1 + ky;
+      const bool oky = oy >= 0 && oy < a.Ho;
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int ox = 2 * ix - 1 + kx;
+        const bool ok = valid && oky && ox >= 0 && ox < a.Wo;
+        const long op = ((long)b * a.Ho + (oky ? oy : 0)) * a.Wo + ((ox >= 0 && ox < a.Wo) ? ox : 0);
+        const int t = ky * 3 + kx;
+        okt[t] = ok;
+        if (pair) {
+          graw[t] = *(const unsigned*)(a.gy + op * a.gyp);
+          yraw[t] = a.act ? *(const unsigned*)(a.ya + op * a.yap) : 0u;
+        } else {
+          unsigned g = 0u, y = 0u;
+#pragma unroll
+          for (int co = 0; co < CO; co++) {
+            g |= (unsigned)__builtin_bit_cast(unsigned short, a.gy[op * a.gyp + co]) << (16 * (co & 1));
+            if (a.act) y |= (unsigned)__builtin_bit_cast(unsigned short, a.ya[op * a.yap + co]) << (16 * (co & 1));
+          }
+          graw[t] = g; yraw[t] = y;  // (CO <= 2: both channels fit one dword)
+        }
+      }
+    }
+    if (!valid) {
+#pragma unroll
+      for (int j = 0; j < CPT; j++) xv[j] = 0.f;
+    }
+    float gv[9][CO];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int co = 0; co < CO; co++) {
+        float g = co == 0 ? __uint_as_float(graw[t] << 16) : __uint_as_float(graw[t] & 0xffff0000u);
+        if (a.act) {
+          const float y = co == 0 ? __uint_as_float(yraw[t] << 16) : __uint_as_float(yraw[t] & 0xffff0000u);
+          g = (float)(bf16)((g * (1.f - y)) * y);  // (dz_at: the framework's sigmoid_backward, rounded to the feature dtype)
+        }
+        gv[t][co] = okt[t] ? g : 0.f;
+      }
+    // ---- weight gradient
+#pragma unroll
+    for (int j = 0; j < CPT; j++)
+#pragma unroll
+      for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int co = 0; co < CO; co++) acc[j][t * CO + co] = __builtin_fmaf(xv[j], gv[t][co], acc[j][t * CO + co]);
+    // ---- bias gradient: taps (1,1) (1,2) (2,1) (2,2) partition the output pixels
+    if (c0 == 0) {
+#pragma unroll
+      for (int co = 0; co < CO; co++) bsum[co] += (gv[4][co] + gv[5][co]) + (gv[7][co] + gv[8][co]);
+    }
+    // ---- input gradient
+    if (need_gx) {
+      float gx[CPT];
+#pragma unroll
+      for (int j = 0; j < CPT; j++) gx[j] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int co = 0; co < CO; co++) {
+          const float* wr = sw + (t * CO + co) * a.Ci + c0;
+#pragma unroll
+          for (int j = 0; j < CPT; j++) gx[j] = __builtin_fmaf(gv[t][co], wr[j], gx[j]);
+        }
+      if (valid) {
+        bf16* o = a.gx + (long)p * a.gxp + c0;
+        if (CPT == 8) {
+          bf16x8 v;
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = (bf16)gx[j % CPT];
+          *(bf16x8*)o = v;
+        } else if (CPT == 4) {
+          typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+          bf16x4v v;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = (bf16)gx[j % CPT];
+          *(bf16x4v*)o = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < CPT; j++) o[j] = (bf16)gx[j];
+        }
+      }
+    }
+  }
+  // ---- sum over the lanes of the same channel group, then over the block's waves.  One tree LEVEL at a time over a whole row of 9 CO
+  // values: the exchanges of a level are independent and go out back to back (written value by value, the compiler waited for every
+  // single ds_bpermute before issuing the next: 576 dependent round trips, 25 us of a 31 us launch)
+  const int grp = lane & (cg - 1);
+#pragma unroll
+  for (int j = 0; j < CPT; j++) {
+#pragma unroll
+    for (int o = 32; o >= cg; o >>= 1) {
+      float tmp[9 * CO];
+#pragma unroll
+      for (int k = 0; k < 9 * CO; k++) tmp[k] = __shfl_xor(acc[j][k], o, 64);
+#pragma unroll
+      for (int k = 0; k < 9 * CO; k++) acc[j][k] += tmp[k];
+    }
+    if (lane < cg) {
+#pragma unroll
+      for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int co = 0; co < CO; co++) red[wid * n + ((grp * CPT + j) * CO + co) * 9 + t] = acc[j][t * CO + co];  // [ci][co][ky][kx]
+    }
+  }
+  if (a.gbias) {
+#pragma unroll
+    for (int co = 0; co < CO; co++) {
+      const float t = wave_sum(bsum[co]);
+      if (lane == 0) redb[wid][co] = t;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const float v = (red[i] + red[n + i]) + (red[2 * n + i] + red[3 * n + i]);
+    const int t = i % 9, r = i / 9, co = r % CO, c = r / CO;
+    atomicAdd(a.gw + c * a.gsi + co * a.gso + (t / 3) * a.gsy + (t % 3) * a.gsx, v);
+  }
+  if (a.gbias && tid < CO) atomicAdd(a.gbias + tid, (redb[0][tid] + redb[1][tid]) + (redb[2][tid] + redb[3][tid]));
+}
 }  // namespace dcv
 }  // namespace ocf
 
@@ -317,6 +499,55 @@ extern "C" int ocf_deconv3x3s2_bwd(const ocf_tensor4* x, const void* w, int64_t 
   a.gw = gw; a.gsi = g_si; a.gso = g_so; a.gsy = g_sy; a.gsx = g_sx; a.gbias = gbias;
   LaunchProf lp;
   bool launched = false;
+  // ONE launch for all three gradients where the fused kernel takes the layer: a weight gradient is wanted, Co <= 2, Ci in {1, 2} or
+  // a multiple of 8 whose channel groups divide a wave (8, 16, 32, 64) with 16-byte aligned pixels
+  if (gw && Co <= 2) {
+    const bool wide = Ci % 8 == 0 && (Ci == 8 || Ci == 16 || Ci == 32 || Ci == 64) && a.xp % 8 == 0 && ((uintptr_t)a.x & 15) == 0;
+    bool gx_ok = true;
+    long gxp = 0, dummy = 0;
+    if (gx) {
+      if (!gx->data) return OCF_EINVAL;
+      dcv::Args t = a;
+      gx_ok = dcv_fill(t, gx, Ci, H, W, gy, Co, Ho, Wo, B, &gxp, &dummy) && (!wide || (gxp % 8 == 0 && ((uintptr_t)gx->data & 15) == 0));
+    }
+#ifdef OCF_TUNING_BUILD
+    static const bool off = getenv("OCF_DECONV_BWD_SPLIT") != nullptr;  // (A/B: the two-kernel form)
+#else
+    constexpr bool off = false;
+#endif
+    if (!off && gx_ok && (wide || Ci <= 2)) {
+      // channels per thread: 4 for the wide layers (72 accumulators at Co = 2: two waves per SIMD; with 8 the kernel sat at 256 registers,
+      // one wave per SIMD, and every trip's load round trip was exposed), the whole pixel for Ci <= 2
+#ifdef OCF_TUNING_BUILD
+      static const int cpt_env = getenv("OCF_DECONV_CPT") ? atoi(getenv("OCF_DECONV_CPT")) : 0;
+#else
+      constexpr int cpt_env = 0;  // (measured: 264.6 us with 8 channels per thread against 245.5 with 4 over the 16 layers of scripts/bench_deconv.py)
+#endif
+      const int cpt = wide ? ((cpt_env == 8 || Ci == 8) ? 8 : 4) : Ci, cg = Ci / cpt;
+      if (gx) { a.gx = (bf16*)gx->data; a.gxp = gxp; }
+      const long nitem = (long)B * H * W * cg;
+      // at most 256 blocks (every block ends in 9 Co Ci atomics on the same addresses)
+      long blocks = (nitem + 255) / 256;
+      if (blocks > 256) blocks = 256;
+      if (blocks < 1) blocks = 1;
+      const int n = 9 * Co * Ci;
+      const size_t lds = (size_t)(((n + 3) & ~3) + 4 * n) * sizeof(float);
+      const dim3 grid((unsigned)blocks);
+      const int need_gx = gx ? 1 : 0;
+#define OCF_DCV_FUSED(CO, CPT, CG) lp.launch(true, dcv::deconv_bwd_fused_kernel<CO, CPT, CG>, grid, dim3(256), lds, (hipStream_t)stream, a, need_gx)
+#define OCF_DCV_FUSED_CO(CO)                                                                                       \
+  if (cpt == 8) {                                                                                                  \
+    if (cg == 1) OCF_DCV_FUSED(CO, 8, 1); else if (cg == 2) OCF_DCV_FUSED(CO, 8, 2);                                \
+    else if (cg == 4) OCF_DCV_FUSED(CO, 8, 4); else OCF_DCV_FUSED(CO, 8, 8);                                        \
+  } else if (cpt == 4) {                                                                                           \
+    if (cg == 4) OCF_DCV_FUSED(CO, 4, 4); else if (cg == 8) OCF_DCV_FUSED(CO, 4, 8); else OCF_DCV_FUSED(CO, 4, 16); \
+  } else if (cpt == 2) OCF_DCV_FUSED(CO, 2, 1); else OCF_DCV_FUSED(CO, 1, 1);
+      if (Co == 1) { OCF_DCV_FUSED_CO(1) } else { OCF_DCV_FUSED_CO(2) }
+#undef OCF_DCV_FUSED_CO
+#undef OCF_DCV_FUSED
+      return launch_status();
+    }
+  }
   if (gx) {
     if (!gx->data) return OCF_EINVAL;
     long gxp, dummy;

@@ -75,6 +75,35 @@ def dense_block(net, lvl, x):
     return x
 
 
+def dense_convs(net, lvl):
+    return [getattr(net, f"conv{lvl}_{j}")[0] for j in range(5)]  # (ConvLReLU = Sequential(conv, LeakyReLU(0.1)))
+
+
+def level_features(net, lvl, corr_fn, others, native, like, dense=None):
+    """decoder features of one pyramid level: LeakyReLU(cost volume), concatenated in front of `others`, through the level's dense block
+    (cost_volume_flow_net.py:172-180,188-195; cost_volume_flow_occ_net.py:188-213).  `corr_fn(leaky_slope=..., grad_premasked=...)`
+    computes the cost volume of features shaped like `like`.  In the bf16 channels_last configuration the whole level is ONE buffer:
+    ocf_corr_fwd applies the LeakyReLU in its store epilogue, ocf_concat_channels writes [corr | others | zeros] into the buffer's tail and
+    every dense layer reads / writes channel ranges of it (conv.conv3x3_dense_block) -- no torch.cat, no separate activation pass.
+    Otherwise: the reference's op chain (with the concatenation aligned to 32 channels when `native`)."""
+    convs = dense_convs(net, lvl)
+    others = [t if t.dtype == like.dtype else t.to(like.dtype) for t in others]
+    dense = native if dense is None else dense
+    if dense and nconv.dense_block_eligible(others, convs, lead_channels=(2 * int(getattr(net, 'displacement', 4)) + 1) ** 2, like=like):
+        corr = corr_fn(leaky_slope=0.1, grad_premasked=True)
+        parts = [corr] + others
+        if not nconv.dense_block_eligible(parts, convs):  # (cannot happen for the dense channels_last volume ocf_corr_fwd returns)
+            raise RuntimeError(f"level_features: cost volume layout {tuple(corr.shape)} / {corr.stride()} / {corr.dtype}")
+        return nconv.conv3x3_dense_block(parts, convs, 0.1, lead_mask_channels=int(corr.shape[1]))
+    corr = corr_fn(leaky_slope=0.1, grad_premasked=False)
+    if others:
+        parts = [corr] + [t.to(corr.dtype) for t in others]
+        feats = cat_aligned(parts) if native else torch.cat(parts, 1)
+    else:
+        feats = cat_aligned([corr]) if native else corr
+    return dense_block(net, lvl, feats)
+
+
 class FlowNetCV(nn.Module):
     def __init__(self, displacement=4):
         super().__init__()
@@ -110,7 +139,6 @@ class FlowNetCV(nn.Module):
         env = os.environ.get("OCFLOW_PAD_PWC", "auto")
         native = env == "auto" and nconv.enabled() and x.is_cuda and torch.is_autocast_enabled() and not torch.compiler.is_compiling()
         pad = env == "1" or native
-        cat = cat_aligned if pad else torch.cat
         c1 = encode(self, x[:, :3])
         c2 = encode(self, x[:, 3:])
         up_flow = up_feat = flow = feats = None
@@ -119,13 +147,11 @@ class FlowNetCV(nn.Module):
             if lvl < 6:
                 f2 = ops.warp(f2, up_flow, False, flow_scale=WARP_SCALE[lvl])
             f1, f2 = self.normalize([f1, f2])
-            corr = self.leakyRELU(ops.compute_cost_volume(f1, f2, max_displacement=self.displacement))
-            if lvl == 6:
-                feats = cat_aligned([corr]) if native else corr
-            else:
-                # the NORMALISED c1 is what enters the decoder (:190)
-                feats = cat((corr, f1, up_flow.to(corr.dtype), up_feat.to(corr.dtype)), 1)
-            feats = dense_block(self, lvl, feats)
+            # LeakyReLU(cost volume) [| normalised c1 | up_flow | up_feat] through the dense block (the NORMALISED c1 is what enters the
+            # decoder: SURVEY F6, :190)
+            corr_fn = lambda leaky_slope, grad_premasked, a=f1, b=f2: ops.compute_cost_volume(
+                a, b, max_displacement=self.displacement, leaky_slope=leaky_slope, grad_premasked=grad_premasked)
+            feats = level_features(self, lvl, corr_fn, [] if lvl == 6 else [f1, up_flow, up_feat], pad, f1, dense=native)
             if pad:
                 flow = conv_bias(getattr(self, f"predict_flow{lvl}"), feats)
                 if lvl > 2:

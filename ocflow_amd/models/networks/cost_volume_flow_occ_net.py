@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from ._epilogue import cat_aligned, conv_bias, deconv_bias
 from .cost_volume_flow_net import (DENSE_TOTAL, DENSE_WIDTHS, ENC_WIDTHS, WARP_SCALE, build_context, build_encoder, context,
-                                   conv, deconv, dense_block, encode, predict_flow)
+                                   conv, deconv, dense_block, encode, level_features, predict_flow)
 from .cost_volume_net import CostVolumeLayer
 from .flow_net import kaiming_init_
 from ocflow_amd import conv as nconv
@@ -60,15 +60,18 @@ class FlowOccNetCV(nn.Module):
         up_flow = up_occ = up_feat = flow = occ = feats = None
         for lvl in range(6, 1, -1):
             f1, f2 = c1[lvl - 1], c2[lvl - 1]
+            # LeakyReLU(cost volume of f1 against warp(f2) * up_occ) [| f1 | up_flow | up_occ | up_feat] through the dense block
+            # (cost_volume_flow_occ_net.py:188-213); see cost_volume_flow_net.level_features
+            d = self.corr.max_displacement
             if lvl == 6:
-                feats = self.leakyRELU(self.corr(f1, f2))
-                if native:
-                    feats = cat_aligned([feats])
+                corr_fn = lambda leaky_slope, grad_premasked, a=f1, b=f2: ops.corr_warp(
+                    a, b, None, None, d, leaky_slope=leaky_slope, grad_premasked=grad_premasked)
+                others = []
             else:
-                corr = self.leakyRELU(self.corr(f1, f2, up_flow, up_occ, WARP_SCALE[lvl]))
-                parts = (corr.to(f1.dtype), f1, up_flow.to(f1.dtype), up_occ.to(f1.dtype), up_feat.to(f1.dtype))
-                feats = cat_aligned(parts) if native else torch.cat(parts, 1)
-            feats = dense_block(self, lvl, feats)
+                corr_fn = lambda leaky_slope, grad_premasked, a=f1, b=f2, fl=up_flow, oc=up_occ, sc=WARP_SCALE[lvl]: ops.corr_warp(
+                    a, b, fl, oc, d, sc, False, leaky_slope=leaky_slope, grad_premasked=grad_premasked)
+                others = [f1, up_flow, up_occ, up_feat]
+            feats = level_features(self, lvl, corr_fn, others, native, f1)
             if native:
                 flow = conv_bias(getattr(self, f"predict_flow{lvl}"), feats)
                 po = getattr(self, f"predict_occ{lvl}")

@@ -1000,17 +1000,28 @@ def psnr(img1, img2, pixel_max=255.0, per_sample=True):
 
 
 # ------------------------------------------------------------------------- channel concatenation of the decoder inputs
+def concat_raw(parts, out, cout: int):
+    """ocf_concat_channels into `out` = a [B, cout, H, W] bf16 channels_last tensor OR a channel slice of a wider one (16-byte aligned
+    pixels): out[:, :sum C_k] = cat(parts), out[:, sum C_k:] = 0"""
+    B, _, H, W = parts[0].shape
+    n = len(parts)
+    t4s = [_lib.Tensor4(t.data_ptr(), *t.stride()) for t in parts]
+    arr = (C.POINTER(_lib.Tensor4) * n)(*[C.pointer(t) for t in t4s])
+    chans = (C.c_int * n)(*[int(t.shape[1]) for t in parts])
+    with torch.cuda.device(out.device):
+        fn = lambda: _lib.check(_lib.load().ocf_concat_channels(arr, chans, n, _t4(out), int(cout), B, H, W, _lib.OCF_BF16, _stream(out)),
+                                "ocf_concat_channels")
+        _launch("concat", lambda: _meta(f"B{B}x{'+'.join(str(int(t.shape[1])) for t in parts)}->{cout}x{H}x{W}",
+                                        2 * B * H * W * (sum(int(t.shape[1]) for t in parts) + int(cout))), fn)
+    return out
+
+
 class _ConcatFn(Function):
     @staticmethod
     def forward(ctx, cout, *parts):
         B, _, H, W = parts[0].shape
         out = torch.empty((B, cout, H, W), device=parts[0].device, dtype=torch.bfloat16, memory_format=torch.channels_last)
-        n = len(parts)
-        t4s = [_lib.Tensor4(t.data_ptr(), *t.stride()) for t in parts]
-        arr = (C.POINTER(_lib.Tensor4) * n)(*[C.pointer(t) for t in t4s])
-        chans = (C.c_int * n)(*[int(t.shape[1]) for t in parts])
-        with torch.cuda.device(out.device):
-            _lib.check(_lib.load().ocf_concat_channels(arr, chans, n, _t4(out), int(cout), B, H, W, _lib.OCF_BF16, _stream(out)), "ocf_concat_channels")
+        concat_raw(parts, out, cout)
         ctx.sizes = [int(t.shape[1]) for t in parts]
         return out
 

@@ -7,8 +7,19 @@ from contextlib import contextmanager
 from oracle import ocflow_oracle as O
 
 
-def _corr_warp(f1, f2, flow=None, occ=None, max_displacement=4, flow_scale=1.0, align_corners=False):
-    return O.corr_warp(f1, f2, flow, occ, max_displacement, flow_scale, align_corners)
+def _lrelu(cv, leaky_slope):
+    """the activation the PWC-style nets apply to the cost volume (cost_volume_flow_net.py:173,189): the product fuses it into the launch"""
+    import torch.nn.functional as F
+    return F.leaky_relu(cv, float(leaky_slope)) if leaky_slope else cv
+
+
+def _corr_warp(f1, f2, flow=None, occ=None, max_displacement=4, flow_scale=1.0, align_corners=False, out=None, *, leaky_slope=0.0,
+               grad_premasked=False):
+    return _lrelu(O.corr_warp(f1, f2, flow, occ, max_displacement, flow_scale, align_corners), leaky_slope)
+
+
+def _compute_cost_volume(features1, features2, max_displacement=4, *, leaky_slope=0.0, grad_premasked=False):
+    return _lrelu(O.compute_cost_volume(features1, features2, max_displacement), leaky_slope)
 
 
 def _warp(img, flow, align_corners=False, flow_scale=1.0):
@@ -33,7 +44,7 @@ def _occ_from_flow(flow):
 
 PATCHES = {
     "corr_warp": _corr_warp,
-    "compute_cost_volume": O.compute_cost_volume,
+    "compute_cost_volume": _compute_cost_volume,
     "warp": _warp,
     "normalize_features": _normalize,
     "warp_photometric_error": _warp_photo,

@@ -20,7 +20,12 @@ with open(path) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                      (int(r.get("Grid_Size_X", 0) or 0), int(r.get("Grid_Size_Y", 0) or 0), int(r.get("Grid_Size_Z", 0) or 0))))
 rows.sort()
+import os
 marks = [i for i, r in enumerate(rows) if "corr_fwd_wave<7" in r[2] or "corr_fwd_waveILi7" in r[2]]
+# OCF_MARKS_PER_STEP=2: the occlusion-aware unsupervised step runs the network twice (models/model.py:376,384): two coarsest-level
+# correlation launches per step
+mps = int(os.environ.get("OCF_MARKS_PER_STEP", "1"))
+marks = marks[::mps]
 steps = [(rows[b][0] - rows[a][0], a, b) for a, b in zip(marks[:-1], marks[1:])]
 med = statistics.median(s[0] for s in steps)
 rep = [s for s in steps if abs(s[0] - med) < 0.1 * med]
