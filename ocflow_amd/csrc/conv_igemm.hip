@@ -295,20 +295,37 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_igemm_kernel(const Args a) {
     if (s + 1 < nstage && early && !(a.tune & 2)) issue(s + 1);
     const char* buf = smem + (s & 1) * buf_bytes;
     const char* wbuf = buf + pix_bytes + aoff;
+    // Fragment reads are software-pipelined by hand: the weight fragment of step (kx, m + 1) -- and, at the end of a tap, the four pixel
+    // fragments of tap kx + 1 -- are requested BEFORE the four MFMAs of step (kx, m) issue.  Left to the compiler, every step was
+    // `ds_read_b128 aq; s_waitcnt lgkmcnt(0); 4 x v_mfma` into ONE register quad: 24 exposed LDS round trips per stage and wave
+    // (~100 cycles each beside 64 cycles of matrix work), which is why the fragment-read and matrix phases of this kernel ADDED in the
+    // round-4 ablation instead of overlapping.
+    if (!(a.tune & 1)) {
+      bf16x8 bq[2][4], aq[2];
 #pragma unroll
-    for (int kx = 0; kx < 3; kx++) {
-      if (!(a.tune & 1)) {
-        bf16x8 bq[4];
+      for (int j = 0; j < 4; j++) bq[0][j] = *(const bf16x8*)(buf + boff[j][0]);
+      aq[0] = *(const bf16x8*)(wbuf);
 #pragma unroll
-        for (int j = 0; j < 4; j++) bq[j] = *(const bf16x8*)(buf + boff[j][kx]);
+      for (int kx = 0; kx < 3; kx++) {
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-          const bf16x8 aq = *(const bf16x8*)(wbuf + (kx * MT + m) * 1024);
+          const int st = kx * MT + m;  // (all indices below are compile-time after unrolling)
+          if (m + 1 < MT) {
+            aq[(st + 1) & 1] = *(const bf16x8*)(wbuf + (st + 1) * 1024);
+          } else if (kx + 1 < 3) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq[j], acc[m][j], 0, 0, 0);
+            for (int j = 0; j < 4; j++) bq[(kx + 1) & 1][j] = *(const bf16x8*)(buf + boff[j][kx + 1]);
+            aq[(st + 1) & 1] = *(const bf16x8*)(wbuf + (st + 1) * 1024);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // the requests above stay above the matrix work below
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[st & 1], bq[kx & 1][j], acc[m][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (kx == SPLIT_KX && s + 1 < nstage && !early && !(a.tune & 2)) issue(s + 1);
       }
-      if (kx == SPLIT_KX && s + 1 < nstage && !early && !(a.tune & 2)) issue(s + 1);
+    } else if (s + 1 < nstage && !early && !(a.tune & 2)) {
+      issue(s + 1);
     }
   }
 

@@ -6,6 +6,8 @@ Charbonnier photometric error (+ occlusion mask), first/second-order edge-aware 
 the backward flow -- runs as fused HIP kernels (ops.warp_photometric_error, ops.smoothness_losses,
 ops.occlusion_from_flow).  The two-stage trainers (model.py:928-1394) are in two_stage_model.py and re-exported here; the
 inpainting-stage GAN trainers (model.py:511-926) are out of scope."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.optim import Adam
@@ -57,11 +59,11 @@ class FlowStageModel(HotPathHelpers, LightningModule):
         return self.flow_pred(x)
 
     # ------------------------------------------------------------------------------------------ loss side
-    def _predict(self, imgs):
+    def _predict(self, imgs, net_out=None):
         """-> (full-res flow, flow used by the smoothness terms, image used by the smoothness terms)"""
         img1 = imgs[:, 0:3]
         if self.model == "pwc":
-            flow_pred, flow_l2 = self(imgs)
+            flow_pred, flow_l2 = self(imgs) if net_out is None else net_out
             img1_l2 = F.interpolate(img1, scale_factor=0.25, mode="bilinear", align_corners=True)
             return flow_pred, flow_l2, img1_l2
         flow_pred = self(imgs)
@@ -100,9 +102,16 @@ class FlowStageModel(HotPathHelpers, LightningModule):
         """photometric masked by the range-map occlusion of the backward flow  (models/model.py:366-409)"""
         imgs, flow, occ = self._unpack(batch)
         img1, img2 = imgs[:, 0:3], imgs[:, 3:6]
-        pred = self._predict(imgs)  # forward flow first, then the no-grad backward flow, as the reference orders them
+        two_way = getattr(self.flow_pred, "forward_two_way", None)
+        if two_way is not None and os.environ.get("OCFLOW_SHARED_ENCODER", "1") != "0":
+            # both directions from ONE encoder pass (FlowNetCV: no batch-coupled layer, the swapped call's pyramids are these, swapped)
+            out, back = two_way(imgs)
+            pred = self._predict(imgs, out)
+        else:
+            pred = self._predict(imgs)  # forward flow first, then the no-grad backward flow, as the reference orders them
+            with torch.no_grad():
+                back = self(torch.cat((img2, img1), dim=1))
         with torch.no_grad():
-            back = self(torch.cat((img2, img1), dim=1))
             back_flow = back[0] if self.model == "pwc" else back
             occ_pred = ops.occlusion_from_flow(back_flow)  # 0: non-occluded, 1: occluded
         flow_pred, photo, smooth1, smooth2, flow_error = self._losses(imgs, flow, occ_pred, pred)

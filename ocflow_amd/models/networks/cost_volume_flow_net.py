@@ -129,7 +129,33 @@ class FlowNetCV(nn.Module):
         """feature warp, align_corners=False variant (cost_volume_flow_net.py:121-151)"""
         return ops.warp(img, flow, align_corners=False)
 
+    def pyramids(self, x):
+        """(c1, c2): the siamese encoder on both images (cost_volume_flow_net.py:158-169).  The encoder has no batch-coupled layer, so the two
+        calls of the reference are ONE call on the 2B images of the pair (same values per image; half the launches of 18 layers, twice
+        the work per launch) in the bf16 throughput configuration, where ops.pair_input assembles that batch in one launch; every
+        other configuration (fp32 parity runs, CPU) calls the encoder per image, as the reference does"""
+        x1, x2 = x[:, :3], x[:, 3:]
+        if os.environ.get("OCFLOW_UNPAIRED_PWC", "0") != "1" and not torch.compiler.is_compiling() and ops.pair_input_eligible(x1, x2):
+            both = ops.pair_input(x1, x2)
+            B = x.shape[0]
+            feats = encode(self, both)
+            return [f[:B] for f in feats], [f[B:] for f in feats]
+        return encode(self, x1), encode(self, x2)
+
     def forward(self, x):
+        return self.decode(x, *self.pyramids(x))
+
+    def forward_two_way(self, x):
+        """(forward(x), forward(cat(x[:, 3:], x[:, :3])) without gradient): what the occlusion-aware step asks for in two calls
+        (models/model.py:376,384) -- the second call's pyramids ARE the first call's, swapped (same weights, no batch-coupled layer), so
+        the encoder runs once"""
+        c1, c2 = self.pyramids(x)
+        out = self.decode(x, c1, c2)
+        with torch.no_grad():
+            back = self.decode(x, [t.detach() for t in c2], [t.detach() for t in c1])
+        return out, back
+
+    def decode(self, x, c1, c2):
         # Aligned (32-channel) concatenations: with the repo's own convolution kernels consuming them (round 4: every dense-block layer,
         # the prediction layers and the context network run on ocf_conv3x3_igemm / ocf_conv3x3_wgrad_bias when their input has a multiple of
         # 8 channels) this is the default in the bf16 channels_last configuration.  The ONE library kernel class that met padded operands
@@ -139,8 +165,6 @@ class FlowNetCV(nn.Module):
         env = os.environ.get("OCFLOW_PAD_PWC", "auto")
         native = env == "auto" and nconv.enabled() and x.is_cuda and torch.is_autocast_enabled() and not torch.compiler.is_compiling()
         pad = env == "1" or native
-        c1 = encode(self, x[:, :3])
-        c2 = encode(self, x[:, 3:])
         up_flow = up_feat = flow = feats = None
         for lvl in range(6, 1, -1):
             f1, f2 = c1[lvl - 1], c2[lvl - 1]

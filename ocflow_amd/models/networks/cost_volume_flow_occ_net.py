@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from ._epilogue import cat_aligned, conv_bias, deconv_bias
-from .cost_volume_flow_net import (DENSE_TOTAL, DENSE_WIDTHS, ENC_WIDTHS, WARP_SCALE, build_context, build_encoder, context,
+from .cost_volume_flow_net import (DENSE_TOTAL, DENSE_WIDTHS, ENC_WIDTHS, WARP_SCALE, FlowNetCV, build_context, build_encoder, context,
                                    conv, deconv, dense_block, encode, level_features, predict_flow)
 from .cost_volume_net import CostVolumeLayer
 from .flow_net import kaiming_init_
@@ -55,8 +55,7 @@ class FlowOccNetCV(nn.Module):
         # (cost_volume_flow_net.py): the library's transposed convolution `upfeat` is handed the unpadded channel range
         native = (os.environ.get("OCFLOW_PAD_PWC", "auto") == "auto" and nconv.enabled() and x.is_cuda and torch.is_autocast_enabled()
                   and not torch.compiler.is_compiling())
-        c1 = encode(self, x[:, :3])
-        c2 = encode(self, x[:, 3:])
+        c1, c2 = FlowNetCV.pyramids(self, x)  # (both images through the encoder as one batch: no batch-coupled layer)
         up_flow = up_occ = up_feat = flow = occ = feats = None
         for lvl in range(6, 1, -1):
             f1, f2 = c1[lvl - 1], c2[lvl - 1]

@@ -153,7 +153,10 @@ def _dtype_code(t: torch.Tensor) -> int:
 
 
 def _is_cl(t: torch.Tensor) -> bool:
-    return t.stride(1) == 1 and t.size(1) > 1
+    # (a [B, C, 1, 1] map is both layouts at once: its results are allocated with the plain contiguous strides, which the library's
+    # convolutions then take with either weight format -- channels_last STRIDES on such a tensor made MIOpen demand channels_last weights
+    # of an NCHW model: the 1 x 1 top level of a 64 x 64 input)
+    return t.stride(1) == 1 and t.size(1) > 1 and (t.size(2) * t.size(3) > 1 or not t.is_contiguous())
 
 
 def _empty_like_layout(ref: torch.Tensor, shape, dtype=None) -> torch.Tensor:

@@ -20,6 +20,7 @@ ap.add_argument("--tw", type=int, default=0, help="policy of ocf_conv3x3_igemm: 
 ap.add_argument("--levels", default="2,3,4,5,6")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--ours-only", action="store_true", help="skip the library timings (kernel A/B runs)")
 args = ap.parse_args()
 use_repo_miopen_db(None)
 dev = "cuda:0"
@@ -90,6 +91,8 @@ for ci, co, d, H, W in layers:
         gx = torch.empty_like(x)
         d_ours = lambda: conv.igemm_raw(gy, pkt, ci, None, None, d, 1.0, 1.0, out=gx, policy=args.tw)
     d_lib = lambda: torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, [True, False, False])
+    if args.ours_only:
+        f_lib = f_lib_epi = d_lib = (lambda: None)
     fns = [f_ours, f_lib, f_lib_epi] + ([d_ours] if can_d else []) + [d_lib]
     for fn in fns:
         for _ in range(3):
