@@ -14,6 +14,6 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 echo "[profile] WRITE_SIZE pass"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --preroll 1 --cpu-seconds 0 --unsup-steps 2 --cfg3-steps 0 > $OUT/prof_${TAG}_write.log 2>&1 || exit 1
 true
-python3 $ROOT/scripts/summarize_prof.py $OUT/prof_${TAG} > $OUT/prof_${TAG}_summary.txt 2>&1
+python3 $ROOT/scripts/summarize_prof.py $OUT/prof_${TAG} ${OCF_PROF_KEEP:+--keep} > $OUT/prof_${TAG}_summary.txt 2>&1
 rm -f $OUT/prof_${TAG}*.log.bak
 ls -la $OUT | head -30

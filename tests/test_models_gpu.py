@@ -324,6 +324,48 @@ def test_feature_pyramid_pair_equals_two_calls(monkeypatch, mode):
         np.testing.assert_allclose(s1[k].numpy(), s0[k].numpy(), rtol=1e-4 if fp32 else 2e-2, atol=1e-5 if fp32 else 2e-3, err_msg=k)
 
 
+def test_feature_pyramid_bf16_native_kernels_are_no_worse_than_the_library(monkeypatch):
+    """the pair-vs-two-calls test above is a self-comparison with loose bars at the coarse levels.  This one measures
+    both bf16 paths of the encoder -- this repo's kernels (default) and the library's convolutions (OCFLOW_NATIVE_CONV=0) -- against the
+    fp32 run of the SAME network and weights, at an input large enough for the two coarsest levels to hold per-element statistics
+    (512 x 768: 8 x 12 and 16 x 24 pixels, 384 / 1536 values per channel at the paired batch of 4).  Every pyramid level and every
+    parameter gradient: relative L2 error of the native path <= 1.5 x the library path's + 1e-2 (both are bf16 roundings of the same
+    fp32 computation; the native kernels must not add an error of their own)."""
+    from ocflow_amd.models.networks.feature_pyramid_net import FeaturePyramidNet
+    gen = torch.Generator().manual_seed(21)
+    x1 = (torch.rand((2, 3, 512, 768), generator=gen) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    x2 = (torch.rand((2, 3, 512, 768), generator=gen) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    names = [k for k, _ in FeaturePyramidNet().named_parameters()]
+    runs = {}
+    for tag, env, amp in (("fp32", {}, False), ("native", {}, True), ("library", {"OCFLOW_NATIVE_CONV": "0"}, True)):
+        for k in ("OCFLOW_NATIVE_CONV",):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(0)
+        net = FeaturePyramidNet().to(DEV).to(memory_format=torch.channels_last).train()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            p1, p2 = net.forward_pair(x1, x2)
+            loss = sum((t.float() ** 2).mean() for t in p1) + 0.5 * sum(t.float().abs().mean() for t in p2)
+        grads = torch.autograd.grad(loss, list(net.parameters()))
+        runs[tag] = ([t.float() for t in p1 + p2], [g.float() for g in grads])
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    worst = []
+    for i, ref in enumerate(runs["fp32"][0]):
+        en, el = rel(runs["native"][0][i], ref), rel(runs["library"][0][i], ref)
+        worst.append((en / max(el, 1e-6), en, el, f"pyramid[{i}]"))
+        assert en <= 1.5 * el + 1e-2, ("pyramid", i, en, el)
+    gscale = max(float(g.norm()) for g in runs["fp32"][1])
+    for k, gn, gl, gr in zip(names, runs["native"][1], runs["library"][1], runs["fp32"][1]):
+        if float(gr.norm()) < 1e-3 * gscale:  # (mathematically zero gradients: a bias in front of a BatchNorm)
+            continue
+        en, el = rel(gn, gr), rel(gl, gr)
+        worst.append((en / max(el, 1e-6), en, el, k))
+        assert en <= 1.5 * el + 1e-2, (k, en, el)
+    worst.sort(reverse=True)
+    print("encoder bf16 error vs fp32, native / library (worst ratios):", [(round(r, 2), f"{a:.3f}", f"{b:.3f}", k) for r, a, b, k in worst[:4]])
+
+
 def _stepper(fused, graph, amp=None, batch=None, steps=6):
     """train `steps` steps of the supervised FlowOccModel step on one fixed batch; returns (losses, parameters)"""
     from ocflow_amd.models.flow_occ_model import FlowOccModel
