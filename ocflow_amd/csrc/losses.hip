@@ -386,7 +386,9 @@ __global__ __launch_bounds__(LB) void smooth_bwd_kernel(T4 img, T4 flow, const f
 // Same expressions, term by term, as the kernels above, with the hardware's 1-ulp square root / reciprocal square root / exp2 in place
 // of the correctly-rounded library expansions (sqrtf, division, expf are ~12 / ~10 / ~15 instructions each and there are 30 of them per
 // pixel in the backward pass, which was instruction-bound with them: 106 us for 102 MB): d / sqrt(d^2 + eps) = d * rsq(d^2 + eps).
-constexpr int SMR = 8;
+// rows per strip: a row is fetched once per strip + 2 (forward) / 4 (backward) halo rows.  Forward 16 (halo 1.125 x; round 3's 8: 34.1 ->
+// 26.3 us at 8 x 3 x 436 x 1024 on one box), backward 8 (with 16 its register window costs an occupancy step: 43.5 -> 48.4 us)
+constexpr int SMR_F = 16, SMR_B = 8;
 __device__ __forceinline__ float charb_hw(float d) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(d, d, 1e-6f)); }
 __device__ __forceinline__ float dcharb_hw(float d) { return d * __builtin_amdgcn_rsqf(__builtin_fmaf(d, d, 1e-6f)); }  // d / charb(d)
 struct Px5 { float i[3]; float f[2]; };
@@ -420,6 +422,7 @@ __device__ __forceinline__ float edge3(const Px5& a, const Px5& b, float alpha) 
 }
 
 struct StripId { int b, x, y0; };
+template <int SMR>
 __device__ __forceinline__ StripId strip_of(int xblocks, int ychunks) {
   int bid = blockIdx.x;
   const int xb = bid % xblocks;
@@ -432,7 +435,7 @@ template <bool CL>
 __global__ __launch_bounds__(LB) void smooth_fwd_rows_kernel(T4 img, T4 flow, double* sums, int H, int W, float alpha, int xblocks, int ychunks) {
   const float* im = (const float*)img.p;
   const float* fl = (const float*)flow.p;
-  const StripId t = strip_of(xblocks, ychunks);
+  const StripId t = strip_of<SMR_F>(xblocks, ychunks);
   const bool xin = t.x < W;
   const int xc = xin ? t.x : W - 1, x1 = xc + 1 < W ? xc + 1 : W - 1, x2 = xc + 2 < W ? xc + 2 : W - 1;
   const long ib = (long)t.b * img.sb, fb = (long)t.b * flow.sb;
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(LB) void smooth_fwd_rows_kernel(T4 img, T4 flow, do
     const int yc = y < H ? y : H - 1;
     const long oi = ib + (long)yc * img.sh, of = fb + (long)yc * flow.sh;
     c = load_px5<CL>(im, fl, oi + (long)xc * img.sw, of + (long)xc * flow.sw, img.sc, flow.sc);
-    if (r < SMR) {
+    if (r < SMR_F) {
       a1 = load_px5<CL>(im, fl, oi + (long)x1 * img.sw, of + (long)x1 * flow.sw, img.sc, flow.sc);
       a2 = load_px5<CL>(im, fl, oi + (long)x2 * img.sw, of + (long)x2 * flow.sw, img.sc, flow.sc);
     }
@@ -453,12 +456,12 @@ __global__ __launch_bounds__(LB) void smooth_fwd_rows_kernel(T4 img, T4 flow, do
   Px5 cn = {}, a1n = {}, a2n = {};
   fetch(0, cn, a1n, a2n);
 #pragma unroll
-  for (int r = 0; r < SMR + 2; r++) {
+  for (int r = 0; r < SMR_F + 2; r++) {
     const int y = t.y0 + r;
     const Px5 c = cn, a1 = a1n, a2 = a2n;
-    if (r + 1 < SMR + 2) fetch(r + 1, cn, a1n, a2n);
+    if (r + 1 < SMR_F + 2) fetch(r + 1, cn, a1n, a2n);
     if (y < H) {  // (uniform per wave)
-      if (r < SMR) {  // the x terms of row y (one of the strip's own rows)
+      if (r < SMR_F) {  // the x terms of row y (one of the strip's own rows)
         if (xin && t.x + 1 < W) {
           float s = 0.f;
 #pragma unroll
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(LB) void smooth_fwd_rows_kernel(T4 img, T4 flow, do
           part[2] = __builtin_fmaf(edge3(c, a2, alpha), s, part[2]);
         }
       }
-      if (xin && r >= 1 && r <= SMR) {  // first-order y term of row y - 1
+      if (xin && r >= 1 && r <= SMR_F) {  // first-order y term of row y - 1
         float s = 0.f;
 #pragma unroll
         for (int f = 0; f < 2; f++) s += charb_hw(c.f[f] - p1.f[f]);
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(LB) void smooth_bwd_rows_kernel(T4 img, T4 flow, co
   const float* fl = (const float*)flow.p;
   float* gf = (float*)gflow.p;
   const float cx1 = coef[0], cy1 = coef[1], cx2 = coef[2], cy2 = coef[3];
-  const StripId t = strip_of(xblocks, ychunks);
+  const StripId t = strip_of<SMR_B>(xblocks, ychunks);
   if (t.y0 >= H) return;
   const bool xin = t.x < W;
   const int xc = xin ? t.x : W - 1;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(LB) void smooth_bwd_rows_kernel(T4 img, T4 flow, co
   for (int k = 0; k < 5; k++)
     if (k != 2) nh[k] = row(t.y0, xs[k]);
 #pragma unroll
-  for (int r = 0; r < SMR; r++) {
+  for (int r = 0; r < SMR_B; r++) {
     const int y = t.y0 + r;
 #pragma unroll
     for (int k = 0; k < 4; k++) col[k] = col[k + 1];
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(LB) void smooth_bwd_rows_kernel(T4 img, T4 flow, co
     Px5 hor[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) hor[k] = k == 2 ? col[2] : nh[k];
-    if (r + 1 < SMR) {
+    if (r + 1 < SMR_B) {
       nbot = row(y + 3, xc);
 #pragma unroll
       for (int k = 0; k < 5; k++)
@@ -767,6 +770,35 @@ __global__ __launch_bounds__(LB) void moments_kernel(T4 f, double* sums, int C, 
     const float v = ldf<T>(f.p, (long)b * f.sb + (long)c * f.sc + (long)y * f.sh + (long)x * f.sw);
     s1 += v; s2 = __builtin_fmaf(v, v, s2);
     if (++cnt == 64) { acc[0] += (double)s1; acc[1] += (double)s2; s1 = s2 = 0.f; cnt = 0; }
+  }
+  acc[0] += (double)s1; acc[1] += (double)s2;
+  block_reduce_atomic<2>(acc, sums + 2 * b);
+}
+
+// A sample that is ONE contiguous run of n elements (dense NCHW or dense channels_last: what normalize_features is handed) needs no
+// index arithmetic at all: 16-byte loads over the run.  The generic kernel above pays two 64-bit divisions per 2-byte element -- 12-18 us
+// per launch at every pyramid level of configs[2] (20 launches per step, profiles/r5_cfg3_step_breakdown.txt).
+template <typename T>
+__global__ __launch_bounds__(LB) void moments_dense_kernel(const T* __restrict__ f, long sb, double* sums, long n, int blocks_per_b) {
+  constexpr int U = Unit<T>::U;
+  const int b = blockIdx.x / blocks_per_b, blk = blockIdx.x % blocks_per_b;
+  const T* p = f + (long)b * sb;
+  const long nu = n / U;
+  double acc[2] = {0.0, 0.0};
+  float s1 = 0.f, s2 = 0.f;
+  int cnt = 0;
+  for (long u = (long)blk * LB + threadIdx.x; u < nu; u += (long)blocks_per_b * LB) {
+    float v[U];
+    unit_to_f<T>(*(const u32x4*)(p + u * U), v);
+#pragma unroll
+    for (int k = 0; k < U; k++) { s1 += v[k]; s2 = __builtin_fmaf(v[k], v[k], s2); }
+    if (++cnt == 8) { acc[0] += (double)s1; acc[1] += (double)s2; s1 = s2 = 0.f; cnt = 0; }
+  }
+  if (blk == 0) {  // the tail that does not fill a 16-byte unit
+    for (long e = nu * U + threadIdx.x; e < n; e += LB) {
+      const float v = (float)p[e];
+      s1 += v; s2 = __builtin_fmaf(v, v, s2);
+    }
   }
   acc[0] += (double)s1; acc[1] += (double)s2;
   block_reduce_atomic<2>(acc, sums + 2 * b);
@@ -1011,7 +1043,7 @@ extern "C" int ocf_smooth_loss_fwd(const ocf_tensor4* img, const ocf_tensor4* fl
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, 4 * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
   const long npix = (long)B * H * W;
-  const int xblocks = (W + 63) / 64, ychunks = (H + SMR * (LB / 64) - 1) / (SMR * (LB / 64));
+  const int xblocks = (W + 63) / 64, ychunks = (H + SMR_F * (LB / 64) - 1) / (SMR_F * (LB / 64));
   const bool rows = C == 3 && (long)B * xblocks * ychunks <= 0x7fffffffL;
   if (rows && img->sc == 1)
     LaunchProf().launch(true, smooth_fwd_rows_kernel<true>, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, st, mk(img), mk(flow), sums, H, W,
@@ -1032,7 +1064,7 @@ extern "C" int ocf_smooth_loss_bwd(const ocf_tensor4* img, const ocf_tensor4* fl
   if (!img || !flow || !coef || !gflow || !img->data || !flow->data || !gflow->data) return OCF_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   const long npix = (long)B * H * W;
-  const int xblocks = (W + 63) / 64, ychunks = (H + SMR * (LB / 64) - 1) / (SMR * (LB / 64));
+  const int xblocks = (W + 63) / 64, ychunks = (H + SMR_B * (LB / 64) - 1) / (SMR_B * (LB / 64));
   if (C == 3 && (long)B * xblocks * ychunks <= 0x7fffffffL && img->sc == 1)
     LaunchProf().launch(true, smooth_bwd_rows_kernel<true>, dim3((unsigned)(B * xblocks * ychunks)), dim3(LB), 0, (hipStream_t)stream, mk(img), mk(flow),
                        coef, mk(gflow), H, W, alpha, xblocks, ychunks);
@@ -1128,6 +1160,24 @@ extern "C" int ocf_moments(const ocf_tensor4* f, double* sums, int B, int C, int
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, 2 * (size_t)B * sizeof(double), st) != hipSuccess) return OCF_ELAUNCH;
   const long n = (long)C * H * W;
+  if (dtype != OCF_F32 && dtype != OCF_BF16) return OCF_EINVAL;
+  // dense sample (either layout), 16-byte aligned: the contiguous-run kernel
+  {
+    const bool cl = (f->sc == 1 || C == 1) && (f->sw == C || W == 1) && (f->sh == (int64_t)W * C || H == 1);
+    const bool nchw = (f->sw == 1 || W == 1) && (f->sh == W || H == 1) && (f->sc == (int64_t)H * W || C == 1);
+    const int es = dtype == OCF_F32 ? 4 : 2;
+    if ((cl || nchw) && (B == 1 || f->sb >= n) && (uintptr_t)f->data % 16 == 0 && ((int64_t)f->sb * es) % 16 == 0) {
+      const long nu = n / (16 / es);
+      long bpb = (nu + LB * 4 - 1) / (LB * 4);  // >= 4 units per thread
+      if (bpb < 1) bpb = 1;
+      if (bpb > 128) bpb = 128;
+      if (dtype == OCF_F32)
+        hipLaunchKernelGGL(moments_dense_kernel<float>, dim3((unsigned)(B * bpb)), dim3(LB), 0, st, (const float*)f->data, (long)f->sb, sums, n, (int)bpb);
+      else
+        hipLaunchKernelGGL(moments_dense_kernel<bf16>, dim3((unsigned)(B * bpb)), dim3(LB), 0, st, (const bf16*)f->data, (long)f->sb, sums, n, (int)bpb);
+      return launch_status();
+    }
+  }
   long bpb = (n + LB * 16 - 1) / (LB * 16);
   if (bpb < 1) bpb = 1;
   if (bpb > 512) bpb = 512;
