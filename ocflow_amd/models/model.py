@@ -66,7 +66,7 @@ class FlowStageModel(HotPathHelpers, LightningModule):
             flow_pred, flow_l2 = self(imgs) if net_out is None else net_out
             img1_l2 = F.interpolate(img1, scale_factor=0.25, mode="bilinear", align_corners=True)
             return flow_pred, flow_l2, img1_l2
-        flow_pred = self(imgs)
+        flow_pred = self(imgs) if net_out is None else net_out
         return flow_pred, flow_pred, img1
 
     @staticmethod

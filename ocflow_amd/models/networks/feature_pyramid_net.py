@@ -90,17 +90,20 @@ class FeaturePyramidNet(nn.Module):
             pyramid.append(p)
         return pyramid  # [p6, p5, p4, p3, p2] with 196, 128, 96, 64, 32 channels
 
+    def pairs(self, x1, x2) -> bool:
+        """does `forward_pair` take the two images as one batch?"""
+        return (x1.is_cuda and x1.shape == x2.shape and x1.dim() == 4 and os.environ.get("OCFLOW_UNPAIRED_FPN", "0") != "1"
+                and not torch.compiler.is_compiling()
+                and os.environ.get("OCFLOW_UNFUSED_BN", "0") != "1"
+                and (not self.training or x1.is_contiguous(memory_format=torch.channels_last) or x1.shape[1] == 3))
+
     def forward_pair(self, x1, x2):
         """the pyramids of both images of a pair: `(self(x1), self(x2))` (flow_net.py:100-101, flow_occ_net.py:149-150), computed as ONE
         batch of 2B images on the GPU.  The convolutions do not couple samples; every BatchNorm runs with two statistics groups
         (ops.batchnorm_lrelu(groups=2): per-half statistics, running buffers updated half after half, as the two calls would), so
         the values are those of the two calls while the 17 convolutions / BatchNorm sites per image -- most of them launch-bound at
         the coarse levels -- are launched once instead of twice.  OCFLOW_UNPAIRED_FPN=1, CPU tensors and NCHW layouts: two calls."""
-        paired = (x1.is_cuda and x1.shape == x2.shape and x1.dim() == 4 and os.environ.get("OCFLOW_UNPAIRED_FPN", "0") != "1"
-                  and not torch.compiler.is_compiling()
-                  and os.environ.get("OCFLOW_UNFUSED_BN", "0") != "1"
-                  and (not self.training or x1.is_contiguous(memory_format=torch.channels_last) or x1.shape[1] == 3))
-        if not paired:
+        if not self.pairs(x1, x2):
             return self(x1), self(x2)
         B = x1.shape[0]
         both = ops.pair_input(x1, x2) if ops.pair_input_eligible(x1, x2) else torch.cat([x1, x2], 0)

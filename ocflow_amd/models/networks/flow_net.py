@@ -1,6 +1,8 @@
 """`FlowNet` (model 'flownet'): FPN encoder + per-level {warp -> cost volume -> estimator} + context network
 (reference: models/networks/flow_net.py:11-131).  On MI355X the warp and the cost volume of a level are ONE kernel
 (ops.corr_warp): the reference's `warped2` tensor (flow_net.py:110-112) is never written to HBM."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -65,6 +67,36 @@ class FlowNet(nn.Module):
 
     def forward(self, inputs):
         pyr1, pyr2 = self.feature_pyramid_network.forward_pair(inputs[:, 0:3], inputs[:, 3:6])
+        return self.decode(pyr1, pyr2)
+
+    def forward_two_way(self, inputs):
+        """(forward(inputs), forward(cat(inputs[:, 3:], inputs[:, :3])) without gradient) -- what the occlusion-aware step asks for in two
+        calls (models/model.py:376,384) -- from ONE encoder pass where that is exact: with the paired encoder every image is normalised
+        by its own statistics group, so the swapped call's pyramids ARE these, swapped; what it would have done to the BatchNorm buffers
+        (one more momentum update per group, the second image's group first; num_batches_tracked += 2) is replayed from the statistics
+        this pass saved (ops.bn_replay_running_update).  Otherwise (unpaired encoder, layouts the BatchNorm kernels do not take): two
+        forwards, as the reference."""
+        fpn = self.feature_pyramid_network
+        x1, x2 = inputs[:, 0:3], inputs[:, 3:6]
+        if not (fpn.pairs(x1, x2) and os.environ.get("OCFLOW_SHARED_ENCODER", "1") != "0"):
+            out = self.forward(inputs)
+            with torch.no_grad():
+                return out, self.forward(torch.cat((x2, x1), dim=1))
+        with ops.bn_record_stats() as rec:
+            pyr1, pyr2 = fpn.forward_pair(x1, x2)
+        sites = sum(1 for m in fpn.modules() if isinstance(m, nn.BatchNorm2d))
+        if fpn.training and len(rec) != sites:  # a BatchNorm site went through the framework's own operator: its update cannot be replayed
+            out = self.decode(pyr1, pyr2)
+            with torch.no_grad():
+                return out, self.forward(torch.cat((x2, x1), dim=1))
+        out = self.decode(pyr1, pyr2)
+        with torch.no_grad():
+            if fpn.training:
+                ops.bn_replay_running_update(rec, order=(1, 0))
+            back = self.decode([t.detach() for t in pyr2], [t.detach() for t in pyr1])
+        return out, back
+
+    def decode(self, pyr1, pyr2):
         flow_up = feat_up = flow = feat = None
         for i, level in enumerate(LEVELS):
             f1, f2 = pyr1[i], pyr2[i]

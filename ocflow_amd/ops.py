@@ -1347,6 +1347,54 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# ---- replaying the running-statistics update of a BatchNorm forward WITHOUT running the forward again.  The occlusion-aware training step
+# calls the network a second time on the swapped pair without gradient (models/model.py:384); for the FPN nets that second encoder pass
+# computes exactly the features of the first one (per-image statistics groups), so networks/flow_net.py re-uses them -- and what the second
+# pass would have done to the BatchNorm buffers (momentum update with the same batch statistics, groups in swapped order;
+# num_batches_tracked) is applied from the statistics the first pass saved.
+_BN_RECORD = None  # list of (running_mean, running_var, num_batches_tracked, mean [G,C], invstd [G,C], rows per group, momentum, eps) while recording
+
+
+class bn_record_stats:
+    """`with bn_record_stats() as rec:` -- every training-mode ocf_bn_act_fwd inside notes its buffers and saved statistics in `rec`"""
+
+    def __enter__(self):
+        global _BN_RECORD
+        self.prev, _BN_RECORD = _BN_RECORD, []
+        return _BN_RECORD
+
+    def __exit__(self, *exc):
+        global _BN_RECORD
+        _BN_RECORD = self.prev
+        return False
+
+
+def bn_replay_running_update(records, order):
+    """apply to the recorded BatchNorm buffers what one more forward over the same batch would: for g in `order` (statistics groups),
+    running = (1 - momentum) * running + momentum * stat_g (variance unbiased by n / (n - 1)), num_batches_tracked += len(order).
+    A few multi-tensor launches for the whole network."""
+    if not records:
+        return
+    with torch.no_grad():
+        by_mom = {}
+        for r in records:
+            by_mom.setdefault(r[6], []).append(r)
+        for mom, recs in by_mom.items():
+            for g in order:
+                rms, rvs, means, vars_ = [], [], [], []
+                for rm, rv, nbt, mean, invstd, n, _mo, eps in recs:
+                    rms.append(rm)
+                    rvs.append(rv)
+                    means.append(mean[g])
+                    unb = n / (n - 1.0) if n > 1 else 1.0
+                    vars_.append(((invstd[g].double().pow(-2) - eps) * unb).float())
+                torch._foreach_lerp_(rms, means, mom)
+                torch._foreach_lerp_(rvs, vars_, mom)
+        nbts = [r[2] for r in records if r[2] is not None]
+        if nbts:
+            torch._foreach_add_(nbts, len(order))
+
+
 class _BnActFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, slope, groups):
@@ -1360,6 +1408,8 @@ class _BnActFn(Function):
                                             _ptr(mean), _ptr(invstd), _ptr(ws), B, C_, H, W, float(eps), float(momentum), float(slope), 1,
                                             int(groups), _dtype_code(x), _stream(x))
         _lib.check(st, "ocf_bn_act_fwd")
+        if _BN_RECORD is not None:
+            _BN_RECORD.append((running_mean, running_var, nbt, mean, invstd, (B // groups) * H * W, float(momentum), float(eps)))
         # the backward recomputes the LeakyReLU mask from x (ocf_bn_act_bwd_x): y is not kept for it.  OCFLOW_BN_BWD_Y=1: the first form,
         # which reads the saved output (A/B; same results)
         ctx.with_y = os.environ.get("OCFLOW_BN_BWD_Y", "0") == "1"

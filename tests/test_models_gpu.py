@@ -324,6 +324,42 @@ def test_feature_pyramid_pair_equals_two_calls(monkeypatch, mode):
         np.testing.assert_allclose(s1[k].numpy(), s0[k].numpy(), rtol=1e-4 if fp32 else 2e-2, atol=1e-5 if fp32 else 2e-3, err_msg=k)
 
 
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32", "bf16"])
+def test_flownet_two_way_forward_equals_two_forwards(monkeypatch, amp):
+    """FlowNet.forward_two_way (models/model.py:376,384: the forward flow with gradient, then the flow of the swapped pair without) from
+    ONE encoder pass: same two outputs as two real forwards, and the BatchNorm buffers (running mean / variance, num_batches_tracked) end
+    where the two forwards leave them -- the second pass's momentum update is replayed from the saved statistics, second image's group
+    first.  Training mode (batch statistics) and evaluation mode."""
+    from ocflow_amd.models.networks.flow_net import FlowNet
+    gen = torch.Generator().manual_seed(4)
+    x = (torch.rand((2, 6, 128, 192), generator=gen) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    for train in (True, False):
+        res = {}
+        for shared in ("0", "1"):
+            monkeypatch.setenv("OCFLOW_SHARED_ENCODER", shared)
+            torch.manual_seed(1)
+            net = FlowNet().to(DEV).to(memory_format=torch.channels_last).train(train)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                out, back = net.forward_two_way(x)
+            assert out.requires_grad and not back.requires_grad
+            bufs = {k: v.detach().double().cpu() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}
+            res[shared] = (out.detach().float().cpu(), back.float().cpu(), bufs)
+        (o0, b0, s0), (o1, b1, s1) = res["0"], res["1"]
+        tol = 1e-5 if not amp else 2e-2  # (two instances of the net: the library's convolutions are not bit-reproducible run to run;
+        #                                  bf16: the swapped call's encoder runs them on another batch order)
+        assert float((o0 - o1).abs().max()) <= tol * (float(o0.abs().max()) + 1e-6), float((o0 - o1).abs().max())
+        # bf16: the real second call runs the encoder on the batch in the other order (library kernels are not bit-identical across batch
+        # positions) and a randomly initialised net amplifies that rounding noise through five warped levels: measured 5 % of the flow's
+        # scale; the fp32 case (1e-5) is the one that pins the logic
+        tol_back = tol if not amp else 0.12
+        assert float((b0 - b1).abs().max()) <= tol_back * (float(b0.abs().max()) + 1e-6), float((b0 - b1).abs().max())
+        for k in s0:
+            if "num_batches" in k:
+                assert float(s0[k]) == float(s1[k]) == (4.0 if train else 0.0), (k, float(s0[k]), float(s1[k]))
+            else:
+                np.testing.assert_allclose(s1[k].numpy(), s0[k].numpy(), rtol=2e-5 if not amp else 3e-3, atol=1e-6 if not amp else 1e-4, err_msg=k)
+
+
 def test_feature_pyramid_bf16_native_kernels_are_no_worse_than_the_library(monkeypatch):
     """the pair-vs-two-calls test above is a self-comparison with loose bars at the coarse levels.  This one measures
     both bf16 paths of the encoder -- this repo's kernels (default) and the library's convolutions (OCFLOW_NATIVE_CONV=0) -- against the
