@@ -371,6 +371,18 @@ int ocf_conv3x3_wgrad_bias(const ocf_tensor4* x, const ocf_tensor4* dz, float* g
 int ocf_conv3x3_wgrad_plan(int B, int Ci, int Co, int H, int W, int dilation, int policy, int* workgroups, int* chunks, int* tiles,
                            int* segments_per_chunk, int* chunks_capped);
 
+/* ---- forward of the PWC-style decoders' feature up-sampling layers: nn.ConvTranspose2d(Ci, Co <= 2, kernel 4, stride 2, padding 1) on a channel
+ * range of the level's decoder buffer (round 5; csrc/deconv4x4.hip):
+ *   y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx : oy = 2 iy - 1 + ky, ox = 2 ix - 1 + kx} x[b,ci,iy,ix] * w[ci,co,ky,kx]
+ * x: bf16 pixel-major [B, Ci, H, W] view, 16-byte aligned pixels whose pitch covers Ci rounded up to 16 (the channels behind Ci must exist:
+ * they meet zero weights); w: [Ci][Co][4][4] with element strides, fp32 or bf16; y: bf16 pixel-major [B, Co, 2H, 2W]; workspace:
+ * ocf_deconv4x4s2_fwd_workspace_bytes() bytes, 16-byte aligned, any contents.  Two launches (GEMM on the matrix cores + gather), no atomics.
+ * replaces: `upfeat6..3` of cost_volume_flow_net.py:63-65,182-183,197-198 / cost_volume_flow_occ_net.py (forward; the backward stays the
+ *           framework's convolution_backward). */
+int ocf_deconv4x4s2_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int64_t* bytes);
+int ocf_deconv4x4s2_fwd(const ocf_tensor4* x, const void* w, int64_t w_si, int64_t w_so, int64_t w_sy, int64_t w_sx, int w_is_f32,
+                        const float* bias, const ocf_tensor4* y, void* workspace, int B, int Ci, int Co, int H, int W, int dtype, void* stream);
+
 /* ---- channel concatenation of the decoder inputs: out[:, c0_k : c0_k + channels[k]] = parts[k], out[:, sum(channels):Cout] = 0, one launch.
  * parts: n <= 6 pixel-major (channel stride 1, one pixel pitch) bf16 views of [B, channels[k], H, W]; out: channels_last
  * [B, Cout, H, W] or a channel slice of a wider channels_last tensor (pixel pitch a multiple of 8), Cout % 8 == 0, 16-byte aligned.  Anything else: OCF_EUNSUPPORTED (the caller keeps the framework's cat).

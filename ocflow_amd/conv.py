@@ -831,6 +831,69 @@ def deconv3x3s2_bias(x, weight, bias, output_padding, sigmoid: bool = False):
     return _DeconvBiasFn.apply(x, weight, bias, (int(output_padding[0]), int(output_padding[1])), bool(sigmoid))
 
 
+# ---- the PWC-style decoders' `upfeat` layers (ConvTranspose2d(Ci ~ 550, 2, 4, 2, 1) on a channel range of the dense-block buffer):
+# forward on csrc/deconv4x4.hip (GEMM on the matrix cores + gather), backward through the framework
+
+def deconv4x4_eligible(x, weight, stride, padding, dilation, groups, output_padding) -> bool:
+    """layers ocf_deconv4x4s2_fwd takes: bf16 pixel-major x [B, Ci >= 32, H, W] with 16-byte aligned pixels whose pitch covers Ci rounded up
+    to 16, weight [Ci, Co <= 2, 4, 4], stride 2, padding 1, no output padding"""
+    if not (enabled() and os.environ.get("OCFLOW_NATIVE_DECONV4", "1") != "0"):
+        return False
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and _pixel_major(x, 16)):
+        return False
+    if weight.dtype not in (torch.bfloat16, torch.float32) or tuple(weight.shape[2:]) != (4, 4) or groups != 1:
+        return False
+    if tuple(stride) != (2, 2) or tuple(padding) != (1, 1) or tuple(dilation) != (1, 1) or any(p != 0 for p in output_padding):
+        return False
+    ci, co = int(weight.shape[0]), int(weight.shape[1])
+    B, _, H, W = x.shape
+    return (ci == x.shape[1] and 32 <= ci <= 1000 and co <= 2 and _pitch(x) >= (ci + 15) // 16 * 16 and B * H * W * _pitch(x) < (1 << 31))
+
+
+class _Deconv4x4Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, ci, H, W = x.shape
+        co = int(weight.shape[1])
+        y = torch.empty((B, co, 2 * H, 2 * W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        nb = C.c_int64(0)
+        _lib.check(_lib.load().ocf_deconv4x4s2_fwd_workspace_bytes(B, ci, co, H, W, C.byref(nb)), "ocf_deconv4x4s2_fwd_workspace_bytes")
+        ws = torch.empty(nb.value, device=x.device, dtype=torch.uint8)
+        bf = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        si, so, sy, sx = weight.stride()
+        with torch.cuda.device(x.device):
+            fn = lambda: _lib.check(_lib.load().ocf_deconv4x4s2_fwd(_t4(x), C.c_void_p(weight.data_ptr()), si, so, sy, sx,
+                                                                     int(weight.dtype == torch.float32), _ptr(bf), _t4(y), _ptr(ws), B, ci, co, H, W,
+                                                                     _lib.OCF_BF16, _stream(x)), "ocf_deconv4x4s2_fwd")
+            ops._launch("deconv4x4s2_fwd", lambda: ops._meta(f"B{B}x{ci}->{co}x{H}x{W}", 2 * B * H * W * (ci + 4 * co), 2 * B * H * W * ci * 16 * co), fn)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        gg = gy if gy.dtype == x.dtype else gy.to(x.dtype)
+        gg = gg if gg.is_contiguous(memory_format=torch.channels_last) else gg.contiguous(memory_format=torch.channels_last)
+        xc = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+        wb = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        gx, gw, gb = torch.ops.aten.convolution_backward(gg, xc, wb, [int(weight.shape[1])] if ctx.has_bias else None, (2, 2), (1, 1), (1, 1), True,
+                                                         (0, 0), 1, [need[0], need[1], bool(need[2])])
+        if gw is not None and gw.dtype != weight.dtype:
+            gw = gw.to(weight.dtype)
+        if gb is not None and ctx.bias_dtype is not None and gb.dtype != ctx.bias_dtype:
+            gb = gb.to(ctx.bias_dtype)
+        return gx, gw, (gb if need[2] else None)
+
+
+def deconv4x4s2_bias(x, weight, bias):
+    """`F.conv_transpose2d(x, weight, bias, 2, 1)` for a 4 x 4 kernel and <= 2 output channels; the caller checks `deconv4x4_eligible` first"""
+    return _Deconv4x4Fn.apply(x, weight, bias)
+
+
 # ---- the encoder's full-resolution 16 -> 16 layer (csrc/conv_c16.hip): forward and input gradient on the direct matrix-core kernel, weight
 # gradient from the framework
 

@@ -239,6 +239,8 @@ def deconv_bias(deconv: nn.ConvTranspose2d, x, output_size=None, sigmoid: bool =
         return act(F.conv_transpose2d(x, w, deconv.bias, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation))
     if nconv.deconv_eligible(x, deconv.weight, deconv.stride, deconv.padding, deconv.dilation, deconv.groups, output_padding):
         return nconv.deconv3x3s2_bias(x, deconv.weight, deconv.bias, output_padding, sigmoid)
+    if not sigmoid and nconv.deconv4x4_eligible(x, deconv.weight, deconv.stride, deconv.padding, deconv.dilation, deconv.groups, output_padding):
+        return nconv.deconv4x4s2_bias(x, deconv.weight, deconv.bias)  # the PWC-style `upfeat` layers (forward; backward: the framework's)
     y = F.conv_transpose2d(x, w, None, deconv.stride, deconv.padding, output_padding, deconv.groups, deconv.dilation)
     return act(ops.bias_add(y, deconv.bias))
 
