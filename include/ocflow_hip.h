@@ -376,7 +376,7 @@ int ocf_conv3x3_wgrad_plan(int B, int Ci, int Co, int H, int W, int dilation, in
  *   y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx : oy = 2 iy - 1 + ky, ox = 2 ix - 1 + kx} x[b,ci,iy,ix] * w[ci,co,ky,kx]
  * x: bf16 pixel-major [B, Ci, H, W] view, 16-byte aligned pixels whose pitch covers Ci rounded up to 16 (the channels behind Ci must exist:
  * they meet zero weights); w: [Ci][Co][4][4] with element strides, fp32 or bf16; y: bf16 pixel-major [B, Co, 2H, 2W]; workspace:
- * ocf_deconv4x4s2_fwd_workspace_bytes() bytes, 16-byte aligned, any contents.  Two launches (GEMM on the matrix cores + gather), no atomics.
+ * ocf_deconv4x4s2_fwd_workspace_bytes() bytes, 16-byte aligned, any contents.  Three launches (weight pack, GEMM on the matrix cores, gather), no atomics.
  * replaces: `upfeat6..3` of cost_volume_flow_net.py:63-65,182-183,197-198 / cost_volume_flow_occ_net.py (forward; the backward stays the
  *           framework's convolution_backward). */
 int ocf_deconv4x4s2_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int64_t* bytes);

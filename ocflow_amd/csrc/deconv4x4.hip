@@ -5,11 +5,12 @@
 //   y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx : oy = 2 iy - 1 + ky, ox = 2 ix - 1 + kx} x[b,ci,iy,ix] * w[ci,co,ky,kx]
 //
 // The library serves these through its generic backward-data implicit GEMM behind a strided copy of the 529 .. 661 channel slice and a fill /
-// cast pair: 14 / 23 / 54 / 176 us at the four levels of configs[2] (profiles/r5_cfg3_step_breakdown.txt), twice per step.  Two launches here:
+// cast pair: 14 / 23 / 54 / 176 us at the four levels of configs[2] (profiles/r5_cfg3_step_breakdown.txt), twice per step.  Three launches here:
 //
+//   pack    the weight in B-fragment order, bf16 (fp32 masters rounded as autocast would), once per call
 //   gemm    contrib[p][n] = sum_ci x[p][ci] * w[ci][n],  n = co * 16 + ky * 4 + kx  (a [pixels x Ci] x [Ci x 16 Co] product on the matrix
-//           cores: v_mfma_f32_32x32x16_bf16, one wave = 32 input pixels x all 16 Co columns; A fragments straight from global memory --
-//           a lane's 8 k-values are 16 contiguous bytes of its pixel --, B fragments from an LDS copy of the weight transposed to [n][ci]);
+//           cores: v_mfma_f32_32x32x16_bf16, one workgroup = 32 input pixels x all 16 Co columns, the k-steps split over its four waves;
+//           A fragments straight from global memory -- a lane's 8 k-values are 16 contiguous bytes of its pixel --, B fragments from the pack);
 //           the features are read ONCE (26 MB at the largest level)
 //   gather  y[b, co, oy, ox] = bias + the (up to) four contrib entries whose tap lands on (oy, ox): col2im without atomics.
 #include "ocf_common.h"
@@ -25,86 +26,67 @@ struct Args {
   float* contrib;  // [B H W][16 Co]
   long xp, wsi, wso, wsy, wsx;
   long npix;
-  int Ci, Co, kpad, w_f32, w_vec, wpitch;  // wpitch: bf16 elements per LDS weight row (kpad + 8: the rows of a fragment read land on different banks)
+  int Ci, Co, kpad, w_f32;
 };
 
-constexpr int DEPTH = 8;  // k-steps of A fragments in flight per wave (8 x 1 KB: the stream is latency-bound below that at < 4 waves per CU)
+// the weight in MFMA B-fragment order, rounded to bf16 (fp32 masters: the rounding autocast applies), zero beyond Ci and beyond 16 Co columns:
+//   packed[((k * 2 + kg) * 32 + n) * 8 + e] = w[ci = k * 16 + kg * 8 + e][n]      (one k-step = 1 KB, a wave's fragment load is contiguous)
+// one thread per element, once per call, into the workspace
+__global__ __launch_bounds__(256) void deconv4x4_pack_kernel(const Args a, bf16* packed) {
+  const int N = 16 * a.Co;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // = ci * 32 + n: consecutive threads read consecutive elements of a dense weight
+  if (i >= 32 * a.kpad) return;
+  const int ci = i >> 5, n = i & 31;
+  float v = 0.f;
+  if (ci < a.Ci && n < N) {
+    const long off = ci * a.wsi + (n >> 4) * a.wso + ((n >> 2) & 3) * a.wsy + (n & 3) * a.wsx;
+    v = a.w_f32 ? ((const float*)a.w)[off] : (float)((const bf16*)a.w)[off];
+  }
+  packed[(((ci >> 4) * 2 + ((ci >> 3) & 1)) * 32 + n) * 8 + (ci & 7)] = (bf16)v;
+}
 
-template <int CO>
-__global__ __launch_bounds__(NT) void deconv4x4_gemm_kernel(const Args a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [16 Co][wpitch] bf16
-  bf16* sw = (bf16*)smem;
-  constexpr int N = 16 * CO;
+// workgroup = 32 pixels, its four waves split the k-steps: every wave issues ALL its loads (<= KQ A fragments from the pixels' rows + <= KQ B
+// fragments from the packed weight, both straight from global memory) before the first MFMA -- one memory latency per workgroup instead of
+// one per prefetch group (the layer's levels have 12 .. 768 such tiles: few waves, so latency, not bandwidth, is what a k-loop pays) --,
+// then the four partial tiles meet in LDS and every wave stores a quarter of the rows
+template <int KQ>
+__global__ __launch_bounds__(NT) void deconv4x4_gemm_kernel(const Args a, const bf16* __restrict__ packed) {
+  __shared__ float part[4][16][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // ---- the weight, transposed to [n][ci] and rounded to bf16 (fp32 masters: the rounding autocast applies); zero beyond Ci.  Thread = one
-  // input channel: its N values are one contiguous run of a dense weight (all loads of a row in flight together), and consecutive threads
-  // write consecutive bf16 of one LDS row
-  const bool dense = a.w_vec && a.wsx == 1 && a.wsy == 4 && a.wso == 16 && a.wsi == N;
-  for (int ci = tid; ci < a.kpad; ci += NT) {
-    float v[N];
-#pragma unroll
-    for (int n = 0; n < N; n++) v[n] = 0.f;
-    if (ci < a.Ci) {
-      if (dense && a.w_f32) {
-        const float4* src = (const float4*)((const float*)a.w + (long)ci * N);
-#pragma unroll
-        for (int q = 0; q < N / 4; q++) {
-          const float4 t = src[q];
-          v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-        }
-      } else if (dense) {
-        const bf16x8* src = (const bf16x8*)((const bf16*)a.w + (long)ci * N);
-#pragma unroll
-        for (int q = 0; q < N / 8; q++) {
-          const bf16x8 t = src[q];
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[8 * q + e] = (float)t[e];
-        }
-      } else {
-#pragma unroll
-        for (int n = 0; n < N; n++) {
-          const long off = ci * a.wsi + (n >> 4) * a.wso + ((n >> 2) & 3) * a.wsy + (n & 3) * a.wsx;
-          v[n] = a.w_f32 ? ((const float*)a.w)[off] : (float)((const bf16*)a.w)[off];
-        }
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < N; n++) sw[n * a.wpitch + ci] = (bf16)v[n];
-  }
-  __syncthreads();
-  const long p0 = ((long)blockIdx.x * (NT / 64) + wave) * PXW;
-  if (p0 >= a.npix) return;
+  const int N = 16 * a.Co;
+  const long p0 = (long)blockIdx.x * PXW;
   const int m = lane & 31, kg = lane >> 5;
   const long p = p0 + m;
   const bf16* xr = a.x + (p < a.npix ? p : 0) * a.xp + kg * 8;
-  const bf16* wr = sw + (m < N ? m : 0) * a.wpitch + kg * 8;  // (Co = 1: columns 16 .. 31 duplicate column 0; never stored)
+  const bf16* wr = packed + lane * 8;
+  const int ksteps = a.kpad >> 4, kq = (ksteps + 3) >> 2;  // (kq <= KQ: the launcher picks KQ)
+  const int kb = wave * kq, cnt = min(kq, ksteps - kb);    // this wave's k-steps [kb, kb + cnt); cnt may be <= 0 for the last wave
+  const int last = ksteps - 1;
+  bf16x8 fa[KQ], fb[KQ];
+#pragma unroll
+  for (int j = 0; j < KQ; j++) {  // (indices clamped into the row: a redundant load instead of a branch)
+    const int k = min(kb + j, last);
+    fa[j] = *(const bf16x8*)(xr + k * 16);
+    fb[j] = *(const bf16x8*)(wr + k * 512);
+  }
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; e++) acc[e] = 0.f;
-  const int ksteps = a.kpad >> 4;
-  bf16x8 fa[DEPTH];  // A fragments straight from global memory, DEPTH k-steps ahead; B fragments from LDS
 #pragma unroll
-  for (int u = 0; u < DEPTH; u++) fa[u] = u < ksteps ? *(const bf16x8*)(xr + u * 16) : bf16x8{};
-  for (int k0 = 0; k0 < ksteps; k0 += DEPTH) {
+  for (int j = 0; j < KQ; j++)
+    if (j < cnt) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j], fb[j], acc, 0, 0, 0);  // (wave-uniform)
 #pragma unroll
-    for (int u = 0; u < DEPTH; u++) {
-      const int k = k0 + u;
-      if (k < ksteps) {  // (wave-uniform)
-        const bf16x8 av = fa[u];
-        if (k + DEPTH < ksteps) fa[u] = *(const bf16x8*)(xr + (k + DEPTH) * 16);
-        const bf16x8 bv = *(const bf16x8*)(wr + k * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
-      }
-    }
-  }
-  // D[row][col]: register e of lane l = row (e & 3) + 8 (e >> 2) + 4 (l >> 5), col l & 31 -> 32 lanes write one pixel's N consecutive floats
-  if (m < N) {
+  for (int e = 0; e < 16; e++) part[wave][e][lane] = acc[e];
+  __syncthreads();
+  // D[row][col]: register e of lane l = row (e & 3) + 8 (e >> 2) + 4 (l >> 5), col l & 31; wave w sums and stores registers 4 w .. 4 w + 3
+  // (32 lanes write one pixel's N consecutive floats)
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const int row = (e & 3) + 8 * (e >> 2) + 4 * kg;
-      if (p0 + row < a.npix) a.contrib[(p0 + row) * N + m] = acc[e];
-    }
+  for (int q = 0; q < 4; q++) {
+    const int e = wave * 4 + q;
+    const float v = part[0][e][lane] + part[1][e][lane] + part[2][e][lane] + part[3][e][lane];
+    const int row = q + 8 * wave + 4 * kg;
+    if (m < N && p0 + row < a.npix) a.contrib[(p0 + row) * N + m] = v;
   }
 }
 
@@ -158,10 +140,12 @@ static bool d44_pixel_major(const ocf_tensor4* t, int B, int C, int H, int W, lo
   return (C == 1 || t->sc == 1) && p >= C && (H == 1 || t->sh == p * W) && (B == 1 || t->sb == p * W * H);
 }
 
+static int64_t d44_contrib_bytes(int B, int Co, int H, int W) { return ((int64_t)B * H * W * 16 * Co * 4 + 255) / 256 * 256; }
+
 extern "C" int ocf_deconv4x4s2_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int64_t* bytes) {
   if (!bytes || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return OCF_EINVAL;
   if (Co > 2) return OCF_EUNSUPPORTED;
-  *bytes = (int64_t)B * H * W * 16 * Co * 4;
+  *bytes = d44_contrib_bytes(B, Co, H, W) + (int64_t)32 * ((Ci + 15) / 16 * 16) * 2;  // contributions + the packed weight
   return OCF_OK;
 }
 
@@ -184,14 +168,16 @@ extern "C" int ocf_deconv4x4s2_fwd(const ocf_tensor4* x, const void* w, int64_t 
   d44::Args a;
   a.x = (const bf16*)x->data; a.w = w; a.contrib = (float*)workspace;
   a.xp = xp; a.wsi = w_si; a.wso = w_so; a.wsy = w_sy; a.wsx = w_sx;
-  a.npix = npix; a.Ci = Ci; a.Co = Co; a.kpad = kpad; a.w_f32 = w_is_f32; a.wpitch = kpad + 8;
-  const size_t lds = (size_t)16 * Co * a.wpitch * 2;
-  if (lds > 64 * 1024) return OCF_EUNSUPPORTED;  // (Ci <= 1000 at Co = 2)
-  const long tiles = (npix + d44::PXW - 1) / d44::PXW, blocks = (tiles + 3) / 4;
+  a.npix = npix; a.Ci = Ci; a.Co = Co; a.kpad = kpad; a.w_f32 = w_is_f32;
+  const int ksteps = kpad / 16, kq = (ksteps + 3) / 4;
+  if (kq > 16) return OCF_EUNSUPPORTED;  // (Ci <= 1024)
+  const long tiles = (npix + d44::PXW - 1) / d44::PXW;
+  bf16* packed = (bf16*)((char*)workspace + d44_contrib_bytes(B, Co, H, W));
   LaunchProf lp;
-  a.w_vec = (uintptr_t)w % 16 == 0;  // (the vector loads of a dense weight need 16-byte aligned rows)
-  if (Co == 1) lp.launch(false, d44::deconv4x4_gemm_kernel<1>, dim3((unsigned)blocks), dim3(d44::NT), lds, (hipStream_t)stream, a);
-  else lp.launch(false, d44::deconv4x4_gemm_kernel<2>, dim3((unsigned)blocks), dim3(d44::NT), lds, (hipStream_t)stream, a);
+  lp.launch(false, d44::deconv4x4_pack_kernel, dim3((unsigned)((32 * kpad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, packed);
+  if (kq <= 8) lp.launch(false, d44::deconv4x4_gemm_kernel<8>, dim3((unsigned)tiles), dim3(d44::NT), 0, (hipStream_t)stream, a, (const bf16*)packed);
+  else if (kq <= 12) lp.launch(false, d44::deconv4x4_gemm_kernel<12>, dim3((unsigned)tiles), dim3(d44::NT), 0, (hipStream_t)stream, a, (const bf16*)packed);
+  else lp.launch(false, d44::deconv4x4_gemm_kernel<16>, dim3((unsigned)tiles), dim3(d44::NT), 0, (hipStream_t)stream, a, (const bf16*)packed);
   d44::GArgs g;
   g.contrib = a.contrib; g.bias = bias; g.y = (bf16*)y->data; g.yp = yp; g.B = B; g.H = H; g.W = W; g.Co = Co;
   const long nout = npix * 4, gblocks = (nout + 255) / 256;
