@@ -361,6 +361,46 @@ def wgrad_bias_raw(x, dz, gw, gbias=None, dilation: int = 1, policy: int = 0):
     return gw
 
 
+# ---- weight gradients beside the input gradients (OFF by default: OCFLOW_WGRAD_STREAM=1 turns it on).  Inside a layer's backward the two
+# are independent (both read dz; one reads the saved input, the other the weight), and with gradient sinks armed the weight gradient has
+# no consumer before the optimizer: it can be launched on a second stream that forks from the current one (dz is ready) and is joined
+# once, after the whole backward (`join_wgrad_stream`, called by TrainStepper); inside a hipGraph capture the fork / join become graph
+# edges.  Measured (profiles/r5_wgrad_side_stream_not_default.txt): a replayed graph with ANY such branch is 0.65 - 0.8 ms per step SLOWER
+# than the single-stream graph on this runtime (8.95 -> 9.61 ms with only the layers of <= 2048 pixels forked, 9.72 ms with all of them):
+# the multi-branch graph loses more in its replay than the concurrency of two matrix-core kernels returns.
+_WGRAD_SIDE: Dict[int, "torch.cuda.Stream"] = {}
+_WGRAD_PENDING: Dict[int, bool] = {}
+
+
+def _wgrad_async() -> bool:
+    return os.environ.get("OCFLOW_WGRAD_STREAM", "0") == "1" and ops._KERNEL_TIMER is None
+
+
+def wgrad_bias_async(x, dz, gw, gbias, dilation: int, sinks_only: bool):
+    """`wgrad_bias_raw`, on the side stream when every output is a gradient sink (nothing of this backward reads it)"""
+    if not (sinks_only and _wgrad_async() and x.shape[0] * x.shape[2] * x.shape[3] <= int(os.environ.get("OCFLOW_WGRAD_STREAM_MAX_PIXELS", str(1 << 30)))):
+        return wgrad_bias_raw(x, dz, gw, gbias, dilation)
+    dev = x.device.index
+    side = _WGRAD_SIDE.get(dev)
+    if side is None:
+        side = _WGRAD_SIDE[dev] = torch.cuda.Stream(device=x.device)
+    side.wait_stream(torch.cuda.current_stream(x.device))
+    with torch.cuda.stream(side):
+        wgrad_bias_raw(x, dz, gw, gbias, dilation)
+    for t in (x, dz):  # their memory must not be handed out again (on the main stream) while the side stream reads it
+        t.record_stream(side)
+    _WGRAD_PENDING[dev] = True
+    return gw
+
+
+def join_wgrad_stream():
+    """the current stream waits for the weight gradients launched beside it (no-op when there are none)"""
+    for dev, pending in list(_WGRAD_PENDING.items()):
+        if pending:
+            torch.cuda.current_stream(torch.device("cuda", dev)).wait_stream(_WGRAD_SIDE[dev])
+            _WGRAD_PENDING[dev] = False
+
+
 _MAX_ELEMS = 1 << 30  # the kernels index a tensor with 32-bit in-image offsets: B*H*W*pitch below 2^30 elements (csrc/conv_igemm.hip,
                       # conv_wgrad3.hip return OCF_EUNSUPPORTED beyond; the predicates below say False first, so callers fall back)
 
@@ -489,7 +529,7 @@ class _ConvBiasActFn(Function):
             if need_b and gb is None:
                 gb2, b_sink = _grad_target(bias, gy.device)
                 gb = gb2
-            gw = wgrad_bias_raw(x, dz, acc, gb2, d)
+            gw = wgrad_bias_async(x, dz, acc, gb2, d, w_sink and (gb2 is None or b_sink))
             if w_sink:
                 gw = None
             if b_sink:
@@ -570,7 +610,7 @@ class _ConvChainFn(Function):
                 gb_t, b_sink = None, False
                 if need_b[i] and not (i == n - 1 and last_bias_done):
                     gb_t, b_sink = _grad_target(bs[i], dev)
-                wgrad_bias_raw(xin, dz, gw_t, gb_t, dils[i])
+                wgrad_bias_async(xin, dz, gw_t, gb_t, dils[i], w_sink and (gb_t is None or b_sink))
                 gws[i] = None if w_sink else gw_t
                 if gb_t is not None:
                     gbs[i] = None if b_sink else gb_t
@@ -679,7 +719,7 @@ class _DenseBlockFn(Function):
                 gb2, b_sink = (None, False)
                 if need_b[j] and j != n - 1:
                     gb2, b_sink = _grad_target(bs[j], dev)
-                wgrad_bias_raw(x_j, dz_j, gw_t, gb2, 1)
+                wgrad_bias_async(x_j, dz_j, gw_t, gb2, 1, w_sink and (gb2 is None or b_sink))
                 gws[j] = None if w_sink else gw_t
                 if gb2 is not None:
                     gbs[j] = None if b_sink else gb2

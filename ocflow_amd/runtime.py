@@ -350,6 +350,8 @@ class TrainStepper:
             (loss / self.env.world_size).backward()  # sum over ranks of grad(loss / N) = DDP's averaged gradient
         else:
             loss.backward()
+        from ocflow_amd import conv as nconv
+        nconv.join_wgrad_stream()  # weight gradients launched beside the input gradients (ocflow_amd.conv.wgrad_bias_async)
         return loss.detach()
 
     def _grad_params(self):

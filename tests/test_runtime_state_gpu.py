@@ -10,12 +10,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _stepper(model="flowoccnet", amp=torch.bfloat16):
+def _stepper(model="flowoccnet", amp=torch.bfloat16, lr=1e-4):
     from ocflow_amd.models.flow_occ_model import FlowOccModel
     from ocflow_amd.runtime import DistEnv, TrainStepper, synthetic_batch
     torch.manual_seed(5)
     env = DistEnv(device=torch.device(DEV))
-    st = TrainStepper(FlowOccModel({"model": model, "learning_rate": 1e-4}), env, amp_dtype=amp, channels_last=True, fused_optimizer=True,
+    st = TrainStepper(FlowOccModel({"model": model, "learning_rate": lr}), env, amp_dtype=amp, channels_last=True, fused_optimizer=True,
                       master_weights=True)
     batch = st.prepare(synthetic_batch(2, 128, 192, env.device, seed=3))
     return st, batch
@@ -95,3 +95,31 @@ def test_descriptor_tables_die_with_their_graphs():
     nconv.PACKER._purge()
     # the weights of both models are gone: so are their entries (what other tests left alive stays)
     assert len(nconv.PACKER._retired) <= n_before and all(e.src_ref() is not None for e in nconv.PACKER._order)
+
+
+def test_side_stream_weight_gradients_match_the_single_stream_step(monkeypatch):
+    """weight gradients launched beside the input gradients (conv.wgrad_bias_async: a fork / join inside the captured graph) against the
+    same capture on one stream.  Learning rate 0: the weights stay where the seed put them (Adam's first steps are sign-like, so with a
+    real learning rate the order of the fp32 atomics decides the update of every near-zero gradient and the two runs drift apart), every
+    replay computes the same gradients up to that order"""
+    from ocflow_amd import conv as nconv
+    flats, losses = [], []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OCFLOW_WGRAD_STREAM", mode)
+        st, batch = _stepper(lr=0.0)
+        st.step(batch)
+        st.enable_graph(batch)
+        assert not any(nconv._WGRAD_PENDING.values())  # joined before the capture ended
+        ls = [float(st.step(st._static_batch)) for _ in range(3)]
+        torch.cuda.synchronize()
+        flats.append(st._flat.clone())
+        losses.append(ls)
+        st.close()
+        del st
+        gc.collect()
+    assert nconv._WGRAD_SIDE  # the second run did fork
+    g0, g1 = flats
+    assert torch.isfinite(g1).all() and float(g0.norm()) > 0
+    rel = float((g0 - g1).norm() / g0.norm())
+    assert rel < 2e-2, rel
+    assert all(abs(a - b) <= 1e-3 * max(1.0, abs(a)) for a, b in zip(*losses)), losses
