@@ -467,12 +467,21 @@ def _shape_like(weight, cin, dtype=torch.bfloat16):
 
 class _ConvBiasActFn(Function):
     """forward: one launch (convolution + bias + LeakyReLU).  backward: LeakyReLU derivative + bias gradient (ocf_bias_act_bwd), input
-    gradient by the same implicit-GEMM kernel on the transposed weight, weight gradient by ocf_conv3x3_wgrad or the framework."""
+    gradient by the same implicit-GEMM kernel on the transposed weight, weight gradient by ocf_conv3x3_wgrad or the framework.
+    `cpad` > out_channels: the output is a [B, cpad, H, W] tensor whose channels behind the layer's own are ZERO (one fill + the launch
+    into the channel range) -- the alignment channels the next layer's kernels want when the layer has e.g. 196 channels; the incoming
+    gradient then has cpad channels too and its tail is ignored."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, slope, dilation):
+    def forward(ctx, x, weight, bias, slope, dilation, cpad=0):
         pk = PACKER.get(weight, False)
-        y = igemm_raw(x, pk, weight.shape[0], bias, None, dilation, slope, 1.0)
+        co = int(weight.shape[0])
+        if cpad > co:
+            B, _, H, W = x.shape
+            y = torch.zeros((B, cpad, H, W), device=x.device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            igemm_raw(x, pk, co, bias, None, dilation, slope, 1.0, out=y[:, :co])
+        else:
+            y = igemm_raw(x, pk, co, bias, None, dilation, slope, 1.0)
         ctx.save_for_backward(x, weight, y, *([bias] if bias is not None else []))
         ctx.cfg = (float(slope), int(dilation), bias is not None, None if bias is None else bias.dtype)
         return y
@@ -483,23 +492,27 @@ class _ConvBiasActFn(Function):
         x, weight, y = ctx.saved_tensors[:3]
         slope, d, has_bias, bias_dtype = ctx.cfg
         bias = ctx.saved_tensors[3] if has_bias else None
-        B, co, H, W = y.shape
+        B, cy, H, W = y.shape            # cy: channels of the output tensor (> co when it carries alignment zeros)
+        co = int(weight.shape[0])
+        padded = cy != co
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
         gg = gy if gy.dtype == y.dtype else gy.to(y.dtype)
-        if not _pixel_major(gg, 2):
+        if not _pixel_major(gg, 16 if padded else 2):
             gg = gg.contiguous(memory_format=torch.channels_last)
         # dz = gy * lrelu'(y): one elementwise pass (ocf_bias_act_bwd, which also reduces the bias gradient); a layer without activation
         # needs no pass at all when the weight-gradient kernel takes the bias gradient along
         use_wg3 = need_w and _native_wgrad() and wgrad_eligible(x, gg, weight.shape[1], co)
         gb = None
-        if slope != 1.0 or (need_b and not use_wg3):
-            gb = ops._take_zeros(co, gy.device)
+        if slope != 1.0 or (need_b and (padded or not use_wg3)):
+            gb = ops._take_zeros(cy, gy.device)
             dz = torch.empty_like(y) if slope != 1.0 else None
             with torch.cuda.device(gy.device):
-                _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y if slope != 1.0 else None), _t4(gg), _t4(dz), C.c_void_p(gb.data_ptr()), B, co, H, W,
+                _lib.check(_lib.load().ocf_bias_act_bwd(_t4(y if slope != 1.0 else None), _t4(gg), _t4(dz), C.c_void_p(gb.data_ptr()), B, cy, H, W,
                                                         slope, 1, _lib.OCF_BF16, _stream(gg)), "ocf_bias_act_bwd")
             if dz is None:
                 dz = gg
+            if padded:
+                gb = gb[:co]
         else:
             dz = gg
         gx = gw = None
@@ -514,14 +527,17 @@ class _ConvBiasActFn(Function):
                 dzp[:, :co] = dz
                 dz = dzp
             use_wg3 = need_w and wgrad_eligible(x, dz, weight.shape[1], co)
+
+        def for_library(t):  # the framework's convolution backward wants exactly the layer's channels, dense
+            t = t[:, :co] if t.shape[1] != co else t
+            return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
         if need_x:
-            if (co % 8 == 0 or co < 8) and _pixel_major(dz, 16) and dz.shape[1] % 8 == 0:
+            if (cy % 8 == 0 or co < 8) and _pixel_major(dz, 16) and dz.shape[1] % 8 == 0:
                 pkt = PACKER.get(weight, True, x.shape[1])
                 gx = igemm_raw(dz, pkt, x.shape[1], None, None, d, 1.0, 1.0)
             else:
-                dzc = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
-                gx = torch.ops.aten.convolution_backward(dzc, x, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False, (0, 0), 1,
-                                                         [True, False, False])[0]
+                gx = torch.ops.aten.convolution_backward(for_library(dz), x, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False,
+                                                         (0, 0), 1, [True, False, False])[0]
         w_sink = b_sink = False
         if need_w and use_wg3 and wgrad_eligible(x, dz, weight.shape[1], co):
             acc, w_sink = _grad_target(weight, gy.device)
@@ -535,19 +551,18 @@ class _ConvBiasActFn(Function):
             if b_sink:
                 gb = None
         elif need_w:
-            dzc = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
             xc = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
-            gw = torch.ops.aten.convolution_backward(dzc, xc, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False, (0, 0), 1,
-                                                     [False, True, False])[1]
+            gw = torch.ops.aten.convolution_backward(for_library(dz), xc, _shape_like(weight, x.shape[1]), None, (1, 1), (d, d), (d, d), False,
+                                                     (0, 0), 1, [False, True, False])[1]
             if gw.shape[1] != weight.shape[1]:
                 gw = gw[:, :weight.shape[1]].contiguous(memory_format=torch.channels_last)
             if gw.dtype != weight.dtype:
                 gw = gw.to(weight.dtype)
         if need_b and gb is None and not b_sink:
-            gb = dz.float().sum((0, 2, 3))
+            gb = for_library(dz).float().sum((0, 2, 3))
         if gb is not None and need_b and bias_dtype != torch.float32:
             gb = gb.to(bias_dtype)
-        return gx, gw, (gb if need_b else None), None, None
+        return gx, gw, (gb if need_b else None), None, None, None
 
 
 class _ConvChainFn(Function):
@@ -778,10 +793,11 @@ def conv3x3_dense_block(parts, convs, negative_slope: float = 0.1, lead_mask_cha
                                *[c.bias for c in convs])
 
 
-def conv3x3_bias_act(x, weight, bias=None, negative_slope: float = 1.0, dilation: int = 1):
+def conv3x3_bias_act(x, weight, bias=None, negative_slope: float = 1.0, dilation: int = 1, out_channels: int = 0):
     """`F.leaky_relu(F.conv2d(x, weight, bias, 1, dilation, dilation), negative_slope)` (negative_slope = 1: no activation) on the
-    implicit-GEMM kernel; the caller checks `eligible` first"""
-    return _ConvBiasActFn.apply(x, weight, bias, float(negative_slope), int(dilation))
+    implicit-GEMM kernel; the caller checks `eligible` first.  out_channels > weight.shape[0]: the result carries that many channels, the
+    ones behind the layer's own zero (see _ConvBiasActFn)"""
+    return _ConvBiasActFn.apply(x, weight, bias, float(negative_slope), int(dilation), int(out_channels))
 
 
 def _native_wgrad() -> bool:

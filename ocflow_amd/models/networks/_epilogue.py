@@ -192,6 +192,32 @@ def conv_lrelu(conv: nn.Conv2d, x, negative_slope: float = 0.1):
     return ops.bias_leaky_relu(_conv_nobias(conv, x), conv.bias, negative_slope)
 
 
+def padded_channels_ok(x) -> bool:
+    """may a layer whose channel count is no multiple of 8 (the PWC encoders' 196) hand on a zero-padded output?  Only where the repo's
+    own kernels consume it: bf16 autocast on a HIP device, channels_last activations (OCFLOW_PAD_ENCODER=0: never)"""
+    return (nconv.enabled() and os.environ.get("OCFLOW_PAD_ENCODER", "1") != "0" and torch.is_tensor(x) and x.is_cuda and x.dim() == 4
+            and x.dtype == torch.bfloat16 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+            and not torch.compiler.is_compiling() and not _unfused())
+
+
+def conv_lrelu_padded(conv: nn.Conv2d, x, negative_slope: float = 0.1):
+    """conv_lrelu whose result carries conv.out_channels rounded up to 8 channels, the extra ones ZERO -- so that the next 3x3 layer (and
+    this layer's own backward) run on ocf_conv3x3_igemm / ocf_conv3x3_wgrad_bias, which read pixels in 16-byte chunks.  With 196 channels
+    the library serves these layers through its slowest solvers: 142 us forward, 170 us input gradient per layer at 16 x 6 x 8 against
+    ~10 us (profiles/r5_cfg3_step_breakdown.txt).  `x` may itself be such a padded tensor.  Falls back to conv_lrelu (plain channels)
+    where the padded form cannot be produced."""
+    cw = int(conv.out_channels)
+    cp = (cw + 7) // 8 * 8
+    if cp == cw or conv.bias is None or conv.padding_mode != "zeros":
+        return conv_lrelu(conv, x, negative_slope)
+    if tuple(conv.stride) == (1, 1) and _native(conv, x):
+        return nconv.conv3x3_bias_act(x, conv.weight, conv.bias, negative_slope, conv.dilation[0], out_channels=cp)
+    y = conv_lrelu(conv, x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x, negative_slope)
+    if ops.concat_channels_eligible([y], cp):
+        return ops.concat_channels([y], cp)  # (one launch: the copy and the zero channels)
+    return y
+
+
 def conv_lrelu_chain(convs, x, negative_slope: float = 0.1):
     """`for conv in convs: x = F.leaky_relu(conv(x), negative_slope)` for layers whose outputs feed only the next one (conv1..conv5 of the
     estimators, flow_net.py:25-37 / flow_occ_net.py:33-45; conv1..conv6 of the context network, context_net.py:20-27).  On the

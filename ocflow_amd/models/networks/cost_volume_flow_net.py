@@ -11,7 +11,7 @@ import os
 
 from ocflow_amd import conv as nconv
 from ocflow_amd import ops
-from ._epilogue import ConvLReLU, cat_aligned, conv_bias, deconv_bias
+from ._epilogue import ConvLReLU, cat_aligned, conv_bias, conv_lrelu_padded, deconv_bias, padded_channels_ok
 
 ENC_WIDTHS = (3, 16, 32, 64, 96, 128, 196)
 DENSE_WIDTHS = (128, 128, 96, 64, 32)
@@ -43,12 +43,21 @@ def build_encoder(net):
 
 
 def encode(net, im):
+    """c1..c6 of one image batch (cost_volume_flow_net.py:158-169).  A level whose channel count is no multiple of 8 (level 6: 196) keeps
+    its activations in tensors rounded up to 8 channels, the extra ones zero, where the repo's kernels consume them (_epilogue.
+    conv_lrelu_padded); the level's feature map is the channel range of the last one"""
     feats = []
     x = im
     for lvl in range(1, 7):
         names = ("a", "aa", "b") if lvl < 6 else ("aa", "a", "b")
         for suffix in names:
-            x = getattr(net, f"conv{lvl}{suffix}")(x)
+            layer = getattr(net, f"conv{lvl}{suffix}")
+            c = layer[0].out_channels
+            if c % 8 and isinstance(layer, ConvLReLU) and padded_channels_ok(x):
+                x = conv_lrelu_padded(layer[0], x, layer[1].negative_slope)
+            else:
+                x = layer(x[:, :layer[0].in_channels] if x.shape[1] != layer[0].in_channels else x)
+        x = x[:, :c] if x.shape[1] != c else x
         feats.append(x)
     return feats  # c1..c6
 

@@ -635,3 +635,44 @@ def test_graph_env_guard_sees_a_runtime_started_without_torchs_lazy_init():
     first = subprocess.run([sys.executable, "-c", "import ocflow_amd, torch; torch.cuda.is_available(); print(ocflow_amd.GRAPH_ENV_LATE)"],
                            capture_output=True, text=True, env=env, cwd=root)
     assert first.returncode == 0 and first.stdout.strip().splitlines()[-1] == "False", (first.stdout, first.stderr[-500:])
+
+
+def test_pwc_encoder_padded_level_is_no_worse_than_the_library(monkeypatch):
+    """level 6 of the PWC encoders has 196 channels; in the bf16 configuration its activations live in 200-channel tensors whose last
+    four channels are zero, so that conv6a / conv6b and their backward run on ocf_conv3x3_igemm / ocf_conv3x3_wgrad_bias
+    (cost_volume_flow_net.encode, _epilogue.conv_lrelu_padded).  Against the fp32 run of the same network and weights: every pyramid
+    level and every parameter gradient of the padded path is as close as the library's bf16 path (OCFLOW_PAD_ENCODER=0)."""
+    from ocflow_amd import conv as nconv
+    from ocflow_amd.models.networks.cost_volume_flow_net import FlowNetCV, encode
+    gen = torch.Generator().manual_seed(33)
+    im = (torch.rand((4, 3, 256, 384), generator=gen) * 2 - 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    runs, launched = {}, {}
+    for tag, env, amp in (("fp32", {}, False), ("padded", {}, True), ("library", {"OCFLOW_PAD_ENCODER": "0"}, True)):
+        monkeypatch.delenv("OCFLOW_PAD_ENCODER", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(0)
+        net = FlowNetCV().to(DEV).to(memory_format=torch.channels_last).train()
+        names = [k for k, p in net.named_parameters() if k.split(".")[0] in {f"conv{l}{s}" for l in range(1, 7) for s in ("a", "aa", "b")}]
+        params = [dict(net.named_parameters())[k] for k in names]
+        seen = []
+        real = nconv.igemm_raw
+        monkeypatch.setattr(nconv, "igemm_raw", lambda x, pk, cout, *a, **k: (seen.append((int(x.shape[1]), int(cout))), real(x, pk, cout, *a, **k))[1])
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            feats = encode(net, im)
+            assert [int(f.shape[1]) for f in feats] == [16, 32, 64, 96, 128, 196]
+            loss = sum((t.float() ** 2).mean() for t in feats) + feats[-1].float().abs().mean()
+        grads = torch.autograd.grad(loss, params)
+        monkeypatch.setattr(nconv, "igemm_raw", real)
+        runs[tag] = ([t.float() for t in feats], [g.float() for g in grads])
+        launched[tag] = seen
+    # the padded run: forward of conv6a / conv6b on 200-channel inputs, and their input gradients (200 -> 200 / 200 -> 200)
+    assert (200, 196) in launched["padded"] and (200, 200) in launched["padded"], launched["padded"]
+    assert not [s for s in launched["library"] if 196 in s or 200 in s]
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    for i, ref in enumerate(runs["fp32"][0]):
+        en, el = rel(runs["padded"][0][i], ref), rel(runs["library"][0][i], ref)
+        assert en <= 1.5 * el + 1e-2, ("pyramid", i, en, el)
+    for k, gn, gl, gr in zip(names, runs["padded"][1], runs["library"][1], runs["fp32"][1]):
+        en, el = rel(gn, gr), rel(gl, gr)
+        assert en <= 1.5 * el + 1e-2, (k, en, el)
