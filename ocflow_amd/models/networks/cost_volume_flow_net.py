@@ -57,7 +57,7 @@ def encode(net, im):
                 x = conv_lrelu_padded(layer[0], x, layer[1].negative_slope)
             else:
                 x = layer(x[:, :layer[0].in_channels] if x.shape[1] != layer[0].in_channels else x)
-        x = x[:, :c] if x.shape[1] != c else x
+        x = ops.unpad_channels(x, c)  # (dense: the feature normalisation and the correlation kernels want whole pixels)
         feats.append(x)
     return feats  # c1..c6
 

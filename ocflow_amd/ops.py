@@ -1072,6 +1072,31 @@ def concat_channels(parts, cout=None):
     return _ConcatFn.apply(cout, *parts)
 
 
+class _UnpadChannelsFn(Function):
+    """x[:, :c] of a zero-padded channels_last tensor as a DENSE channels_last tensor (one copy); backward: the incoming gradient
+    zero-padded back to x's channel count by one ocf_concat_channels launch (autograd's own slice backward is a fill of an
+    NCHW-contiguous tensor plus a strided copy, which the consumer then has to re-layout)"""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.cp = int(x.shape[1])
+        return x[:, :c].contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        if gy.dtype == torch.bfloat16 and ctx.cp % 8 == 0 and concat_channels_eligible([gy], ctx.cp):
+            return _ConcatFn.apply(ctx.cp, gy), None
+        gx = torch.zeros((gy.shape[0], ctx.cp, gy.shape[2], gy.shape[3]), device=gy.device, dtype=gy.dtype).contiguous(memory_format=torch.channels_last)
+        gx[:, :gy.shape[1]] = gy
+        return gx, None
+
+
+def unpad_channels(x, c: int):
+    """the first `c` channels of `x` as a dense channels_last tensor (the inverse of `concat_channels([y], cpad)`)"""
+    return x if x.shape[1] == c else _UnpadChannelsFn.apply(x, int(c))
+
+
 class _HeadLossFn(Function):
     """(mean L1 of the x4 up-sampled flow, mean BCE of the x4 up-sampled occlusion probability) and their gradients w.r.t. the
     quarter-resolution tensors: ocf_flow_occ_head_fwd / _bwd (csrc/head_loss.hip)"""
