@@ -907,10 +907,16 @@ def deconv4x4_eligible(x, weight, stride, padding, dilation, groups, output_padd
 
 
 class _Deconv4x4Fn(Function):
+    """x = channels [0, Ci) of `xfull` (Ci = weight.shape[0]; xfull: the level's dense-block buffer).  The Function takes the WHOLE buffer so
+    that its gradient is a channels_last tensor of the buffer's shape (zero behind Ci, one ocf_concat_channels launch): autograd's own
+    slice backward fills an NCHW-contiguous tensor and copies into it, and every consumer of that sum then re-lays it out -- 65 - 72 us
+    per pass over the 30 MB buffer of level 3, three passes per step (profiles/r5_cfg3_step_breakdown.txt)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        B, ci, H, W = x.shape
-        co = int(weight.shape[1])
+    def forward(ctx, xfull, weight, bias):
+        ci, co = int(weight.shape[0]), int(weight.shape[1])
+        x = xfull[:, :ci]
+        B, _, H, W = x.shape
         y = torch.empty((B, co, 2 * H, 2 * W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
         nb = C.c_int64(0)
         _lib.check(_lib.load().ocf_deconv4x4s2_fwd_workspace_bytes(B, ci, co, H, W, C.byref(nb)), "ocf_deconv4x4s2_fwd_workspace_bytes")
@@ -922,7 +928,7 @@ class _Deconv4x4Fn(Function):
                                                                      int(weight.dtype == torch.float32), _ptr(bf), _t4(y), _ptr(ws), B, ci, co, H, W,
                                                                      _lib.OCF_BF16, _stream(x)), "ocf_deconv4x4s2_fwd")
             ops._launch("deconv4x4s2_fwd", lambda: ops._meta(f"B{B}x{ci}->{co}x{H}x{W}", 2 * B * H * W * (ci + 4 * co), 2 * B * H * W * ci * 16 * co), fn)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(xfull, weight)
         ctx.has_bias = bias is not None
         ctx.bias_dtype = None if bias is None else bias.dtype
         return y
@@ -930,7 +936,9 @@ class _Deconv4x4Fn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        xfull, weight = ctx.saved_tensors
+        ci = int(weight.shape[0])
+        x = xfull[:, :ci]
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         gg = gy if gy.dtype == x.dtype else gy.to(x.dtype)
         gg = gg if gg.is_contiguous(memory_format=torch.channels_last) else gg.contiguous(memory_format=torch.channels_last)
@@ -938,6 +946,14 @@ class _Deconv4x4Fn(Function):
         wb = weight if weight.dtype == x.dtype else weight.to(x.dtype)
         gx, gw, gb = torch.ops.aten.convolution_backward(gg, xc, wb, [int(weight.shape[1])] if ctx.has_bias else None, (2, 2), (1, 1), (1, 1), True,
                                                          (0, 0), 1, [need[0], need[1], bool(need[2])])
+        if gx is not None and xfull.shape[1] != ci:
+            cf = int(xfull.shape[1])
+            if cf % 8 == 0 and ops.concat_channels_eligible([gx], cf):
+                gx = ops._ConcatFn.apply(cf, gx)
+            else:
+                full = torch.zeros(xfull.shape, device=gx.device, dtype=gx.dtype).contiguous(memory_format=torch.channels_last)
+                full[:, :ci] = gx
+                gx = full
         if gw is not None and gw.dtype != weight.dtype:
             gw = gw.to(weight.dtype)
         if gb is not None and ctx.bias_dtype is not None and gb.dtype != ctx.bias_dtype:
@@ -946,7 +962,8 @@ class _Deconv4x4Fn(Function):
 
 
 def deconv4x4s2_bias(x, weight, bias):
-    """`F.conv_transpose2d(x, weight, bias, 2, 1)` for a 4 x 4 kernel and <= 2 output channels; the caller checks `deconv4x4_eligible` first"""
+    """`F.conv_transpose2d(x[:, :weight.shape[0]], weight, bias, 2, 1)` for a 4 x 4 kernel and <= 2 output channels; `x` may be wider than
+    the layer (the dense-block buffer it reads a channel range of); the caller checks `deconv4x4_eligible` on that range first"""
     return _Deconv4x4Fn.apply(x, weight, bias)
 
 

@@ -271,6 +271,20 @@ def deconv_bias(deconv: nn.ConvTranspose2d, x, output_size=None, sigmoid: bool =
     return act(ops.bias_add(y, deconv.bias))
 
 
+def deconv_bias_range(deconv: nn.ConvTranspose2d, x):
+    """deconv_bias on the first deconv.in_channels channels of `x` (the PWC-style `upfeat` layers read the level's dense-block buffer
+    without its alignment channels).  On ocf_deconv4x4s2_fwd the layer takes the whole buffer, so that its gradient comes back as one
+    channels_last tensor of the buffer's shape instead of autograd's NCHW slice backward"""
+    ci = int(deconv.weight.shape[0])
+    if x.shape[1] == ci:
+        return deconv_bias(deconv, x)
+    xs = x[:, :ci]
+    if deconv.bias is not None and deconv.padding_mode == "zeros" and not _unfused() and deconv.output_padding == (0, 0) \
+            and nconv.deconv4x4_eligible(xs, deconv.weight, deconv.stride, deconv.padding, deconv.dilation, deconv.groups, (0, 0)):
+        return nconv.deconv4x4s2_bias(x, deconv.weight, deconv.bias)
+    return deconv_bias(deconv, xs)
+
+
 class ConvLReLU(nn.Sequential):
     """nn.Sequential(nn.Conv2d, nn.LeakyReLU) with the same children / state_dict keys ('0.weight', '0.bias')"""
 

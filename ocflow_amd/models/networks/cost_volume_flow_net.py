@@ -11,7 +11,7 @@ import os
 
 from ocflow_amd import conv as nconv
 from ocflow_amd import ops
-from ._epilogue import ConvLReLU, cat_aligned, conv_bias, conv_lrelu_padded, deconv_bias, padded_channels_ok
+from ._epilogue import ConvLReLU, cat_aligned, conv_bias, conv_lrelu_padded, deconv_bias, deconv_bias_range, padded_channels_ok
 
 ENC_WIDTHS = (3, 16, 32, 64, 96, 128, 196)
 DENSE_WIDTHS = (128, 128, 96, 64, 32)
@@ -190,7 +190,7 @@ class FlowNetCV(nn.Module):
                 if lvl > 2:
                     up_flow = deconv_bias(getattr(self, f"deconv{lvl}"), flow)
                     upf = getattr(self, f"upfeat{lvl}")
-                    up_feat = deconv_bias(upf, feats[:, :upf.weight.shape[0]] if native else feats)
+                    up_feat = deconv_bias_range(upf, feats) if native else deconv_bias(upf, feats)
                 continue
             flow = getattr(self, f"predict_flow{lvl}")(feats)
             if lvl > 2:

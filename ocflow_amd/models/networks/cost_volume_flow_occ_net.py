@@ -7,7 +7,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ._epilogue import cat_aligned, conv_bias, deconv_bias
+from ._epilogue import cat_aligned, conv_bias, deconv_bias, deconv_bias_range
 from .cost_volume_flow_net import (DENSE_TOTAL, DENSE_WIDTHS, ENC_WIDTHS, WARP_SCALE, FlowNetCV, build_context, build_encoder, context,
                                    conv, deconv, dense_block, encode, level_features, predict_flow)
 from .cost_volume_net import CostVolumeLayer
@@ -82,7 +82,7 @@ class FlowOccNetCV(nn.Module):
                 up_flow = getattr(self, f"upflow{lvl}")(flow)
                 up_occ = getattr(self, f"upocc{lvl}")(occ)
                 upf = getattr(self, f"upfeat{lvl}")
-                up_feat = upf(feats[:, :upf.weight.shape[0]]) if native else upf(feats)
+                up_feat = deconv_bias_range(upf, feats) if native else upf(feats)
         flow2 = flow + context(self, feats)
         if not upsample:
             return flow2, occ

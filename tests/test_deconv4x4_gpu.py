@@ -58,7 +58,8 @@ def test_gradients_equal_the_library_layer():
     grads = []
     for ours in (True, False):
         leaf = buf.detach().clone().requires_grad_(True)  # (the layer reads a channel range of a wider buffer, as in the decoder)
-        xx = leaf.permute(0, 3, 1, 2)[:, :ci]
+        full = leaf.permute(0, 3, 1, 2)
+        xx = full if ours else full[:, :ci]  # (ours reads the channel range of the whole buffer and returns the buffer's gradient)
         ww, bb = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
         if ours:
             y = nconv.deconv4x4s2_bias(xx, ww, bb)
