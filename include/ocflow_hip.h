@@ -444,6 +444,12 @@ int ocf_conv3x3s2_c3_wgrad(const ocf_tensor4* x, const ocf_tensor4* gy, float* g
  *           (reference call sites flow_net.py:100-101, flow_occ_net.py:149-150 run the encoder once per image) */
 int ocf_pair_input(const ocf_tensor4* x, void* out, int B, int H, int W, void* stream);
 
+/* ---- bilinear resize of an fp32 image batch without gradient: x [B,C,H,W] -> y [B,C,h,w], both fp32 with any element strides (x may be a
+ * channel slice of the pair tensor); align_corners as torch.nn.functional.interpolate (source index = dst * (H-1)/(h-1), or
+ * max((dst + 0.5) * H/h - 0.5, 0)); one thread per output element, the framework kernel's fp32 arithmetic.
+ * replaces: F.interpolate(img1, scale_factor=0.25, mode="bilinear", align_corners=True) of the PWC unsupervised step (models/model.py:63-69) */
+int ocf_resize_bilinear(const ocf_tensor4* x, const ocf_tensor4* y, int B, int C, int H, int W, int h, int w, int align_corners, void* stream);
+
 /* ---- supervised head of FlowOccModel: x4 bilinear up-sampling (align_corners = False) of the quarter-resolution flow [B,2,h,w] and occlusion
  * probability [B,1,h,w] (bf16 or fp32, any strides; occ_lr / occ_gt may both be NULL), mean L1 against flow_gt fp32 [B,2,4h,4w] and mean
  * binary cross entropy (logs clamped at -100) against occ_gt fp32 [B,1,4h,4w], without the full-resolution predictions in memory.

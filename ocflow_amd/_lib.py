@@ -88,6 +88,7 @@ SIGNATURES = {
                             _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_deconv4x4s2_fwd_workspace_bytes": [_i, _i, _i, _i, _i, C.POINTER(C.c_int64)],
     "ocf_deconv4x4s2_fwd": [_T4P, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _vp, _T4P, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ocf_resize_bilinear": [_T4P, _T4P, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ocf_pair_input": [_T4P, _vp, _i, _i, _i, _vp],
     "ocf_flow_occ_head_fwd": [_T4P, _T4P, _T4P, _T4P, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ocf_flow_occ_head_bwd": [_vp, _vp, _vp, _T4P, _T4P, _i, _i, _i, _i, _i, _vp],

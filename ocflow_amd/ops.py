@@ -1153,6 +1153,21 @@ def flow_occ_head_loss(flow_lr, occ_lr, flow_gt, occ_gt):
     return _HeadLossFn.apply(flow_lr, occ_lr, flow_gt, occ_gt)
 
 
+def resize_bilinear(x, size, align_corners: bool = True):
+    """`F.interpolate(x, size=size, mode="bilinear", align_corners=align_corners)` for an fp32 device tensor that needs no gradient, any
+    strides (ocf_resize_bilinear: one launch, one thread per output element)"""
+    _check4(x, "x")
+    _require_hip(x)
+    if x.dtype != torch.float32 or x.requires_grad:
+        raise ValueError("resize_bilinear: fp32 tensors without gradient only (use F.interpolate)")
+    B, C_, H, W = x.shape
+    h, w = int(size[0]), int(size[1])
+    y = torch.empty((B, C_, h, w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ocf_resize_bilinear(_t4(x), _t4(y), B, C_, H, W, h, w, int(bool(align_corners)), _stream(x)), "ocf_resize_bilinear")
+    return y
+
+
 def pair_input_eligible(x1, x2) -> bool:
     """x1, x2 = channels 0-2 / 3-5 of ONE fp32 [B, 6, H, W] device tensor that needs no gradient (the reference's `inputs[:, 0:3]`,
     `inputs[:, 3:6]`), with bf16 autocast active -- the case `pair_input` serves"""
